@@ -1,0 +1,96 @@
+"""The CPU oracle (oracle/ref_cpu.py) against the goldens produced by the reference's own code
+(tests/golden/make_golden.py).  Runs anywhere torch-CPU is installed."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from video_dqn_amd import synth
+
+
+def test_g1_state_dict_layout(g1):
+    for ec in (True, False):
+        for pano in (True, False):
+            ref = g1[f"ec{int(ec)}_pano{int(pano)}"]
+            m = ref_cpu.HabitatDQNMultiAction(3, 5, extra_capacity=ec, panorama=pano)
+            sd = m.state_dict()
+            assert list(sd.keys()) == ref["keys"]
+            assert [list(v.shape) for v in sd.values()] == ref["shapes"]
+            assert [n for n, _ in m.named_parameters()] == ref["params"]
+            assert len(ref["keys"]) == (250 if ec else 244)
+            # synth.make_state_dict produces the same key set and loads strictly
+            F = 4 if pano else 1
+            s = synth.make_state_dict(3, extra_capacity=ec, num_frames=F)
+            assert list(s.keys()) == ref["keys"]
+            m.load_state_dict(s, strict=True)
+
+
+def test_g2_forward_matches_reference(golden):
+    for ec, pano, B, st in golden["g2_cases"]:
+        ec, pano, st = bool(ec), bool(pano), bool(st)
+        F = 4 if pano else 1
+        m = ref_cpu.HabitatDQNMultiAction(3, 5, extra_capacity=ec, panorama=pano)
+        m.load_state_dict(synth.make_state_dict(11, extra_capacity=ec, num_frames=F))
+        (tup, _) = synth.make_batch(21 + int(B), int(B), F, structured=True)
+        mode = "set_train" if st else "eval"
+        m.set_train() if st else m.eval()
+        with torch.no_grad():
+            q = m(tup[0]).numpy()
+        ref = golden[f"g2_q_ec{int(ec)}_pano{int(pano)}_B{int(B)}_{mode}"]
+        assert q.shape == ref.shape == (int(B), 5, 3)
+        np.testing.assert_allclose(q, ref, rtol=1e-5, atol=1e-6)
+        bn = [int(mod.training) for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+        assert bn == list(golden[f"g2_bntrain_ec{int(ec)}_pano{int(pano)}_B{int(B)}_{mode}"])
+
+
+def test_g3_td_steps_match_reference(golden):
+    torch.set_num_threads(8)
+    cfg = ref_cpu.default_config()
+    tr = ref_cpu.Trainer(cfg, synth.make_state_dict(7))
+    tr.target_net.load_state_dict(synth.make_state_dict(8))
+    names = [n for n, _ in tr.model.named_parameters()]
+    assert names == list(golden["g3_param_names"])
+    for step in (1, 2, 3):
+        (tup, _) = synth.make_batch(100 + step, 8, 1, structured=True, reward_p=0.3)
+        d = {}
+        loss = tr.step(tup, d)
+        np.testing.assert_allclose(loss, float(golden[f"g3_loss_s{step}"]), rtol=1e-5)
+        np.testing.assert_allclose(d["before_values"].detach().numpy(), golden[f"g3_qbefore_s{step}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(d["after_values"].numpy(), golden[f"g3_qafter_target_s{step}"], rtol=1e-4, atol=1e-6)
+        for n, p in tr.model.named_parameters():
+            if p.grad is None:
+                assert f"g3_gradnone_{n}" in golden.files
+                continue
+            g = p.grad.flatten()
+            idx = synth.randint(1234, "idx." + n, (min(16, g.numel()),), g.numel())
+            amax = float(golden[f"g3_gabsmax_s{step}_{n}"])
+            np.testing.assert_allclose(g[idx].numpy(), golden[f"g3_gsamp_s{step}_{n}"], rtol=1e-3, atol=1e-5 * amax)
+            np.testing.assert_allclose(g.double().norm().item(), float(golden[f"g3_gnorm_s{step}_{n}"]), rtol=1e-4)
+    assert int(golden["g3_bn_unchanged"]) == 1
+    ost = tr.optimizer.state_dict()
+    assert list(golden["g3_opt_param_ids"]) == ost["param_groups"][0]["params"]
+    assert list(golden["g3_opt_state_ids"]) == sorted(ost["state"].keys())
+    assert "g3_gradnone_resnet.fc.weight" in golden.files and "g3_gradnone_resnet.fc.bias" in golden.files
+
+
+def _g4_inputs(s, Bq=6, A=3):
+    qb = torch.from_numpy(synth.uniform(s, "qb", (Bq, 5, A), -1.0, 2.0))
+    qo = torch.from_numpy(synth.uniform(s, "qo", (Bq, 5, A), -1.0, 2.0))
+    qt = torch.from_numpy(synth.uniform(s, "qt", (Bq, 5, A), -1.0, 2.0))
+    qo[0, 0, :] = 1.0
+    qo[1, 1, 1:] = 3.0
+    act = torch.from_numpy(synth.randint(s, "act", (Bq,), A))
+    rew = torch.from_numpy((synth.uniform(s, "rew", (Bq, 5)) < 0.4).astype(np.int64))
+    vm = torch.from_numpy((synth.uniform(s, "vm", (Bq, 5)) < 0.7).astype(np.int64))
+    return qb, qo, qt, act, rew, rew.clone(), vm
+
+
+def test_g4_loss_branches_match_reference(golden):
+    for cid, clip, linear, rbr, gamma, s in golden["g4_cases"]:
+        cfg = ref_cpu.default_config(LOSS_CLIP=("none", "rect", "sigmoid")[int(clip)], LINEAR=bool(linear),
+                                     REMOVE_BEFORE_REWARD=bool(rbr), GAMMA=float(gamma))
+        qb, qo, qt, act, rew, term, vm = _g4_inputs(int(s))
+        loss, dq, best, y = ref_cpu.td_loss_from_q(qb, qo, qt, act, rew, term, vm, cfg)
+        np.testing.assert_allclose(loss.item(), float(golden[f"g4_loss_{int(cid)}"]), rtol=1e-6)
+        np.testing.assert_allclose(dq.numpy(), golden[f"g4_dq_{int(cid)}"], rtol=1e-6, atol=1e-8)
+        assert best[0, 0].item() == 0 and best[1, 1].item() == 1  # first max wins
