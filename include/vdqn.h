@@ -1,0 +1,228 @@
+/*
+ * vdqn.h — C ABI of libvdqn.so, the MI355X (gfx950) implementation of the Q-learning hot path of
+ * uiuc-robovision/video-dqn (train_q_network.py's inner loop).
+ *
+ * The reference is pure Python on PyTorch: it has no FFI of its own.  Every entry point below names the
+ * reference call site (file:line under the reference tree) whose arithmetic it replaces; the reference-side
+ * binding a maintainer would add is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless a name ends in _host;
+ *   - the caller owns every buffer (the library allocates nothing on the device except inside an explicit
+ *     vdqn_net_create/vdqn_net_destroy pair, which holds host-side descriptors only);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no host sync;
+ *   - return value 0 = ok, negative = error (vdqn_last_error() gives the text); no exceptions cross the ABI;
+ *   - activations are NHWC; `dtype` selects the storage/compute type of activations and packed weights:
+ *       VDQN_F32  : f32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)   — the parity mode
+ *       VDQN_BF16 : bf16 storage, v_mfma_f32_16x16x32_bf16, f32 accumulate — the throughput mode
+ *     master parameters, gradients, Adam state and Q-values are always f32.
+ */
+#ifndef VDQN_H_
+#define VDQN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDQN_F32 0
+#define VDQN_BF16 1
+
+#define VDQN_OK 0
+#define VDQN_ERR_INVALID (-1)
+#define VDQN_ERR_LAUNCH (-2)
+
+/* thread-local text of the last error returned on this host thread */
+const char* vdqn_last_error(void);
+/* ABI version; bumped on any signature change */
+int vdqn_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator level (each is also what the engine below launches).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Implicit-GEMM convolution / linear layer, forward or data-gradient.
+ *   out[m, n] = epilogue( sum_{r,s,c} in[pix(m,r,s), c] * wt[n][r][s][c] )
+ *   mode 0 (forward gather):  hi = ho*stride - pad + r,           wi likewise
+ *   mode 1 (dgrad gather):    hi = (ho + pad - r) / stride if divisible and in range (transposed conv)
+ *   epilogue: v += bias[n]; v += resid[m,n]; relu; v = mask[m,n] > 0 ? v : 0   (each optional)
+ * Replaces: torch conv2d/linear (+ folded eval BatchNorm, ReLU, residual add) reached from
+ * archs/HabitatDQNMultiAction.py:30-31,49-53 and their autograd backward (train_q_network.py:226).
+ * `ci` must be a multiple of 128 bytes / sizeof(elem); `wt` holds co_pad = roundup(co, 64 or 128) rows. */
+typedef struct vdqn_conv_args {
+  const void* in;      /* [n_img][hi][wi] pixels of pix_stride elems */
+  const void* wt;      /* [co_pad][r][s][ci], K-contiguous */
+  const float* bias;   /* [co_pad] or NULL */
+  const void* resid;   /* [m][ldo] or NULL */
+  const void* mask;    /* [m][ldo] or NULL */
+  void* out;           /* [m][ldo], dtype; may be NULL if out_f32 is given */
+  float* out_f32;      /* optional f32 copy of the result [m][ldo] */
+  int32_t n_img, hi, wi, ci, pix_stride;
+  int32_t ho, wo, co, ldo;
+  int32_t r, s, stride, pad;
+  int32_t mode, relu, dtype;
+} vdqn_conv_args;
+int vdqn_conv2d(const vdqn_conv_args* a, void* stream);
+
+/* Weight gradient of the same layer:  dw[n][r][s][c] += sum_m gy[m, n] * x[pix(m,r,s), c]
+ * (f32 atomics into a pre-zeroed dw; split over `splitk` pixel ranges).  If dbias != NULL it also
+ * accumulates dbias[n] += sum_m gy[m, n].
+ * Replaces: the convolution_backward/addmm weight-gradient kernels behind loss.backward(),
+ * train_q_network.py:226. */
+typedef struct vdqn_wgrad_args {
+  const void* gy;   /* [m][ldg] gradient w.r.t. the layer output (already ReLU-masked) */
+  const void* x;    /* layer input, as vdqn_conv_args.in */
+  float* dw;        /* [co_pad][r][s][ci] f32, pre-zeroed */
+  float* dbias;     /* [co_pad] f32, pre-zeroed, or NULL */
+  int32_t n_img, hi, wi, ci, pix_stride;
+  int32_t ho, wo, co, ldg;
+  int32_t r, s, stride, pad;
+  int32_t splitk, dtype;
+} vdqn_wgrad_args;
+int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream);
+
+/* Input packing: normalise + space-to-depth the 224x224 RGB frames into the conv1 operand
+ * [n][115][115][16] (2x2x3 -> 12 channels + 4 zero, 2-pixel zero border top/left, 1 bottom/right), so the
+ * 7x7/2 stem is a 4x4/1 implicit GEMM with 128-byte contiguous K rows.
+ *   src_kind 0: uint8 NHWC [n][224][224][3]  -> (x/255 - mean)/std   (util/torch.py:5-12, :26-36)
+ *   src_kind 1: f32 NCHW [n][3][224][224] already normalised (the tensor process_batch moves to the
+ *               device, train_q_network.py:127-129) */
+int vdqn_pack_input(const void* src, int32_t src_kind, void* dst, int32_t n_img, int32_t dtype, void* stream);
+
+/* 3x3/2 pad 1 max-pool, NHWC (torchvision resnet stem; archs/HabitatDQNMultiAction.py:30). idx[m][c] stores
+ * the arg-max tap (kh*3+kw, first maximum wins as in torch). */
+int vdqn_maxpool_fwd(const void* in, void* out, uint8_t* idx, int32_t n_img, int32_t hi, int32_t wi, int32_t c,
+                     int32_t dtype, void* stream);
+/* gx[n,h,w,c] = (x[n,h,w,c] > 0) * sum over windows whose arg-max is (h,w) of gy  (pool + ReLU backward) */
+int vdqn_maxpool_bwd(const void* gy, const uint8_t* idx, const void* x, void* gx, int32_t n_img, int32_t hi,
+                     int32_t wi, int32_t c, int32_t dtype, void* stream);
+
+/* Fused Double-DQN target + TD loss + dLoss/dQ  (train_q_network.py:134-169,180).
+ *   Qb = q_before[b,c,act[b]]; a* = argmax_a q_after_online[b,c,:] (first max); Qa = q_after_target[b,c,a*]
+ *   Qa *= (1 - term); y = linear ? rew + (Qa - 0.1) : rew + gamma*Qa; rect clip -> clamp(y,0,1)
+ *   l = 0.5 (Qb - y)^2 (* valid if use_valid); loss += inv_count * sum l;
+ *   dq[b, c*A+a] = (a == act[b]) ? (Qb - y) * (valid) * inv_count : 0   (rows of ldq elems, zero padded)
+ * q_* are f32 [batch][ldq]; act i64; rew/term/valid f32 [batch][n_cat]; loss is a pre-zeroed f32 scalar. */
+typedef struct vdqn_td_args {
+  const float* q_before;
+  const float* q_after_online;
+  const float* q_after_target;
+  const int64_t* act;
+  const float* rew;
+  const float* term;
+  const float* valid;
+  float* loss;
+  void* dq;         /* [batch][ldq] dtype */
+  float* dq_f32;    /* optional [batch][ldq] */
+  int32_t batch, n_cat, n_act, ldq;
+  float gamma, inv_count;
+  int32_t clip_rect, linear, use_valid, dtype;
+} vdqn_td_args;
+int vdqn_td_loss(const vdqn_td_args* a, void* stream);
+
+/* Ground-truth branch (train_q_network.py:170-178): l = 0.5 (Qb*mask - gt)^2, mask = !isnan(gt) when
+ * value_learning, else l = 0.5 (Qb - gt)^2.  gt is f32 [batch][n_cat] (NaN allowed). */
+int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, float* loss, void* dq, float* dq_f32,
+                 int32_t batch, int32_t n_cat, int32_t n_act, int32_t ldq, float inv_count, int32_t value_learning,
+                 int32_t dtype, void* stream);
+
+/* torch.optim.Adam step (train_q_network.py:124,227) over one flat f32 range:
+ *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
+int vdqn_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1,
+              float beta2, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Engine level: the whole HabitatDQNMultiAction network and one TD update.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vdqn_net_config {
+  int32_t action_dim;      /* A: 3, or 1 for VALUE_LEARNING/ONE_ACTION (train_q_network.py:38-41) */
+  int32_t num_classes;     /* 5 */
+  int32_t num_frames;      /* F: 1, or 4 for PANORAMA/PREVIOUS_IMAGES (archs/...:16-19); any F >= 1 accepted */
+  int32_t extra_capacity;  /* ARCHITECTURE == 'extra_capacity' (only 1 is implemented in this round) */
+  int32_t dtype;           /* VDQN_F32 | VDQN_BF16 */
+  int32_t max_batch;       /* largest per-call sample count B the workspaces are sized for */
+} vdqn_net_config;
+
+typedef struct vdqn_net vdqn_net;
+
+int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out);
+void vdqn_net_destroy(vdqn_net* net);
+
+/* Parameter table: the reference's named_parameters()/buffers as slices of two flat f32 arrays.
+ * kind: 0 trainable parameter (offset into `params`, gradient/Adam state at the same offset),
+ *       1 frozen parameter (resnet.fc.*: never receives a gradient; stored after the trainable range),
+ *       2 BatchNorm running_mean, 3 running_var (offsets into `bnstats`).
+ * `param_id` is the index in the reference's model.parameters() order (Adam state_dict ids). */
+typedef struct vdqn_param_info {
+  char name[96];
+  int64_t offset;
+  int64_t numel;
+  int32_t ndim;
+  int32_t shape[4];
+  int32_t kind;
+  int32_t param_id;
+  int32_t stage;     /* backward stage (0 head+layer4, 1 layer3, 2 layer2+layer1+stem) that completes its grad */
+} vdqn_param_info;
+int vdqn_net_num_params(const vdqn_net* net);
+int vdqn_net_param_info(const vdqn_net* net, int index, vdqn_param_info* out);
+int64_t vdqn_net_params_numel(const vdqn_net* net);     /* total flat params (trainable + frozen) */
+int64_t vdqn_net_trainable_numel(const vdqn_net* net);  /* prefix that has gradients / Adam state */
+int64_t vdqn_net_bnstats_numel(const vdqn_net* net);
+/* [begin,end) of the flat gradient completed by backward stage s (for bucketed all-reduce) */
+int vdqn_net_stage_range(const vdqn_net* net, int stage, int64_t* begin, int64_t* end);
+
+/* Workspace sizes in bytes.  packed = folded/packed weights of ONE network instance (online or target);
+ * acts = activations of one forward over `n_samples` samples; bwd = gradient workspaces of one backward. */
+int64_t vdqn_net_packed_bytes(const vdqn_net* net);
+int64_t vdqn_net_acts_bytes(const vdqn_net* net, int32_t n_samples);
+int64_t vdqn_net_bwd_bytes(const vdqn_net* net, int32_t n_samples);
+
+/* Fold eval-mode BatchNorm into the convolutions and pack the master weights (OIHW f32) into the K-contiguous
+ * forward and data-gradient operands (set_train semantics: archs/HabitatDQNMultiAction.py:37-40 — in
+ * extra_capacity all 20 BatchNorm layers run on running statistics). */
+int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad,
+                          void* stream);
+
+/* Forward of `n_samples` samples (n_samples * F frames).  frames: see vdqn_pack_input (src_kind).
+ * q_out: f32 [n_samples][num_classes*action_dim] (HabitatDQNMultiAction.forward, archs/...:44-54). */
+int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples,
+                     void* acts, float* q_out, void* stream);
+
+/* One TD update's device work up to the flat gradient (train_q_network.py:222-226):
+ *   online forward over [before; after] (2B samples, one pass — legal because BatchNorm is in eval mode),
+ *   target forward over after, fused TD loss, full backward of the `before` half.
+ * Split in calls so the host can overlap the gradient all-reduce of stage s with backward stage s+1:
+ *   vdqn_net_td_forward -> vdqn_net_backward_stage(0..2)  (-> all-reduce) -> vdqn_adam on the flat range. */
+typedef struct vdqn_step_args {
+  const float* params;        /* online master parameters (flat) */
+  const float* bnstats;
+  void* packed_online;        /* workspace: vdqn_net_packed_bytes */
+  const void* packed_target;  /* packed target-network weights (refreshed by the caller on target sync) */
+  const void* before;         /* frames of s  : [B][F] frames, src_kind layout */
+  const void* after;          /* frames of s' */
+  int32_t src_kind;
+  int32_t batch;              /* B (per rank) */
+  const int64_t* act;
+  const float* rew;
+  const float* term;
+  const float* valid;
+  const float* gt;            /* ground-truth targets [B][5] when train_on_ground_truth, else NULL */
+  float gamma;
+  float inv_count;            /* 1 / (num_classes * global_batch) */
+  int32_t clip_rect, linear, use_valid, train_on_ground_truth, value_learning;
+  void* acts_online;          /* vdqn_net_acts_bytes(2B) */
+  void* acts_target;          /* vdqn_net_acts_bytes(B)  */
+  void* bwd;                  /* vdqn_net_bwd_bytes(B)   */
+  float* grads;               /* flat f32 [trainable_numel] */
+  float* loss;                /* f32 scalar (device) */
+  float* q_before;            /* optional f32 [B][15] copy of Q(s) */
+} vdqn_step_args;
+int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream);
+int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDQN_H_ */

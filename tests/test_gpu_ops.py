@@ -1,0 +1,264 @@
+"""Per-kernel parity: every HIP operator (through the C ABI) against the torch-CPU fp32 op it replaces.
+f32 mode gates at 1e-3 relative (north_star tolerance); bf16 mode is checked against the same reference with
+bf16-rounded operands at a bf16-appropriate tolerance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from video_dqn_amd import synth  # noqa: E402
+
+DEV = "cuda"
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+
+
+def rnd(seed, name, shape, lo=-1.0, hi=1.0):
+    return torch.from_numpy(synth.uniform(seed, name, shape, lo, hi))
+
+
+def q(t, dtype):
+    """round a CPU f32 tensor to the compute dtype (so the reference sees the same operands)"""
+    return t.to(dtype).float()
+
+
+def nhwc(t, dtype):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def krsc(w, dtype, co_pad=None):
+    co = w.shape[0]
+    co_pad = co_pad or (co + 63) // 64 * 64
+    o = torch.zeros((co_pad,) + tuple(w.permute(0, 2, 3, 1).shape[1:]), dtype=torch.float32)
+    o[:co] = w.permute(0, 2, 3, 1)
+    return o.contiguous().to(dtype).to(DEV)
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+CONV_CASES = [
+    # n, ci, co, h, k, stride, pad
+    (2, 64, 64, 12, 3, 1, 1),
+    (3, 64, 128, 14, 3, 2, 1),
+    (2, 128, 128, 9, 3, 1, 1),
+    (2, 64, 128, 14, 1, 2, 0),
+    (2, 256, 512, 7, 3, 2, 1),
+    (3, 512, 64, 7, 3, 1, 0),
+    (1, 128, 256, 28, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case, dtype):
+    from video_dqn_amd import ops
+    n, ci, co, h, k, stride, pad = case
+    x = q(rnd(1, "x", (n, ci, h, h)), dtype)
+    w = q(rnd(2, "w", (co, ci, k, k), -0.1, 0.1), dtype)
+    b = rnd(3, "b", (co,))
+    ho = (h + 2 * pad - k) // stride + 1
+    res = q(rnd(4, "r", (n, co, ho, ho)), dtype)
+    ref = F.relu(F.conv2d(x, w, b, stride, pad) + res)
+    out = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=ho, wo=ho, co=co, r=k, s=k, stride=stride, pad=pad,
+                     bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert relerr(got, ref) < TOL[dtype]
+    # no-epilogue variant + f32 copy
+    ref2 = F.conv2d(x, w, None, stride, pad)
+    out2, out2f = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=ho, wo=ho, co=co, r=k, s=k, stride=stride, pad=pad, want_f32=True)
+    assert relerr(out2f.cpu().permute(0, 3, 1, 2), ref2) < (1e-3 if dtype == torch.float32 else 5e-3)
+    assert relerr(out2.float().cpu().permute(0, 3, 1, 2), ref2) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad(case, dtype):
+    """gx = mask(x>0) * (conv_transpose(gy, w) + resid)"""
+    from video_dqn_amd import ops
+    n, ci, co, h, k, stride, pad = case
+    ho = (h + 2 * pad - k) // stride + 1
+    w = q(rnd(2, "w", (co, ci, k, k), -0.1, 0.1), dtype)
+    gy = q(rnd(5, "gy", (n, co, ho, ho)), dtype)
+    xact = q(rnd(6, "xa", (n, ci, h, h)), dtype)
+    res = q(rnd(7, "res", (n, ci, h, h)), dtype)
+    ref = F.grad.conv2d_input((n, ci, h, h), w, gy, stride, pad)
+    ref = (ref + res) * (xact > 0)
+    wd = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)  # [ci][r][s][co]
+    got = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=h, co=ci, r=k, s=k, stride=stride, pad=pad, mode=1,
+                     resid=nhwc(res, dtype), mask=nhwc(xact, dtype))
+    torch.cuda.synchronize()
+    assert relerr(got.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES + [(5, 64, 64, 20, 3, 1, 1)])
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_conv_wgrad(case, dtype, splitk):
+    from video_dqn_amd import ops
+    n, ci, co, h, k, stride, pad = case
+    ho = (h + 2 * pad - k) // stride + 1
+    x = q(rnd(1, "x", (n, ci, h, h)), dtype)
+    gy = q(rnd(5, "gy", (n, co, ho, ho)), dtype)
+    ref = F.grad.conv2d_weight(x, (co, ci, k, k), gy, stride, pad)
+    dw, db = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), co=co, r=k, s=k, stride=stride, pad=pad, splitk=splitk)
+    torch.cuda.synchronize()
+    got = dw.cpu()[:co].permute(0, 3, 1, 2)
+    assert relerr(got, ref) < (1e-3 if dtype == torch.float32 else 5e-3)
+    assert relerr(db.cpu()[:co], gy.sum((0, 2, 3))) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_fwd_bwd(dtype):
+    """Linear layers are 1x1 convolutions on a 1x1 image; out features padded to 64 columns (15 -> 64)."""
+    from video_dqn_amd import ops
+    B, fin, fout = 37, 256, 15
+    x = q(rnd(1, "x", (B, fin)), dtype)
+    w = q(rnd(2, "w", (fout, fin), -0.1, 0.1), dtype)
+    b = rnd(3, "b", (fout,))
+    ref = F.linear(x, w, b)
+    wp = torch.zeros((64, fin)); wp[:fout] = w
+    bp = torch.zeros(64); bp[:fout] = b
+    xd = x.view(B, 1, 1, fin).to(dtype).to(DEV)
+    out, outf = ops.conv2d(xd, wp.view(64, 1, 1, fin).to(dtype).to(DEV), ho=1, wo=1, co=64, r=1, s=1, stride=1, pad=0,
+                           bias=bp.to(DEV), want_f32=True)
+    torch.cuda.synchronize()
+    assert relerr(outf.cpu().view(B, 64)[:, :fout], ref) < (1e-3 if dtype == torch.float32 else 5e-3)
+    assert outf.cpu().view(B, 64)[:, fout:].abs().max().item() == 0.0
+    # dgrad: gx = gy @ W   (gy padded to 64 columns)
+    gy = q(rnd(5, "gy", (B, fout)), dtype)
+    gyp = torch.zeros((B, 64)); gyp[:, :fout] = gy
+    wd = torch.zeros((fin, 64)); wd[:, :fout] = w.t()
+    gx = ops.conv2d(gyp.view(B, 1, 1, 64).to(dtype).to(DEV), wd.view(fin, 1, 1, 64).to(dtype).to(DEV), ho=1, wo=1, co=fin,
+                    r=1, s=1, stride=1, pad=0, mode=1)
+    dw, db = ops.conv2d_wgrad(gyp.view(B, 1, 1, 64).to(dtype).to(DEV), xd, co=fout, r=1, s=1, stride=1, pad=0)
+    torch.cuda.synchronize()
+    assert relerr(gx.float().cpu().view(B, fin), gy @ w) < TOL[dtype]
+    assert relerr(dw.cpu().view(64, fin)[:fout], gy.t() @ x) < (1e-3 if dtype == torch.float32 else 5e-3)
+    assert relerr(db.cpu()[:fout], gy.sum(0)) < 1e-3
+
+
+def s2d_weights(w7, dtype):
+    """conv1 [64,3,7,7] -> space-to-depth operand [64][4][1][64] (k = a*64 + j*16 + (bh*2+bw)*3 + c)."""
+    wp = torch.zeros((64, 4, 4, 16))
+    for a in range(4):
+        for bh in range(2):
+            r7 = 2 * a + bh - 1
+            if r7 < 0:
+                continue
+            for j in range(4):
+                for bw in range(2):
+                    s7 = 2 * j + bw - 1
+                    if s7 < 0:
+                        continue
+                    for c in range(3):
+                        wp[:, a, j, (bh * 2 + bw) * 3 + c] = w7[:, c, r7, s7]
+    return wp.reshape(64, 4, 1, 64).to(dtype).to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("src_kind", [0, 1])
+def test_stem_pack_conv1_maxpool(dtype, src_kind):
+    from video_dqn_amd import ops
+    n = 2
+    frames = synth.make_frames_uint8(3, "f", n, 1, structured=True)
+    xn = synth.normalise_frames(frames)  # [n,3,224,224] f32
+    src = torch.from_numpy(frames[:, 0]).to(DEV) if src_kind == 0 else xn.contiguous().to(DEV)
+    packed = ops.pack_input(src, src_kind, n, dtype)
+    w7 = q(rnd(2, "w7", (64, 3, 7, 7), -0.2, 0.2), dtype)
+    b = rnd(3, "b", (64,))
+    c1 = ops.conv2d(packed, s2d_weights(w7, dtype), ho=112, wo=112, co=64, r=4, s=1, stride=1, pad=0, bias=b.to(DEV),
+                    relu=True, ci=64, pix_stride=16)
+    torch.cuda.synchronize()
+    xq = q(xn, dtype)
+    ref = F.relu(F.conv2d(xq, w7, b, 2, 3))
+    assert relerr(c1.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    # max-pool forward on the exact device tensor (so ties/rounding are identical)
+    c1_cpu = c1.float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    pref = F.max_pool2d(c1_cpu, 3, 2, 1)
+    pool, idx = ops.maxpool_fwd(c1)
+    torch.cuda.synchronize()
+    assert torch.equal(pool.float().cpu().permute(0, 3, 1, 2), pref.detach())
+    # backward: gx = relu'(c1) * unpool(gy)
+    gy = q(rnd(9, "gy", tuple(pref.shape)), dtype)
+    pref.backward(gy)
+    gref = c1_cpu.grad * (c1_cpu.detach() > 0)
+    gx = ops.maxpool_bwd(nhwc(gy, dtype), idx, c1)
+    torch.cuda.synchronize()
+    assert relerr(gx.float().cpu().permute(0, 3, 1, 2), gref) < (1e-6 if dtype == torch.float32 else 1e-2)
+    # conv1 weight gradient through the s2d operand
+    g1 = q(rnd(10, "g1", (n, 64, 112, 112), -1, 1), dtype)
+    dw = ops.conv2d_wgrad(nhwc(g1, dtype), packed, co=64, r=4, s=1, stride=1, pad=0, ci=64, pix_stride=16, want_dbias=False)
+    torch.cuda.synchronize()
+    wref = F.grad.conv2d_weight(xq, (64, 3, 7, 7), g1, 2, 3)
+    dws = dw.cpu().view(64, 4, 4, 16)
+    got = torch.zeros_like(wref)
+    for a in range(4):
+        for bh in range(2):
+            for j in range(4):
+                for bw in range(2):
+                    r7, s7 = 2 * a + bh - 1, 2 * j + bw - 1
+                    if r7 >= 0 and s7 >= 0:
+                        got[:, :, r7, s7] = dws[:, a, j, (bh * 2 + bw) * 3:(bh * 2 + bw) * 3 + 3]
+    assert relerr(got, wref) < (1e-3 if dtype == torch.float32 else 5e-3)
+
+
+def test_td_loss_branches_vs_golden(golden):
+    """The fused TD kernel against the goldens produced by the reference's own process_batch statements."""
+    from video_dqn_amd import ops
+    from helpers import g4_inputs
+    for cid, clip, linear, rbr, gamma, s in golden["g4_cases"]:
+        qb, qo, qt, act, rew, term, vm = g4_inputs(int(s))
+        B = qb.shape[0]
+
+        def pad(t):
+            o = torch.zeros((B, 64)); o[:, :15] = t.reshape(B, 15)
+            return o.to(DEV)
+        loss, dq, dq32 = ops.td_loss(pad(qb), pad(qo), pad(qt), act.to(DEV), rew.float().to(DEV), term.float().to(DEV),
+                                     vm.float().to(DEV) if rbr else None, gamma=float(gamma), clip_rect=(int(clip) == 1),
+                                     linear=bool(linear))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(loss.item(), float(golden[f"g4_loss_{int(cid)}"]), rtol=2e-6)
+        got = dq32.cpu()[:, :15].reshape(B, 5, 3).numpy()
+        np.testing.assert_allclose(got, golden[f"g4_dq_{int(cid)}"], rtol=1e-5, atol=1e-8)
+        assert dq32.cpu()[:, 15:].abs().max().item() == 0.0
+    # ground-truth branches
+    for vl in (0, 1):
+        s = 900 + vl
+        qb = torch.from_numpy(synth.uniform(s, "qb", (6, 5, 3), -1.0, 2.0))
+        act = torch.from_numpy(synth.randint(s, "act", (6,), 3))
+        gtv = synth.uniform(s, "gt", (6, 5), 0.0, 1.0).astype(np.float64)
+        if vl:
+            gtv[synth.uniform(s, "nan", (6, 5)) < 0.3] = np.nan
+        o = torch.zeros((6, 64)); o[:, :15] = qb.reshape(6, 15)
+        loss, dq32 = ops.gt_loss(o.to(DEV), act.to(DEV), torch.from_numpy(gtv).float().to(DEV), value_learning=bool(vl))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(loss.item(), float(golden[f"g4gt_loss_{vl}"]), rtol=2e-6)
+        np.testing.assert_allclose(dq32.cpu()[:, :15].reshape(6, 5, 3).numpy(), golden[f"g4gt_dq_{vl}"], rtol=1e-5, atol=1e-8)
+
+
+def test_adam_matches_torch():
+    from video_dqn_amd import ops
+    n = 100003
+    p0 = rnd(1, "p", (n,))
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt], lr=1e-4)
+    p = torch.zeros(n + 1)[:n].copy_(p0).to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        g = rnd(10 + step, "g", (n,), -1e-3, 1e-3)
+        g[::7] = 0.0
+        pt.grad = g.clone()
+        opt.step()
+        ops.adam(p, g.to(DEV), m, v, step, 1e-4)
+        torch.cuda.synchronize()
+        d_ref = pt.detach() - p0
+        d_got = p.cpu() - p0
+        assert (d_got - d_ref).abs().max().item() < 2e-3 * 1e-4 * step  # 0.2 % of one lr-sized step
+        st = opt.state[pt]
+        assert relerr(m, st["exp_avg"]) < 1e-6 and relerr(v, st["exp_avg_sq"]) < 1e-6

@@ -6,6 +6,7 @@ import torch
 
 from oracle import ref_cpu
 from video_dqn_amd import synth
+from helpers import g4_inputs
 
 
 def test_g1_state_dict_layout(g1):
@@ -73,23 +74,11 @@ def test_g3_td_steps_match_reference(golden):
     assert "g3_gradnone_resnet.fc.weight" in golden.files and "g3_gradnone_resnet.fc.bias" in golden.files
 
 
-def _g4_inputs(s, Bq=6, A=3):
-    qb = torch.from_numpy(synth.uniform(s, "qb", (Bq, 5, A), -1.0, 2.0))
-    qo = torch.from_numpy(synth.uniform(s, "qo", (Bq, 5, A), -1.0, 2.0))
-    qt = torch.from_numpy(synth.uniform(s, "qt", (Bq, 5, A), -1.0, 2.0))
-    qo[0, 0, :] = 1.0
-    qo[1, 1, 1:] = 3.0
-    act = torch.from_numpy(synth.randint(s, "act", (Bq,), A))
-    rew = torch.from_numpy((synth.uniform(s, "rew", (Bq, 5)) < 0.4).astype(np.int64))
-    vm = torch.from_numpy((synth.uniform(s, "vm", (Bq, 5)) < 0.7).astype(np.int64))
-    return qb, qo, qt, act, rew, rew.clone(), vm
-
-
 def test_g4_loss_branches_match_reference(golden):
     for cid, clip, linear, rbr, gamma, s in golden["g4_cases"]:
         cfg = ref_cpu.default_config(LOSS_CLIP=("none", "rect", "sigmoid")[int(clip)], LINEAR=bool(linear),
                                      REMOVE_BEFORE_REWARD=bool(rbr), GAMMA=float(gamma))
-        qb, qo, qt, act, rew, term, vm = _g4_inputs(int(s))
+        qb, qo, qt, act, rew, term, vm = g4_inputs(int(s))
         loss, dq, best, y = ref_cpu.td_loss_from_q(qb, qo, qt, act, rew, term, vm, cfg)
         np.testing.assert_allclose(loss.item(), float(golden[f"g4_loss_{int(cid)}"]), rtol=1e-6)
         np.testing.assert_allclose(dq.numpy(), golden[f"g4_dq_{int(cid)}"], rtol=1e-6, atol=1e-8)

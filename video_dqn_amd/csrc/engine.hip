@@ -1,0 +1,778 @@
+// The network engine: HabitatDQNMultiAction (ResNet-18 trunk + extra_capacity head) as a static layer
+// table, BatchNorm-eval folding / weight packing, forward, and the staged backward of one TD update.
+//
+// Follows: archs/HabitatDQNMultiAction.py:9-54 (wiring, set_train: trunk BatchNorm in eval mode),
+// torchvision 0.4.2 resnet18 topology (third-party; restated in oracle/ref_cpu.py),
+// train_q_network.py:126-181 (process_batch) and :222-227 (zero_grad / backward / step order).
+//
+// BatchNorm-eval is folded into the packed weights:  y = conv(x, W * s) + (beta - mean * s),  s = gamma * rstd.
+// Its parameter gradients need no saved conv output:  with dW' = dL/d(W*s) (what the wgrad kernel produces)
+//   dL/dW = dW' * s,   dL/dbeta = sum(gy),   dL/dgamma = rstd * ( <dW'[co,:], W[co,:]> - mean * dL/dbeta ).
+#include <math.h>
+#include <stdarg.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// error text (thread local)
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vdqn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* vdqn_last_error(void) { return g_err; }
+extern "C" int vdqn_abi_version(void) { return 1; }
+
+namespace {
+
+constexpr int kMaxLayers = 24;
+constexpr float kBnEps = 1e-5f;
+
+enum LayerKind { K_CONV = 0, K_CONV1_S2D = 1, K_LINEAR = 2, K_LINEAR_PERM = 3 };
+
+struct Layer {
+  std::string name, bn_name;
+  int kind;
+  int co, ci, r, s, stride, pad;  // master weight dims [co][ci][r][s] and conv geometry
+  int has_bn, has_bias;
+  int k_ci, k_r, k_s, pix_stride;  // kernel view
+  int co_pad;
+  int hi, wi, ho, wo;
+  int per_sample;
+  int stage, has_dgrad;
+  int64_t w_off, g_off, b_off, mean_off, var_off;
+  int64_t wf_off, wd_off, bias_off, scale_off;  // bytes in packed
+  int64_t dw_off, db_off;                        // bytes in bwd workspace
+  int kf() const { return k_r * k_s * k_ci; }
+  int kd() const { return k_r * k_s * co_pad; }
+};
+
+struct FoldDesc {
+  int64_t w_off, g_off, b_off, mean_off, var_off;
+  int64_t wf_off, wd_off, bias_off, scale_off, dw_off, db_off;
+  int co, ci, r, s, kind, co_pad, kf, k_ci, k_s, cd_rows, kd, has_bn, has_bias;
+};
+struct FoldTable {
+  int n;
+  FoldDesc d[kMaxLayers];
+};
+
+struct ActLayout {
+  int64_t t_in, c1, pool, idx;
+  int64_t h[8], o[8], ds[8];
+  int64_t f8, l0, l1, q, qf;
+  int64_t total;
+};
+struct BwdLayout {
+  int64_t zero_begin, zero_bytes;  // region cleared every step: dW', dbias', loss scratch
+  int64_t dq, g_l1, g_l0, g_f8, g_o[8], g_h[8], dsg[8], g_pool, g_c1;
+  int64_t total;
+};
+
+inline int64_t align_up(int64_t v, int64_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct vdqn_net {
+  vdqn_net_config cfg;
+  int esz;  // bytes per activation element
+  std::vector<Layer> layers;
+  std::vector<vdqn_param_info> params;
+  int64_t trainable_numel, params_numel, bnstats_numel, packed_bytes;
+  int64_t stage_begin[3], stage_end[3];
+  int layer_stage_first[3], layer_stage_count[3];
+  int64_t dw_bytes;  // total f32 dW' + dbias' bytes
+  FoldTable fold;
+  // layer indices
+  int l_conv1, l_f8, l_top0, l_top2, l_top4;
+  int l_b_conv1[8], l_b_conv2[8], l_b_ds[8];
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// fold / unfold kernels
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long fold_src_index(const FoldDesc& d, int co, int k) {
+  if (d.kind == K_CONV1_S2D) {
+    const int a = k >> 6, j = (k >> 4) & 3, ch = k & 15;
+    if (ch >= 12) return -1;
+    const int bh = ch / 6, bw = (ch / 3) & 1, c = ch % 3;
+    const int r7 = 2 * a + bh - 1, s7 = 2 * j + bw - 1;
+    if (r7 < 0 || s7 < 0) return -1;
+    return ((long)(co * 3 + c) * 7 + r7) * 7 + s7;
+  } else if (d.kind == K_LINEAR_PERM) {
+    const int f = k / 1600, rem = k - f * 1600;
+    const int hw = rem >> 6, c = rem & 63;
+    return (long)co * d.ci + f * 1600 + c * 25 + hw;
+  } else {
+    const int tap = k / d.k_ci, c = k - tap * d.k_ci;
+    const int kr = tap / d.k_s, ks = tap - kr * d.k_s;
+    return (((long)co * d.ci + c) * d.r + kr) * d.s + ks;
+  }
+}
+
+__device__ __forceinline__ float fold_scale(const FoldDesc& d, const float* params, const float* bnstats, int co) {
+  if (!d.has_bn) return 1.0f;
+  return params[d.g_off + co] / sqrtf(bnstats[d.var_off + co] + kBnEps);
+}
+
+// grid: (blocks, layers, 2): z = 0 packs Wf (+bias, scale), z = 1 packs Wd
+template <typename T>
+__global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const float* __restrict__ params, const float* __restrict__ bnstats,
+                                                   unsigned char* __restrict__ packed, int with_dgrad) {
+  const FoldDesc& d = tab.d[blockIdx.y];
+  const int which = blockIdx.z;
+  if (which == 1 && (!with_dgrad || d.wd_off < 0)) return;
+  const long stride = (long)gridDim.x * blockDim.x;
+  if (which == 0) {
+    T* wf = reinterpret_cast<T*>(packed + d.wf_off);
+    float* bias = reinterpret_cast<float*>(packed + d.bias_off);
+    float* scale = reinterpret_cast<float*>(packed + d.scale_off);
+    const long total = (long)d.co_pad * d.kf;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int row = (int)(i / d.kf), k = (int)(i - (long)row * d.kf);
+      float v = 0.f;
+      if (row < d.co) {
+        const float sc = fold_scale(d, params, bnstats, row);
+        const long src = fold_src_index(d, row, k);
+        if (src >= 0) v = params[d.w_off + src] * sc;
+        if (k == 0) {
+          scale[row] = sc;
+          float b = 0.f;
+          if (d.has_bn) b = params[d.b_off + row] - bnstats[d.mean_off + row] * sc;
+          else if (d.has_bias) b = params[d.b_off + row];
+          bias[row] = b;
+        }
+      } else if (k == 0) {
+        scale[row] = 0.f;
+        bias[row] = 0.f;
+      }
+      wf[i] = from_f32<T>(v);
+    }
+  } else {
+    T* wd = reinterpret_cast<T*>(packed + d.wd_off);
+    const long total = (long)d.cd_rows * d.kd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int n = (int)(i / d.kd), kk = (int)(i - (long)n * d.kd);
+      const int tap = kk / d.co_pad, co = kk - tap * d.co_pad;
+      float v = 0.f;
+      if (co < d.co) {
+        const long src = fold_src_index(d, co, tap * d.k_ci + n);
+        if (src >= 0) v = params[d.w_off + src] * fold_scale(d, params, bnstats, co);
+      }
+      wd[i] = from_f32<T>(v);
+    }
+  }
+}
+
+// grid: (max co, layers of the stage): one block per output channel
+__global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, int first_layer, const float* __restrict__ params,
+                                                     const float* __restrict__ bnstats, const unsigned char* __restrict__ bwd,
+                                                     float* __restrict__ grads) {
+  const FoldDesc& d = tab.d[first_layer + blockIdx.y];
+  const int co = blockIdx.x;
+  if (co >= d.co) return;
+  const float* dw = reinterpret_cast<const float*>(bwd + d.dw_off) + (long)co * d.kf;
+  const float* db = reinterpret_cast<const float*>(bwd + d.db_off);
+  float rstd = 1.f, sc = 1.f;
+  if (d.has_bn) {
+    rstd = 1.0f / sqrtf(bnstats[d.var_off + co] + kBnEps);
+    sc = params[d.g_off + co] * rstd;
+  }
+  float dot = 0.f;
+  for (int k = threadIdx.x; k < d.kf; k += 256) {
+    const long src = fold_src_index(d, co, k);
+    if (src >= 0) {
+      const float g = dw[k];
+      grads[d.w_off + src] = g * sc;
+      dot += g * params[d.w_off + src];
+    }
+  }
+  __shared__ float red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float dbp = db[co];
+    if (d.has_bn) {
+      grads[d.g_off + co] = rstd * (tot - bnstats[d.mean_off + co] * dbp);
+      grads[d.b_off + co] = dbp;
+    } else if (d.has_bias) {
+      grads[d.b_off + co] = dbp;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// table construction
+// ---------------------------------------------------------------------------------------------------------
+void add_param(vdqn_net* net, const std::string& name, int64_t off, std::vector<int> shape, int kind, int stage) {
+  vdqn_param_info pi;
+  memset(&pi, 0, sizeof(pi));
+  snprintf(pi.name, sizeof(pi.name), "%s", name.c_str());
+  pi.offset = off;
+  pi.ndim = (int)shape.size();
+  int64_t n = 1;
+  for (size_t i = 0; i < shape.size(); ++i) {
+    pi.shape[i] = shape[i];
+    n *= shape[i];
+  }
+  pi.numel = n;
+  pi.kind = kind;
+  pi.param_id = -1;
+  pi.stage = stage;
+  net->params.push_back(pi);
+}
+
+Layer make_conv(const std::string& name, const std::string& bn, int co, int ci, int k, int stride, int pad, int hi, int stage) {
+  Layer L;
+  L.name = name;
+  L.bn_name = bn;
+  L.kind = K_CONV;
+  L.co = co; L.ci = ci; L.r = k; L.s = k; L.stride = stride; L.pad = pad;
+  L.has_bn = !bn.empty();
+  L.has_bias = bn.empty();
+  L.k_ci = ci; L.k_r = k; L.k_s = k; L.pix_stride = ci;
+  L.co_pad = (co + 63) / 64 * 64;
+  L.hi = hi; L.wi = hi;
+  L.ho = (hi + 2 * pad - k) / stride + 1;
+  L.wo = L.ho;
+  L.per_sample = 0;
+  L.stage = stage;
+  L.has_dgrad = 1;
+  return L;
+}
+
+Layer make_linear(const std::string& name, int out_f, int in_f, int stage, bool perm) {
+  Layer L;
+  L.name = name;
+  L.bn_name = "";
+  L.kind = perm ? K_LINEAR_PERM : K_LINEAR;
+  L.co = out_f; L.ci = in_f; L.r = 1; L.s = 1; L.stride = 1; L.pad = 0;
+  L.has_bn = 0;
+  L.has_bias = 1;
+  L.k_ci = in_f; L.k_r = 1; L.k_s = 1; L.pix_stride = in_f;
+  L.co_pad = (out_f + 63) / 64 * 64;
+  L.hi = L.wi = L.ho = L.wo = 1;
+  L.per_sample = 1;
+  L.stage = stage;
+  L.has_dgrad = 1;
+  return L;
+}
+
+void build_layers(vdqn_net* net) {
+  const int F = net->cfg.num_frames;
+  std::vector<Layer> fwd;  // forward order
+  {
+    Layer L = make_conv("resnet.conv1", "resnet.bn1", 64, 3, 7, 2, 3, 224, 2);
+    L.kind = K_CONV1_S2D;
+    L.k_ci = 64; L.k_r = 4; L.k_s = 1; L.pix_stride = 16;
+    L.hi = L.wi = 115;  // packed space-to-depth operand
+    L.ho = L.wo = 112;
+    L.has_dgrad = 0;
+    fwd.push_back(L);
+  }
+  int inpl = 64, sp = 56;
+  for (int li = 1; li <= 4; ++li) {
+    const int planes = 64 << (li - 1);
+    const int stage = li == 4 ? 0 : (li == 3 ? 1 : 2);
+    for (int bi = 0; bi < 2; ++bi) {
+      const int stride = (li > 1 && bi == 0) ? 2 : 1;
+      char pfx[64];
+      snprintf(pfx, sizeof(pfx), "resnet.layer%d.%d", li, bi);
+      const std::string p(pfx);
+      fwd.push_back(make_conv(p + ".conv1", p + ".bn1", planes, inpl, 3, stride, 1, sp, stage));
+      const int sp_out = sp / stride;
+      fwd.push_back(make_conv(p + ".conv2", p + ".bn2", planes, planes, 3, 1, 1, sp_out, stage));
+      if (stride != 1 || inpl != planes) fwd.push_back(make_conv(p + ".downsample.0", p + ".downsample.1", planes, inpl, 1, stride, 0, sp, stage));
+      inpl = planes;
+      sp = sp_out;
+    }
+  }
+  fwd.push_back(make_conv("features.8", "", 64, 512, 3, 1, 0, 7, 0));
+  fwd.push_back(make_linear("top.0", 512, 1600 * F, 0, true));
+  fwd.push_back(make_linear("top.2", 256, 512, 0, false));
+  fwd.push_back(make_linear("top.4", net->cfg.action_dim * net->cfg.num_classes, 256, 0, false));
+
+  // store layers ordered by backward stage (stable), so each stage's gradients are one contiguous range
+  net->layers.clear();
+  for (int st = 0; st < 3; ++st) {
+    net->layer_stage_first[st] = (int)net->layers.size();
+    for (auto& L : fwd)
+      if (L.stage == st) net->layers.push_back(L);
+    net->layer_stage_count[st] = (int)net->layers.size() - net->layer_stage_first[st];
+  }
+
+  auto find = [&](const std::string& n) {
+    for (size_t i = 0; i < net->layers.size(); ++i)
+      if (net->layers[i].name == n) return (int)i;
+    return -1;
+  };
+  net->l_conv1 = find("resnet.conv1");
+  net->l_f8 = find("features.8");
+  net->l_top0 = find("top.0");
+  net->l_top2 = find("top.2");
+  net->l_top4 = find("top.4");
+  for (int b = 0; b < 8; ++b) {
+    char pfx[64];
+    snprintf(pfx, sizeof(pfx), "resnet.layer%d.%d", b / 2 + 1, b % 2);
+    net->l_b_conv1[b] = find(std::string(pfx) + ".conv1");
+    net->l_b_conv2[b] = find(std::string(pfx) + ".conv2");
+    net->l_b_ds[b] = find(std::string(pfx) + ".downsample.0");
+  }
+
+  // flat offsets: trainable parameters grouped by stage, then the frozen resnet.fc
+  int64_t poff = 0, soff = 0, pk = 0, dwoff = 0;
+  const int esz = net->esz;
+  for (int st = 0; st < 3; ++st) {
+    net->stage_begin[st] = poff;
+    for (int i = net->layer_stage_first[st]; i < net->layer_stage_first[st] + net->layer_stage_count[st]; ++i) {
+      Layer& L = net->layers[i];
+      L.w_off = poff;
+      if (L.kind == K_LINEAR || L.kind == K_LINEAR_PERM) add_param(net, L.name + ".weight", poff, {L.co, L.ci}, 0, st);
+      else add_param(net, L.name + ".weight", poff, {L.co, L.ci, L.r, L.s}, 0, st);
+      poff += (int64_t)L.co * L.ci * L.r * L.s;
+      poff = (poff + 3) / 4 * 4;  // keep every tensor 16-byte aligned
+      L.g_off = L.b_off = L.mean_off = L.var_off = -1;
+      if (L.has_bn) {
+        L.g_off = poff;
+        add_param(net, L.bn_name + ".weight", poff, {L.co}, 0, st);
+        poff += L.co;
+        L.b_off = poff;
+        add_param(net, L.bn_name + ".bias", poff, {L.co}, 0, st);
+        poff += L.co;
+        L.mean_off = soff;
+        add_param(net, L.bn_name + ".running_mean", soff, {L.co}, 2, st);
+        soff += L.co;
+        L.var_off = soff;
+        add_param(net, L.bn_name + ".running_var", soff, {L.co}, 3, st);
+        soff += L.co;
+      } else if (L.has_bias) {
+        L.b_off = poff;
+        add_param(net, L.name + ".bias", poff, {L.co}, 0, st);
+        poff += L.co;
+        poff = (poff + 3) / 4 * 4;
+      }
+      // packed weights
+      L.wf_off = pk;
+      pk = align_up(pk + (int64_t)L.co_pad * L.kf() * esz);
+      if (L.has_dgrad) {
+        L.wd_off = pk;
+        pk = align_up(pk + (int64_t)L.k_ci * L.kd() * esz);
+      } else {
+        L.wd_off = -1;
+      }
+      L.bias_off = pk;
+      pk = align_up(pk + (int64_t)L.co_pad * 4);
+      L.scale_off = pk;
+      pk = align_up(pk + (int64_t)L.co_pad * 4);
+      // f32 gradient accumulators
+      L.dw_off = dwoff;
+      dwoff = align_up(dwoff + (int64_t)L.co_pad * L.kf() * 4);
+      L.db_off = dwoff;
+      dwoff = align_up(dwoff + (int64_t)L.co_pad * 4);
+    }
+    net->stage_end[st] = poff;
+  }
+  net->trainable_numel = poff;
+  add_param(net, "resnet.fc.weight", poff, {1000, 512}, 1, -1);
+  poff += 1000 * 512;
+  add_param(net, "resnet.fc.bias", poff, {1000}, 1, -1);
+  poff += 1000;
+  net->params_numel = poff;
+  net->bnstats_numel = soff;
+  net->packed_bytes = pk;
+  net->dw_bytes = dwoff;
+
+  // reference model.parameters() order -> param_id (Adam state_dict ids)
+  {
+    std::vector<std::string> order;
+    for (auto& L : fwd) {
+      if (L.name.rfind("resnet.", 0) != 0) continue;
+      order.push_back(L.name + ".weight");
+      order.push_back(L.bn_name + ".weight");
+      order.push_back(L.bn_name + ".bias");
+    }
+    order.push_back("resnet.fc.weight");
+    order.push_back("resnet.fc.bias");
+    for (const char* n : {"features.8", "top.0", "top.2", "top.4"}) {
+      order.push_back(std::string(n) + ".weight");
+      order.push_back(std::string(n) + ".bias");
+    }
+    for (auto& pi : net->params)
+      for (size_t i = 0; i < order.size(); ++i)
+        if (order[i] == pi.name) pi.param_id = (int)i;
+  }
+
+  // device-side descriptors
+  net->fold.n = (int)net->layers.size();
+  for (size_t i = 0; i < net->layers.size(); ++i) {
+    const Layer& L = net->layers[i];
+    FoldDesc& d = net->fold.d[i];
+    d.w_off = L.w_off; d.g_off = L.g_off; d.b_off = L.b_off; d.mean_off = L.mean_off; d.var_off = L.var_off;
+    d.wf_off = L.wf_off; d.wd_off = L.wd_off; d.bias_off = L.bias_off; d.scale_off = L.scale_off;
+    d.dw_off = L.dw_off; d.db_off = L.db_off;
+    d.co = L.co; d.ci = L.ci; d.r = L.r; d.s = L.s; d.kind = L.kind; d.co_pad = L.co_pad; d.kf = L.kf();
+    d.k_ci = L.k_ci; d.k_s = L.k_s; d.cd_rows = L.k_ci; d.kd = L.kd(); d.has_bn = L.has_bn; d.has_bias = L.has_bias;
+  }
+}
+
+ActLayout act_layout(const vdqn_net* net, int n_samples) {
+  const int64_t F = net->cfg.num_frames, n = (int64_t)n_samples * F, e = net->esz;
+  ActLayout L;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    const int64_t o = off;
+    off = align_up(off + bytes);
+    return o;
+  };
+  L.t_in = take(n * 115 * 115 * 16 * e);
+  L.c1 = take(n * 112 * 112 * 64 * e);
+  L.pool = take(n * 56 * 56 * 64 * e);
+  L.idx = take(n * 56 * 56 * 64);
+  for (int b = 0; b < 8; ++b) {
+    const int li = b / 2;
+    const int64_t planes = 64 << li, sp = 56 >> li;
+    const int64_t sz = n * sp * sp * planes * e;
+    L.h[b] = take(sz);
+    L.o[b] = take(sz);
+    L.ds[b] = (b % 2 == 0 && li > 0) ? take(sz) : -1;
+  }
+  L.f8 = take(n * 25 * 64 * e);
+  L.l0 = take((int64_t)n_samples * 512 * e);
+  L.l1 = take((int64_t)n_samples * 256 * e);
+  L.q = take((int64_t)n_samples * 64 * e);
+  L.qf = take((int64_t)n_samples * 64 * 4);
+  L.total = off;
+  return L;
+}
+
+BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
+  const int64_t F = net->cfg.num_frames, n = (int64_t)n_samples * F, e = net->esz;
+  BwdLayout L;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    const int64_t o = off;
+    off = align_up(off + bytes);
+    return o;
+  };
+  L.zero_begin = 0;
+  take(net->dw_bytes);
+  L.zero_bytes = off;
+  L.dq = take((int64_t)n_samples * 64 * e);
+  L.g_l1 = take((int64_t)n_samples * 256 * e);
+  L.g_l0 = take((int64_t)n_samples * 512 * e);
+  L.g_f8 = take(n * 25 * 64 * e);
+  for (int b = 0; b < 8; ++b) {
+    const int li = b / 2;
+    const int64_t planes = 64 << li, sp = 56 >> li;
+    const int64_t sz = n * sp * sp * planes * e;
+    L.g_o[b] = take(sz);
+    L.g_h[b] = take(sz);
+    // gradient of the downsample branch w.r.t. the block input (input geometry of the block)
+    L.dsg[b] = (b % 2 == 0 && li > 0) ? take(n * (sp * 2) * (sp * 2) * (planes / 2) * e) : -1;
+  }
+  L.g_pool = take(n * 56 * 56 * 64 * e);
+  L.g_c1 = take(n * 112 * 112 * 64 * e);
+  L.total = off;
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------------------
+int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* in, void* out, int n_units, const void* resid,
+             int relu, float* out_f32, hipStream_t st) {
+  vdqn_conv_args a;
+  memset(&a, 0, sizeof(a));
+  a.in = in;
+  a.wt = packed + L.wf_off;
+  a.bias = reinterpret_cast<const float*>(packed + L.bias_off);
+  a.resid = resid;
+  a.mask = nullptr;
+  a.out = out;
+  a.out_f32 = out_f32;
+  a.n_img = n_units; a.hi = L.hi; a.wi = L.wi; a.ci = L.k_ci; a.pix_stride = L.pix_stride;
+  a.ho = L.ho; a.wo = L.wo; a.co = L.co_pad; a.ldo = L.co_pad;
+  a.r = L.k_r; a.s = L.k_s;
+  a.stride = L.kind == K_CONV1_S2D ? 1 : L.stride;
+  a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
+  a.mode = 0; a.relu = relu; a.dtype = net->cfg.dtype;
+  return vdqn_conv2d(&a, st);
+}
+
+// data gradient: gx = (dgrad(gy) + resid) masked by (mask > 0)
+int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* gy, void* gx, int n_units, const void* resid,
+              const void* mask, hipStream_t st) {
+  vdqn_conv_args a;
+  memset(&a, 0, sizeof(a));
+  a.in = gy;
+  a.wt = packed + L.wd_off;
+  a.bias = nullptr;
+  a.resid = resid;
+  a.mask = mask;
+  a.out = gx;
+  a.n_img = n_units; a.hi = L.ho; a.wi = L.wo; a.ci = L.co_pad; a.pix_stride = L.co_pad;
+  a.ho = L.hi; a.wo = L.wi; a.co = L.k_ci; a.ldo = L.k_ci;
+  a.r = L.k_r; a.s = L.k_s; a.stride = L.stride; a.pad = L.pad;
+  a.mode = 1; a.relu = 0; a.dtype = net->cfg.dtype;
+  return vdqn_conv2d(&a, st);
+}
+
+int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const void* gy, const void* x, int n_units, hipStream_t st) {
+  vdqn_wgrad_args a;
+  memset(&a, 0, sizeof(a));
+  a.gy = gy;
+  a.x = x;
+  a.dw = reinterpret_cast<float*>(bwd + L.dw_off);
+  a.dbias = reinterpret_cast<float*>(bwd + L.db_off);
+  a.n_img = n_units; a.hi = L.hi; a.wi = L.wi; a.ci = L.k_ci; a.pix_stride = L.pix_stride;
+  a.ho = L.ho; a.wo = L.wo; a.co = L.co_pad; a.ldg = L.co_pad;
+  a.r = L.k_r; a.s = L.k_s;
+  a.stride = L.kind == K_CONV1_S2D ? 1 : L.stride;
+  a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
+  a.splitk = 0; a.dtype = net->cfg.dtype;
+  return vdqn_conv2d_wgrad(&a, st);
+}
+
+#define RC(x)                     \
+  do {                            \
+    int rc_ = (x);                \
+    if (rc_ != VDQN_OK) return rc_; \
+  } while (0)
+
+// forward over n_samples samples whose packed input already sits at `t_in`
+int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t_in, int n_samples, unsigned char* acts, const ActLayout& A,
+                 hipStream_t st) {
+  const int n = n_samples * net->cfg.num_frames;
+  const int dt = net->cfg.dtype;
+  RC(run_conv(net, net->layers[net->l_conv1], packed, t_in, acts + A.c1, n, nullptr, 1, nullptr, st));
+  RC(vdqn_maxpool_fwd(acts + A.c1, acts + A.pool, acts + A.idx, n, 112, 112, 64, dt, st));
+  const unsigned char* x = acts + A.pool;
+  for (int b = 0; b < 8; ++b) {
+    const Layer& c1 = net->layers[net->l_b_conv1[b]];
+    const Layer& c2 = net->layers[net->l_b_conv2[b]];
+    RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st));
+    const void* identity = x;
+    if (net->l_b_ds[b] >= 0) {
+      RC(run_conv(net, net->layers[net->l_b_ds[b]], packed, x, acts + A.ds[b], n, nullptr, 0, nullptr, st));
+      identity = acts + A.ds[b];
+    }
+    RC(run_conv(net, c2, packed, acts + A.h[b], acts + A.o[b], n, identity, 1, nullptr, st));
+    x = acts + A.o[b];
+  }
+  RC(run_conv(net, net->layers[net->l_f8], packed, x, acts + A.f8, n, nullptr, 1, nullptr, st));
+  RC(run_conv(net, net->layers[net->l_top0], packed, acts + A.f8, acts + A.l0, n_samples, nullptr, 1, nullptr, st));
+  RC(run_conv(net, net->layers[net->l_top2], packed, acts + A.l0, acts + A.l1, n_samples, nullptr, 1, nullptr, st));
+  RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.l1, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
+  return VDQN_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out) {
+  VDQN_CHECK(cfg && out, "vdqn_net_create: null arg");
+  VDQN_CHECK(cfg->extra_capacity == 1, "vdqn_net_create: only ARCHITECTURE='extra_capacity' is implemented (basic arch: BatchNorm train mode, next round)");
+  VDQN_CHECK(cfg->dtype == VDQN_F32 || cfg->dtype == VDQN_BF16, "vdqn_net_create: bad dtype %d", cfg->dtype);
+  VDQN_CHECK(cfg->action_dim >= 1 && cfg->num_classes >= 1 && cfg->action_dim * cfg->num_classes <= 64, "vdqn_net_create: action_dim*num_classes must be in 1..64");
+  VDQN_CHECK(cfg->num_frames >= 1 && cfg->num_frames <= 64, "vdqn_net_create: num_frames out of range");
+  VDQN_CHECK(cfg->max_batch >= 1, "vdqn_net_create: max_batch");
+  vdqn_net* net = new vdqn_net();
+  net->cfg = *cfg;
+  net->esz = cfg->dtype == VDQN_BF16 ? 2 : 4;
+  build_layers(net);
+  if ((int)net->layers.size() > kMaxLayers) {
+    delete net;
+    vdqn_set_error("vdqn_net_create: layer table overflow");
+    return VDQN_ERR_INVALID;
+  }
+  *out = net;
+  return VDQN_OK;
+}
+
+extern "C" void vdqn_net_destroy(vdqn_net* net) { delete net; }
+
+extern "C" int vdqn_net_num_params(const vdqn_net* net) { return net ? (int)net->params.size() : 0; }
+extern "C" int vdqn_net_param_info(const vdqn_net* net, int index, vdqn_param_info* out) {
+  VDQN_CHECK(net && out && index >= 0 && index < (int)net->params.size(), "vdqn_net_param_info: bad index");
+  *out = net->params[index];
+  return VDQN_OK;
+}
+extern "C" int64_t vdqn_net_params_numel(const vdqn_net* net) { return net->params_numel; }
+extern "C" int64_t vdqn_net_trainable_numel(const vdqn_net* net) { return net->trainable_numel; }
+extern "C" int64_t vdqn_net_bnstats_numel(const vdqn_net* net) { return net->bnstats_numel; }
+extern "C" int vdqn_net_stage_range(const vdqn_net* net, int stage, int64_t* begin, int64_t* end) {
+  VDQN_CHECK(net && stage >= 0 && stage < 3 && begin && end, "vdqn_net_stage_range: bad args");
+  *begin = net->stage_begin[stage];
+  *end = net->stage_end[stage];
+  return VDQN_OK;
+}
+extern "C" int64_t vdqn_net_packed_bytes(const vdqn_net* net) { return net->packed_bytes; }
+extern "C" int64_t vdqn_net_acts_bytes(const vdqn_net* net, int32_t n_samples) { return act_layout(net, n_samples).total; }
+extern "C" int64_t vdqn_net_bwd_bytes(const vdqn_net* net, int32_t n_samples) { return bwd_layout(net, n_samples).total; }
+
+extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad, void* stream) {
+  VDQN_CHECK(net && params && bnstats && packed, "vdqn_net_pack_weights: null arg");
+  dim3 grid(256, (unsigned)net->layers.size(), 2);
+  if (net->cfg.dtype == VDQN_BF16)
+    hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, with_dgrad);
+  else
+    hipLaunchKernelGGL((fold_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, with_dgrad);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples, void* acts,
+                                float* q_out, void* stream) {
+  VDQN_CHECK(net && packed && frames && acts && q_out, "vdqn_net_forward: null arg");
+  VDQN_CHECK(n_samples >= 1 && n_samples <= net->cfg.max_batch, "vdqn_net_forward: n_samples %d exceeds max_batch %d", n_samples, net->cfg.max_batch);
+  hipStream_t st = (hipStream_t)stream;
+  const ActLayout A = act_layout(net, n_samples);
+  unsigned char* ab = (unsigned char*)acts;
+  RC(vdqn_pack_input(frames, src_kind, ab + A.t_in, n_samples * net->cfg.num_frames, net->cfg.dtype, st));
+  RC(forward_impl(net, (const unsigned char*)packed, ab + A.t_in, n_samples, ab, A, st));
+  const int nq = net->cfg.action_dim * net->cfg.num_classes;
+  hipError_t e = hipMemcpy2DAsync(q_out, (size_t)nq * 4, ab + A.qf, 64 * 4, (size_t)nq * 4, (size_t)n_samples, hipMemcpyDeviceToDevice, st);
+  VDQN_CHECK(e == hipSuccess, "vdqn_net_forward: q copy failed: %s", hipGetErrorString(e));
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream) {
+  VDQN_CHECK(net && a, "vdqn_net_td_forward: null arg");
+  VDQN_CHECK(a->params && a->bnstats && a->packed_online && a->before && a->act && a->acts_online && a->bwd && a->loss, "vdqn_net_td_forward: null buffer");
+  const int B = a->batch;
+  const bool gtb = a->train_on_ground_truth != 0;
+  VDQN_CHECK(B >= 1 && 2 * B <= net->cfg.max_batch, "vdqn_net_td_forward: batch %d needs max_batch >= %d", B, 2 * B);
+  VDQN_CHECK(gtb ? (a->gt != nullptr) : (a->after && a->packed_target && a->acts_target && a->rew && a->term), "vdqn_net_td_forward: missing inputs for this loss branch");
+  hipStream_t st = (hipStream_t)stream;
+  const int F = net->cfg.num_frames, dt = net->cfg.dtype;
+  const int ns_online = gtb ? B : 2 * B;
+  const ActLayout A = act_layout(net, ns_online);
+  const BwdLayout W = bwd_layout(net, B);
+  unsigned char* ao = (unsigned char*)a->acts_online;
+  unsigned char* bw = (unsigned char*)a->bwd;
+
+  RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, 1, st));
+  const int64_t frame_bytes = (int64_t)115 * 115 * 16 * net->esz;
+  RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, st));
+  if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, st));
+  RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st));
+
+  hipError_t e = hipMemsetAsync(bw + W.zero_begin, 0, (size_t)W.zero_bytes, st);
+  VDQN_CHECK(e == hipSuccess, "vdqn_net_td_forward: memset failed: %s", hipGetErrorString(e));
+  e = hipMemsetAsync(a->loss, 0, 4, st);
+  VDQN_CHECK(e == hipSuccess, "vdqn_net_td_forward: memset failed: %s", hipGetErrorString(e));
+
+  const float* qf_online = reinterpret_cast<const float*>(ao + A.qf);
+  if (!gtb) {
+    const ActLayout T = act_layout(net, B);
+    unsigned char* at = (unsigned char*)a->acts_target;
+    RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, at, T, st));
+    vdqn_td_args t;
+    memset(&t, 0, sizeof(t));
+    t.q_before = qf_online;
+    t.q_after_online = qf_online + (size_t)B * 64;
+    t.q_after_target = reinterpret_cast<const float*>(at + T.qf);
+    t.act = a->act; t.rew = a->rew; t.term = a->term; t.valid = a->valid;
+    t.loss = a->loss;
+    t.dq = bw + W.dq;
+    t.batch = B; t.n_cat = net->cfg.num_classes; t.n_act = net->cfg.action_dim; t.ldq = 64;
+    t.gamma = a->gamma; t.inv_count = a->inv_count;
+    t.clip_rect = a->clip_rect; t.linear = a->linear; t.use_valid = a->use_valid; t.dtype = dt;
+    RC(vdqn_td_loss(&t, st));
+  } else {
+    RC(vdqn_gt_loss(qf_online, a->act, a->gt, a->loss, bw + W.dq, nullptr, B, net->cfg.num_classes, net->cfg.action_dim, 64, a->inv_count,
+                    a->value_learning, dt, st));
+  }
+  if (a->q_before) {
+    const int nq = net->cfg.action_dim * net->cfg.num_classes;
+    e = hipMemcpy2DAsync(a->q_before, (size_t)nq * 4, qf_online, 64 * 4, (size_t)nq * 4, (size_t)B, hipMemcpyDeviceToDevice, st);
+    VDQN_CHECK(e == hipSuccess, "vdqn_net_td_forward: q copy failed: %s", hipGetErrorString(e));
+  }
+  return VDQN_OK;
+}
+
+namespace {
+
+// backward of BasicBlock b (gradient of its output, already ReLU-masked, is in g_o[b])
+int block_backward(const vdqn_net* net, const vdqn_step_args* a, int b, const ActLayout& A, const BwdLayout& W, int n, hipStream_t st) {
+  const unsigned char* pk = (const unsigned char*)a->packed_online;
+  unsigned char* ao = (unsigned char*)a->acts_online;
+  unsigned char* bw = (unsigned char*)a->bwd;
+  const Layer& c1 = net->layers[net->l_b_conv1[b]];
+  const Layer& c2 = net->layers[net->l_b_conv2[b]];
+  const unsigned char* x = b == 0 ? ao + A.pool : ao + A.o[b - 1];
+  unsigned char* gx = b == 0 ? bw + W.g_pool : bw + W.g_o[b - 1];
+  const void* g_out = bw + W.g_o[b];
+  // conv2: weight gradient, then data gradient into g_h masked by relu(h)
+  RC(run_wgrad(net, c2, bw, g_out, ao + A.h[b], n, st));
+  RC(run_dgrad(net, c2, pk, g_out, bw + W.g_h[b], n, nullptr, ao + A.h[b], st));
+  RC(run_wgrad(net, c1, bw, bw + W.g_h[b], x, n, st));
+  const void* resid = g_out;  // identity shortcut
+  if (net->l_b_ds[b] >= 0) {
+    const Layer& ds = net->layers[net->l_b_ds[b]];
+    RC(run_wgrad(net, ds, bw, g_out, x, n, st));
+    RC(run_dgrad(net, ds, pk, g_out, bw + W.dsg[b], n, nullptr, nullptr, st));
+    resid = bw + W.dsg[b];
+  }
+  RC(run_dgrad(net, c1, pk, bw + W.g_h[b], gx, n, resid, x, st));
+  return VDQN_OK;
+}
+
+}  // namespace
+
+extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream) {
+  VDQN_CHECK(net && a && a->grads, "vdqn_net_backward_stage: null arg");
+  VDQN_CHECK(stage >= 0 && stage < 3, "vdqn_net_backward_stage: stage %d", stage);
+  hipStream_t st = (hipStream_t)stream;
+  const int B = a->batch, F = net->cfg.num_frames, n = B * F, dt = net->cfg.dtype;
+  const bool gtb = a->train_on_ground_truth != 0;
+  const ActLayout A = act_layout(net, gtb ? B : 2 * B);
+  const BwdLayout W = bwd_layout(net, B);
+  const unsigned char* pk = (const unsigned char*)a->packed_online;
+  unsigned char* ao = (unsigned char*)a->acts_online;
+  unsigned char* bw = (unsigned char*)a->bwd;
+
+  if (stage == 0) {
+    const Layer& t4 = net->layers[net->l_top4];
+    const Layer& t2 = net->layers[net->l_top2];
+    const Layer& t0 = net->layers[net->l_top0];
+    const Layer& f8 = net->layers[net->l_f8];
+    RC(run_wgrad(net, t4, bw, bw + W.dq, ao + A.l1, B, st));
+    RC(run_dgrad(net, t4, pk, bw + W.dq, bw + W.g_l1, B, nullptr, ao + A.l1, st));
+    RC(run_wgrad(net, t2, bw, bw + W.g_l1, ao + A.l0, B, st));
+    RC(run_dgrad(net, t2, pk, bw + W.g_l1, bw + W.g_l0, B, nullptr, ao + A.l0, st));
+    RC(run_wgrad(net, t0, bw, bw + W.g_l0, ao + A.f8, B, st));
+    RC(run_dgrad(net, t0, pk, bw + W.g_l0, bw + W.g_f8, B, nullptr, ao + A.f8, st));
+    RC(run_wgrad(net, f8, bw, bw + W.g_f8, ao + A.o[7], n, st));
+    RC(run_dgrad(net, f8, pk, bw + W.g_f8, bw + W.g_o[7], n, nullptr, ao + A.o[7], st));
+    RC(block_backward(net, a, 7, A, W, n, st));
+    RC(block_backward(net, a, 6, A, W, n, st));
+  } else if (stage == 1) {
+    RC(block_backward(net, a, 5, A, W, n, st));
+    RC(block_backward(net, a, 4, A, W, n, st));
+  } else {
+    for (int b = 3; b >= 0; --b) RC(block_backward(net, a, b, A, W, n, st));
+    RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, ao + A.c1, bw + W.g_c1, n, 112, 112, 64, dt, st));
+    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, st));
+  }
+  int max_co = 0;
+  for (int i = net->layer_stage_first[stage]; i < net->layer_stage_first[stage] + net->layer_stage_count[stage]; ++i)
+    max_co = net->layers[i].co > max_co ? net->layers[i].co : max_co;
+  hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, st, net->fold, net->layer_stage_first[stage],
+                     a->params, a->bnstats, (const unsigned char*)bw, a->grads);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}

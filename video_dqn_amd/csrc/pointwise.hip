@@ -1,0 +1,369 @@
+// HBM-bound kernels of the hot path: input packing (normalise + space-to-depth), 3x3/2 max-pool forward and
+// backward, the fused Double-DQN target / TD-loss / dQ kernel, and the flat fused Adam.
+// All accesses are 16-byte vectors over the contiguous NHWC channel axis.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// pack_input: 224x224x3 frame -> [115][115][16] space-to-depth operand of the 4x4/1 stem GEMM.
+// dst pixel (y, x) holds source pixels (2(y-2)+bh, 2(x-2)+bw), channel (bh*2+bw)*3+c; channels 12..15 = 0.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const void* __restrict__ src, int src_kind, T* __restrict__ dst, int n_img) {
+  const int total = n_img * 115 * 115;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i / (115 * 115);
+    const int rem = i - n * (115 * 115);
+    const int y = rem / 115, x = rem - y * 115;
+    const int ys = y - 2, xs = x - 2;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    if ((unsigned)ys < 112u && (unsigned)xs < 112u) {
+#pragma unroll
+      for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+        for (int bw = 0; bw < 2; ++bw) {
+          const int Y = 2 * ys + bh, X = 2 * xs + bw;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float val;
+            if (src_kind == 0) {
+              const uint8_t u = ((const uint8_t*)src)[(((size_t)n * 224 + Y) * 224 + X) * 3 + c];
+              val = (((float)u / 255.0f) - mean[c]) / stdv[c];
+            } else {
+              val = ((const float*)src)[(((size_t)n * 3 + c) * 224 + Y) * 224 + X];
+            }
+            v[(bh * 2 + bw) * 3 + c] = val;
+          }
+        }
+    }
+    T* d = dst + (size_t)i * 16;
+    if constexpr (sizeof(T) == 2) {
+      uint32_t w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+      reinterpret_cast<uint4*>(d)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      reinterpret_cast<uint4*>(d)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) reinterpret_cast<float4*>(d)[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// max-pool 3x3 / stride 2 / pad 1 (NHWC), first maximum wins (torch CPU semantics)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, uint8_t* __restrict__ idx,
+                                                          int n_img, int hi, int wi, int c) {
+  constexpr int E16 = 16 / (int)sizeof(T);
+  const int ho = (hi + 2 - 3) / 2 + 1, wo = (wi + 2 - 3) / 2 + 1;
+  const int cg_n = c / E16;
+  const long total = (long)n_img * ho * wo * cg_n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_n);
+    long t = i / cg_n;
+    const int ow = (int)(t % wo);
+    t /= wo;
+    const int oh = (int)(t % ho);
+    const int n = (int)(t / ho);
+    float best[E16];
+    uint8_t bi[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+    bool first = true;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = oh * 2 - 1 + kh;
+      if ((unsigned)h >= (unsigned)hi) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = ow * 2 - 1 + kw;
+        if ((unsigned)w >= (unsigned)wi) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(in + (((size_t)n * hi + h) * wi + w) * c + cg * E16);
+        const T* pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) {
+          const float f = to_f32<T>(pv[e]);
+          if (first || f > best[e] || f != f) {
+            best[e] = f;
+            bi[e] = (uint8_t)(kh * 3 + kw);
+          }
+        }
+        first = false;
+      }
+    }
+    const size_t o = (((size_t)n * ho + oh) * wo + ow) * c + cg * E16;
+    T ov[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(best[e]);
+    *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ov);
+    if constexpr (E16 == 8) *reinterpret_cast<uint2*>(idx + o) = *reinterpret_cast<const uint2*>(bi);
+    else *reinterpret_cast<uint32_t*>(idx + o) = *reinterpret_cast<const uint32_t*>(bi);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ gy, const uint8_t* __restrict__ idx, const T* __restrict__ x,
+                                                          T* __restrict__ gx, int n_img, int hi, int wi, int c) {
+  constexpr int E16 = 16 / (int)sizeof(T);
+  const int ho = (hi + 2 - 3) / 2 + 1, wo = (wi + 2 - 3) / 2 + 1;
+  const int cg_n = c / E16;
+  const long total = (long)n_img * hi * wi * cg_n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_n);
+    long t = i / cg_n;
+    const int w = (int)(t % wi);
+    t /= wi;
+    const int h = (int)(t % hi);
+    const int n = (int)(t / hi);
+    float s[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) s[e] = 0.f;
+    const int oh_lo = h / 2, oh_hi = min(ho - 1, (h + 1) / 2);
+    const int ow_lo = w / 2, ow_hi = min(wo - 1, (w + 1) / 2);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const int tap = (h - (2 * oh - 1)) * 3 + (w - (2 * ow - 1));
+        const size_t o = (((size_t)n * ho + oh) * wo + ow) * c + cg * E16;
+        const uint4 gv = *reinterpret_cast<const uint4*>(gy + o);
+        const T* pg = reinterpret_cast<const T*>(&gv);
+        uint8_t iv[E16];
+        if constexpr (E16 == 8) *reinterpret_cast<uint2*>(iv) = *reinterpret_cast<const uint2*>(idx + o);
+        else *reinterpret_cast<uint32_t*>(iv) = *reinterpret_cast<const uint32_t*>(idx + o);
+#pragma unroll
+        for (int e = 0; e < E16; ++e)
+          if (iv[e] == tap) s[e] += to_f32<T>(pg[e]);
+      }
+    const size_t xo = (((size_t)n * hi + h) * wi + w) * c + cg * E16;
+    const uint4 xv = *reinterpret_cast<const uint4*>(x + xo);
+    const T* px = reinterpret_cast<const T*>(&xv);
+    T ov[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(to_f32<T>(px[e]) > 0.f ? s[e] : 0.f);
+    *reinterpret_cast<uint4*>(gx + xo) = *reinterpret_cast<const uint4*>(ov);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fused Double-DQN target + TD loss + dQ   (train_q_network.py:134-169,180)
+// one thread per (sample, padded column); loss reduced per block, one atomic per block
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void td_loss_kernel(const vdqn_td_args a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = a.batch * a.ldq;
+  float my_loss = 0.f;
+  if (i < total) {
+    const int b = i / a.ldq, col = i - b * a.ldq;
+    float g = 0.f;
+    if (col < a.n_cat * a.n_act) {
+      const int c = col / a.n_act, ac = col - c * a.n_act;
+      const int act = (int)a.act[b];
+      if (ac == act) {
+        const float qb = a.q_before[(size_t)b * a.ldq + col];
+        const float* qo = a.q_after_online + (size_t)b * a.ldq + c * a.n_act;
+        int best = 0;
+        float bv = qo[0];
+        for (int k = 1; k < a.n_act; ++k) {
+          const float v = qo[k];
+          if (v > bv) {  // strict: first maximum wins (torch.argmax)
+            bv = v;
+            best = k;
+          }
+        }
+        float qa = a.q_after_target[(size_t)b * a.ldq + c * a.n_act + best];
+        qa = qa * (1.0f - a.term[b * a.n_cat + c]);
+        const float r = a.rew[b * a.n_cat + c];
+        float y = a.linear ? r + (qa - 0.1f) : r + a.gamma * qa;
+        if (a.clip_rect) y = fminf(fmaxf(y, 0.f), 1.f);
+        const float d = qb - y;
+        const float vm = a.use_valid ? a.valid[b * a.n_cat + c] : 1.0f;
+        my_loss = 0.5f * d * d * vm;
+        g = d * vm * a.inv_count;
+      }
+    }
+    if (a.dq) ((T*)a.dq)[i] = from_f32<T>(g);
+    if (a.dq_f32) a.dq_f32[i] = g;
+  }
+  // block reduction of the loss
+  __shared__ float red[4];
+  float v = my_loss;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = red[0] + red[1] + red[2] + red[3];
+    if (s != 0.f) atomicAdd(a.loss, s * a.inv_count);
+  }
+}
+
+// ground-truth branch (train_q_network.py:170-178)
+template <typename T>
+__global__ __launch_bounds__(256) void gt_loss_kernel(const float* __restrict__ q_before, const int64_t* __restrict__ act,
+                                                      const float* __restrict__ gt, float* loss, T* dq, float* dq_f32, int batch,
+                                                      int n_cat, int n_act, int ldq, float inv_count, int value_learning) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = batch * ldq;
+  float my_loss = 0.f;
+  if (i < total) {
+    const int b = i / ldq, col = i - b * ldq;
+    float g = 0.f;
+    if (col < n_cat * n_act) {
+      const int c = col / n_act, ac = col - c * n_act;
+      if (ac == (int)act[b]) {
+        const float qb = q_before[(size_t)b * ldq + col];
+        const float t = gt[b * n_cat + c];
+        if (value_learning) {
+          const bool nan = t != t;
+          const float mask = nan ? 0.f : 1.f;
+          const float d = qb * mask - (nan ? 0.f : t);
+          my_loss = 0.5f * d * d;
+          g = d * mask * inv_count;
+        } else {
+          const float d = qb - t;
+          my_loss = 0.5f * d * d;
+          g = d * inv_count;
+        }
+      }
+    }
+    if (dq) dq[i] = from_f32<T>(g);
+    if (dq_f32) dq_f32[i] = g;
+  }
+  __shared__ float red[4];
+  float v = my_loss;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Adam over a flat f32 range (torch.optim.Adam defaults; train_q_network.py:124,227)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float step_size, float beta1, float beta2,
+                                                   float inv_sqrt_bc2, float eps) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+#define VDQN_ADAM1(c)                                              \
+  mm.c = beta1 * mm.c + (1.0f - beta1) * gg.c;                     \
+  vv.c = beta2 * vv.c + (1.0f - beta2) * gg.c * gg.c;              \
+  pp.c = pp.c - step_size * (mm.c / (sqrtf(vv.c) * inv_sqrt_bc2 + eps));
+    VDQN_ADAM1(x) VDQN_ADAM1(y) VDQN_ADAM1(z) VDQN_ADAM1(w)
+#undef VDQN_ADAM1
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gg = g[i];
+    const float mm = beta1 * m[i] + (1.0f - beta1) * gg;
+    const float vv = beta2 * v[i] + (1.0f - beta2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] = p[i] - step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+  }
+}
+
+inline int grid_for(long total, int cap = 8192) {
+  long b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int vdqn_pack_input(const void* src, int32_t src_kind, void* dst, int32_t n_img, int32_t dtype, void* stream) {
+  VDQN_CHECK(src && dst && n_img > 0, "vdqn_pack_input: bad args");
+  VDQN_CHECK(src_kind == 0 || src_kind == 1, "vdqn_pack_input: src_kind %d", src_kind);
+  VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_pack_input: bad dtype");
+  const int g = grid_for((long)n_img * 115 * 115);
+  if (dtype == VDQN_BF16) hipLaunchKernelGGL((pack_input_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, src, src_kind, (bf16raw*)dst, n_img);
+  else hipLaunchKernelGGL((pack_input_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, src, src_kind, (float*)dst, n_img);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_maxpool_fwd(const void* in, void* out, uint8_t* idx, int32_t n_img, int32_t hi, int32_t wi, int32_t c, int32_t dtype,
+                                void* stream) {
+  VDQN_CHECK(in && out && idx && n_img > 0, "vdqn_maxpool_fwd: bad args");
+  VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_maxpool_fwd: bad dtype");
+  VDQN_CHECK(c % 8 == 0, "vdqn_maxpool_fwd: channels must be a multiple of 8");
+  const int ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
+  const int e16 = dtype == VDQN_BF16 ? 8 : 4;
+  const int g = grid_for((long)n_img * ho * wo * (c / e16), 65536);
+  if (dtype == VDQN_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)in, (bf16raw*)out, idx, n_img, hi, wi, c);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, idx, n_img, hi, wi, c);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_maxpool_bwd(const void* gy, const uint8_t* idx, const void* x, void* gx, int32_t n_img, int32_t hi, int32_t wi,
+                                int32_t c, int32_t dtype, void* stream) {
+  VDQN_CHECK(gy && idx && x && gx && n_img > 0, "vdqn_maxpool_bwd: bad args");
+  VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_maxpool_bwd: bad dtype");
+  VDQN_CHECK(c % 8 == 0, "vdqn_maxpool_bwd: channels must be a multiple of 8");
+  const int e16 = dtype == VDQN_BF16 ? 8 : 4;
+  const int g = grid_for((long)n_img * hi * wi * (c / e16), 65536);
+  if (dtype == VDQN_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)gy, idx, (const bf16raw*)x, (bf16raw*)gx, n_img, hi, wi, c);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)gy, idx, (const float*)x, (float*)gx, n_img, hi, wi, c);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_td_loss(const vdqn_td_args* a, void* stream) {
+  VDQN_CHECK(a && a->q_before && a->q_after_online && a->q_after_target && a->act && a->rew && a->term && a->loss, "vdqn_td_loss: null arg");
+  VDQN_CHECK(!a->use_valid || a->valid, "vdqn_td_loss: use_valid without valid mask");
+  VDQN_CHECK(a->batch > 0 && a->n_cat > 0 && a->n_act > 0 && a->ldq >= a->n_cat * a->n_act, "vdqn_td_loss: bad dims");
+  VDQN_CHECK(a->dtype == VDQN_F32 || a->dtype == VDQN_BF16, "vdqn_td_loss: bad dtype");
+  const int g = (a->batch * a->ldq + 255) / 256;
+  if (a->dtype == VDQN_BF16) hipLaunchKernelGGL((td_loss_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL((td_loss_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, *a);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, float* loss, void* dq, float* dq_f32, int32_t batch,
+                            int32_t n_cat, int32_t n_act, int32_t ldq, float inv_count, int32_t value_learning, int32_t dtype, void* stream) {
+  VDQN_CHECK(q_before && act && gt && loss, "vdqn_gt_loss: null arg");
+  VDQN_CHECK(batch > 0 && ldq >= n_cat * n_act, "vdqn_gt_loss: bad dims");
+  VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_gt_loss: bad dtype");
+  const int g = (batch * ldq + 255) / 256;
+  if (dtype == VDQN_BF16) hipLaunchKernelGGL((gt_loss_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, q_before, act, gt, loss, (bf16raw*)dq, dq_f32, batch, n_cat, n_act, ldq, inv_count, value_learning);
+  else hipLaunchKernelGGL((gt_loss_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, q_before, act, gt, loss, (float*)dq, dq_f32, batch, n_cat, n_act, ldq, inv_count, value_learning);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1, float beta2, float eps,
+                         void* stream) {
+  VDQN_CHECK(p && g && m && v && n > 0 && step >= 1, "vdqn_adam: bad args");
+  VDQN_CHECK((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "vdqn_adam: pointers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const int grid = grid_for(n / 4 + 1, 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, inv_sqrt_bc2, eps);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}

@@ -1,0 +1,245 @@
+"""Host-side driver of the HIP engine (libvdqn.so): owns the torch-allocated device buffers and calls
+the C ABI.  PyTorch is used for device memory and streams only — all arithmetic runs in the HIP library.
+
+Mirrors the pieces of ``train_q_network.py`` that touch the device:
+  * model / target_net / Adam construction       (:119-124)
+  * target sync                                   (:121,208,215-216)
+  * zero_grad / process_batch / backward / step   (:222-227)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+DTYPES = {"f32": _lib.VDQN_F32, "fp32": _lib.VDQN_F32, "float32": _lib.VDQN_F32,
+          "bf16": _lib.VDQN_BF16, "bfloat16": _lib.VDQN_BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(device=None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.VdqnError("video_dqn_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+@dataclass
+class ParamSlot:
+    name: str
+    offset: int
+    numel: int
+    shape: tuple
+    kind: int      # 0 trainable, 1 frozen (resnet.fc), 2 running_mean, 3 running_var
+    param_id: int
+    stage: int
+
+
+class NetEngine:
+    """One HabitatDQNMultiAction instance on the device: flat f32 master parameters + BN statistics."""
+
+    def __init__(self, action_dim=3, num_classes=5, num_frames=1, extra_capacity=True, dtype="bf16",
+                 max_batch=512, device=None):
+        self.lib = _lib.load()
+        self.device = require_gpu(device)
+        if not extra_capacity:
+            raise NotImplementedError("ARCHITECTURE='basic' (BatchNorm in train mode) is not implemented yet; "
+                                      "use ARCHITECTURE: 'extra_capacity' (configs/experiments/real_data)")
+        self.action_dim, self.num_classes, self.num_frames = action_dim, num_classes, num_frames
+        self.dtype_name = "bf16" if DTYPES[dtype] == _lib.VDQN_BF16 else "f32"
+        self.cfg = _lib.NetConfig(action_dim, num_classes, num_frames, 1, DTYPES[dtype], max_batch)
+        h = C.c_void_p()
+        _lib.check(self.lib.vdqn_net_create(C.byref(self.cfg), C.byref(h)), "vdqn_net_create")
+        self.handle = h
+        self.max_batch = max_batch
+        self.slots: "OrderedDict[str, ParamSlot]" = OrderedDict()
+        info = _lib.ParamInfo()
+        for i in range(self.lib.vdqn_net_num_params(h)):
+            _lib.check(self.lib.vdqn_net_param_info(h, i, C.byref(info)), "vdqn_net_param_info")
+            name = info.name.decode()
+            self.slots[name] = ParamSlot(name, info.offset, info.numel, tuple(info.shape[:info.ndim]), info.kind,
+                                         info.param_id, info.stage)
+        self.params_numel = self.lib.vdqn_net_params_numel(h)
+        self.trainable_numel = self.lib.vdqn_net_trainable_numel(h)
+        self.bnstats_numel = self.lib.vdqn_net_bnstats_numel(h)
+        self.packed_bytes = self.lib.vdqn_net_packed_bytes(h)
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(self.params_numel, dtype=torch.float32, device=self.device)
+            self.bnstats = torch.zeros(self.bnstats_numel, dtype=torch.float32, device=self.device)
+            self.packed = torch.zeros(self.packed_bytes, dtype=torch.uint8, device=self.device)
+        self._packed_version = -1
+        self._version = 0
+        self._acts: Dict[int, torch.Tensor] = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.vdqn_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- parameter views -------------------------------------------------------------------------
+    def view(self, name: str) -> torch.Tensor:
+        s = self.slots[name]
+        base = self.params if s.kind in (0, 1) else self.bnstats
+        return base[s.offset:s.offset + s.numel].view(s.shape)
+
+    def stage_range(self, stage: int):
+        b, e = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.vdqn_net_stage_range(self.handle, stage, C.byref(b), C.byref(e)), "stage_range")
+        return b.value, e.value
+
+    def load_tensors(self, state_dict) -> None:
+        """Copy every tensor the engine owns (by its reference state_dict name) from ``state_dict``."""
+        with torch.no_grad():
+            for name in self.slots:
+                self.view(name).copy_(state_dict[name].to(torch.float32))
+        self.mark_dirty()
+
+    def mark_dirty(self):
+        """Call after the master parameters changed (load_state_dict, optimiser step)."""
+        self._version += 1
+
+    # ---- packing + forward -----------------------------------------------------------------------
+    def pack_weights(self, packed: Optional[torch.Tensor] = None, with_dgrad: bool = False, params=None, bnstats=None):
+        packed = self.packed if packed is None else packed
+        _lib.check(self.lib.vdqn_net_pack_weights(self.handle, _ptr(self.params if params is None else params),
+                                                  _ptr(self.bnstats if bnstats is None else bnstats),
+                                                  _ptr(packed), int(with_dgrad), _stream()), "vdqn_net_pack_weights")
+
+    def acts_bytes(self, n_samples: int) -> int:
+        return self.lib.vdqn_net_acts_bytes(self.handle, n_samples)
+
+    def bwd_bytes(self, n_samples: int) -> int:
+        return self.lib.vdqn_net_bwd_bytes(self.handle, n_samples)
+
+    def _acts_for(self, n: int) -> torch.Tensor:
+        buf = self._acts.get(n)
+        if buf is None:
+            self._acts.clear()
+            buf = torch.empty(self.acts_bytes(n), dtype=torch.uint8, device=self.device)
+            self._acts[n] = buf
+        return buf
+
+    def forward(self, frames: torch.Tensor, src_kind: int, n_samples: int) -> torch.Tensor:
+        """frames: contiguous device tensor (uint8 NHWC frames if src_kind == 0, f32 NCHW if 1)."""
+        if n_samples > self.max_batch:
+            raise _lib.VdqnError(f"batch {n_samples} exceeds max_batch {self.max_batch}")
+        with torch.cuda.device(self.device):
+            if self._packed_version != self._version:
+                self.pack_weights()
+                self._packed_version = self._version
+            q = torch.empty((n_samples, self.num_classes * self.action_dim), dtype=torch.float32, device=self.device)
+            acts = self._acts_for(n_samples)
+            _lib.check(self.lib.vdqn_net_forward(self.handle, _ptr(self.packed), _ptr(frames), src_kind, n_samples,
+                                                 _ptr(acts), _ptr(q), _stream()), "vdqn_net_forward")
+        return q
+
+
+class TDStepper:
+    """Device state of the training loop: target-network weights, Adam moments, workspaces, and one TD update.
+
+    ``step()`` follows train_q_network.py:213-227: target sync check (before the update), forward x3 (the two
+    online passes run as one 2B batch), Double-DQN target + loss, backward, Adam."""
+
+    def __init__(self, net: NetEngine, batch: int, lr: float, gamma: float, clip_rect: bool, linear: bool = False,
+                 remove_before_reward: bool = False, train_on_ground_truth: bool = False, value_learning: bool = False,
+                 target_update_interval: int = 8000, betas=(0.9, 0.999), eps: float = 1e-8, world_size: int = 1,
+                 allreduce=None):
+        self.net, self.B = net, batch
+        self.lib = net.lib
+        if 2 * batch > net.max_batch:
+            raise _lib.VdqnError(f"TDStepper(batch={batch}) needs NetEngine(max_batch>={2 * batch})")
+        self.lr, self.gamma, self.betas, self.eps = lr, gamma, betas, eps
+        self.clip_rect, self.linear, self.rbr = clip_rect, linear, remove_before_reward
+        self.gtb, self.value_learning = train_on_ground_truth, value_learning
+        self.tui = target_update_interval
+        self.world_size = world_size
+        self.allreduce = allreduce  # callable(tensor_slice, stage) or None
+        dev = net.device
+        nt = net.trainable_numel
+        with torch.cuda.device(dev):
+            self.packed_online = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
+            self.packed_target = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
+            self.acts_online = torch.empty(net.acts_bytes(batch if self.gtb else 2 * batch), dtype=torch.uint8, device=dev)
+            self.acts_target = None if self.gtb else torch.empty(net.acts_bytes(batch), dtype=torch.uint8, device=dev)
+            self.bwd = torch.empty(net.bwd_bytes(batch), dtype=torch.uint8, device=dev)
+            self.grads = torch.zeros(nt, dtype=torch.float32, device=dev)
+            self.exp_avg = torch.zeros(nt, dtype=torch.float32, device=dev)
+            self.exp_avg_sq = torch.zeros(nt, dtype=torch.float32, device=dev)
+            self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.q_before = torch.zeros((batch, net.num_classes * net.action_dim), dtype=torch.float32, device=dev)
+            self._ones = torch.ones((batch, net.num_classes), dtype=torch.float32, device=dev)
+        self.adam_step = 0
+        self.sample_number = 0
+        self.stage_ranges = [net.stage_range(s) for s in range(3)]
+        self.sync_target()
+
+    def sync_target(self):
+        """target_net.load_state_dict(model.state_dict()) (train_q_network.py:121,208,216): the target network
+        only ever runs forward, so its state is the packed (BN-folded) copy of the current online weights."""
+        with torch.cuda.device(self.net.device):
+            self.net.pack_weights(self.packed_target, with_dgrad=False)
+
+    def _args(self, before, after, src_kind, act, rew, term, valid, gt) -> _lib.StepArgs:
+        n = self.net
+        a = _lib.StepArgs()
+        a.params, a.bnstats = _ptr(n.params), _ptr(n.bnstats)
+        a.packed_online, a.packed_target = _ptr(self.packed_online), _ptr(self.packed_target)
+        a.before, a.after, a.src_kind, a.batch = _ptr(before), _ptr(after), src_kind, self.B
+        a.act, a.rew, a.term, a.valid, a.gt = _ptr(act), _ptr(rew), _ptr(term), _ptr(valid), _ptr(gt)
+        a.gamma = self.gamma
+        a.inv_count = 1.0 / (n.num_classes * self.B * self.world_size)
+        a.clip_rect, a.linear, a.use_valid = int(self.clip_rect), int(self.linear), int(self.rbr)
+        a.train_on_ground_truth, a.value_learning = int(self.gtb), int(self.value_learning)
+        a.acts_online, a.acts_target, a.bwd = _ptr(self.acts_online), _ptr(self.acts_target), _ptr(self.bwd)
+        a.grads, a.loss, a.q_before = _ptr(self.grads), _ptr(self.loss), _ptr(self.q_before)
+        return a
+
+    def forward_backward(self, before, after, src_kind, act, rew, term, valid=None, gt=None):
+        """Everything of one update up to (and including) the gradient all-reduce; no optimiser step."""
+        n = self.net
+        keep = (before, after, act, rew, term, valid, gt)  # keep inputs alive until the launches are queued
+        with torch.cuda.device(n.device):
+            a = self._args(before, after, src_kind, act, rew, term, valid if valid is not None else self._ones, gt)
+            st = _stream()
+            _lib.check(self.lib.vdqn_net_td_forward(n.handle, C.byref(a), st), "vdqn_net_td_forward")
+            for stage in range(3):
+                _lib.check(self.lib.vdqn_net_backward_stage(n.handle, C.byref(a), stage, st), "vdqn_net_backward_stage")
+                if self.allreduce is not None:
+                    b, e = self.stage_ranges[stage]
+                    self.allreduce(self.grads[b:e], stage)
+        del keep
+
+    def optimizer_step(self):
+        n = self.net
+        self.adam_step += 1
+        with torch.cuda.device(n.device):
+            _lib.check(self.lib.vdqn_adam(_ptr(n.params), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                          n.trainable_numel, self.adam_step, self.lr, self.betas[0], self.betas[1],
+                                          self.eps, _stream()), "vdqn_adam")
+        n.mark_dirty()
+
+    def step(self, before, after, src_kind, act, rew, term, valid=None, gt=None, finish_allreduce=None) -> torch.Tensor:
+        """One iteration of the reference loop body (train_q_network.py:213-227).  Returns the device loss scalar
+        (no host sync)."""
+        self.sample_number += 1
+        if self.sample_number % self.tui == 0:
+            self.sync_target()
+        self.forward_backward(before, after, src_kind, act, rew, term, valid, gt)
+        if finish_allreduce is not None:
+            finish_allreduce()
+        self.optimizer_step()
+        return self.loss

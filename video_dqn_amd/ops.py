@@ -1,0 +1,130 @@
+"""Operator-level Python wrappers over the C ABI (used by the per-kernel parity tests and available to
+callers that want single ops).  Tensors are torch device tensors; layouts are the ABI's (NHWC activations,
+[co_pad][r][s][ci] weights)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .engine import _ptr, _stream, require_gpu
+
+TORCH_DTYPE = {_lib.VDQN_F32: torch.float32, _lib.VDQN_BF16: torch.bfloat16}
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.VDQN_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.VDQN_BF16
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: int, s: int, stride: int, pad: int,
+           bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+           relu: bool = False, mode: int = 0, pix_stride: Optional[int] = None, ci: Optional[int] = None,
+           want_f32: bool = False, ldo: Optional[int] = None):
+    """x: [n, hi, wi, c] NHWC; wt: [co_pad, r, s, ci].  Returns out [n, ho, wo, ldo] (and the f32 copy)."""
+    lib = _lib.load()
+    require_gpu()
+    n, hi, wi, cx = x.shape
+    ci = cx if ci is None else ci
+    pix_stride = cx if pix_stride is None else pix_stride
+    ldo = co if ldo is None else ldo
+    out = torch.empty((n, ho, wo, ldo), dtype=x.dtype, device=x.device)
+    out_f32 = torch.empty((n, ho, wo, ldo), dtype=torch.float32, device=x.device) if want_f32 else None
+    a = _lib.ConvArgs()
+    a.in_, a.wt, a.bias, a.resid, a.mask = _ptr(x), _ptr(wt), _ptr(bias), _ptr(resid), _ptr(mask)
+    a.out, a.out_f32 = _ptr(out), _ptr(out_f32)
+    a.n_img, a.hi, a.wi, a.ci, a.pix_stride = n, hi, wi, ci, pix_stride
+    a.ho, a.wo, a.co, a.ldo = ho, wo, co, ldo
+    a.r, a.s, a.stride, a.pad = r, s, stride, pad
+    a.mode, a.relu, a.dtype = mode, int(relu), dtype_code(x)
+    _lib.check(lib.vdqn_conv2d(C.byref(a), _stream()), "vdqn_conv2d")
+    return (out, out_f32) if want_f32 else out
+
+
+def conv2d_wgrad(gy: torch.Tensor, x: torch.Tensor, *, co: int, r: int, s: int, stride: int, pad: int,
+                 ci: Optional[int] = None, pix_stride: Optional[int] = None, splitk: int = 0, want_dbias: bool = True):
+    """gy: [n, ho, wo, ldg]; x: [n, hi, wi, c].  Returns dw f32 [co_pad, r, s, ci] (and dbias [co_pad])."""
+    lib = _lib.load()
+    n, ho, wo, ldg = gy.shape
+    _, hi, wi, cx = x.shape
+    ci = cx if ci is None else ci
+    pix_stride = cx if pix_stride is None else pix_stride
+    co_pad = (co + 63) // 64 * 64
+    dw = torch.zeros((co_pad, r, s, ci), dtype=torch.float32, device=x.device)
+    db = torch.zeros((co_pad,), dtype=torch.float32, device=x.device) if want_dbias else None
+    a = _lib.WgradArgs()
+    a.gy, a.x, a.dw, a.dbias = _ptr(gy), _ptr(x), _ptr(dw), _ptr(db)
+    a.n_img, a.hi, a.wi, a.ci, a.pix_stride = n, hi, wi, ci, pix_stride
+    a.ho, a.wo, a.co, a.ldg = ho, wo, co, ldg
+    a.r, a.s, a.stride, a.pad = r, s, stride, pad
+    a.splitk, a.dtype = splitk, dtype_code(x)
+    _lib.check(lib.vdqn_conv2d_wgrad(C.byref(a), _stream()), "vdqn_conv2d_wgrad")
+    return (dw, db) if want_dbias else dw
+
+
+def pack_input(src: torch.Tensor, src_kind: int, n_img: int, dtype: torch.dtype) -> torch.Tensor:
+    lib = _lib.load()
+    dst = torch.empty((n_img, 115, 115, 16), dtype=dtype, device=src.device)
+    _lib.check(lib.vdqn_pack_input(_ptr(src), src_kind, _ptr(dst), n_img, dtype_code(dst), _stream()), "vdqn_pack_input")
+    return dst
+
+
+def maxpool_fwd(x: torch.Tensor):
+    lib = _lib.load()
+    n, hi, wi, c = x.shape
+    ho, wo = (hi - 1) // 2 + 1, (wi - 1) // 2 + 1
+    out = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.vdqn_maxpool_fwd(_ptr(x), _ptr(out), _ptr(idx), n, hi, wi, c, dtype_code(x), _stream()), "vdqn_maxpool_fwd")
+    return out, idx
+
+
+def maxpool_bwd(gy: torch.Tensor, idx: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    n, hi, wi, c = x.shape
+    gx = torch.empty_like(x)
+    _lib.check(lib.vdqn_maxpool_bwd(_ptr(gy), _ptr(idx), _ptr(x), _ptr(gx), n, hi, wi, c, dtype_code(x), _stream()), "vdqn_maxpool_bwd")
+    return gx
+
+
+def td_loss(q_before, q_after_online, q_after_target, act, rew, term, valid=None, *, n_cat=5, n_act=3, gamma=0.99,
+            inv_count=None, clip_rect=True, linear=False, out_dtype=torch.float32):
+    """q_*: f32 [B, ldq] (ldq >= n_cat*n_act).  Returns (loss[1], dq[B, ldq] out_dtype, dq_f32)."""
+    lib = _lib.load()
+    B, ldq = q_before.shape
+    dev = q_before.device
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    dq = torch.empty((B, ldq), dtype=out_dtype, device=dev)
+    dq32 = torch.empty((B, ldq), dtype=torch.float32, device=dev)
+    a = _lib.TdArgs()
+    a.q_before, a.q_after_online, a.q_after_target = _ptr(q_before), _ptr(q_after_online), _ptr(q_after_target)
+    a.act, a.rew, a.term, a.valid = _ptr(act), _ptr(rew), _ptr(term), _ptr(valid)
+    a.loss, a.dq, a.dq_f32 = _ptr(loss), _ptr(dq), _ptr(dq32)
+    a.batch, a.n_cat, a.n_act, a.ldq = B, n_cat, n_act, ldq
+    a.gamma = gamma
+    a.inv_count = (1.0 / (B * n_cat)) if inv_count is None else inv_count
+    a.clip_rect, a.linear, a.use_valid, a.dtype = int(clip_rect), int(linear), int(valid is not None), dtype_code(dq)
+    _lib.check(lib.vdqn_td_loss(C.byref(a), _stream()), "vdqn_td_loss")
+    return loss, dq, dq32
+
+
+def gt_loss(q_before, act, gt, *, n_cat=5, n_act=3, inv_count=None, value_learning=False):
+    lib = _lib.load()
+    B, ldq = q_before.shape
+    dev = q_before.device
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    dq32 = torch.empty((B, ldq), dtype=torch.float32, device=dev)
+    inv = (1.0 / (B * n_cat)) if inv_count is None else inv_count
+    _lib.check(lib.vdqn_gt_loss(_ptr(q_before), _ptr(act), _ptr(gt), _ptr(loss), None, _ptr(dq32), B, n_cat, n_act, ldq,
+                                inv, int(value_learning), _lib.VDQN_F32, _stream()), "vdqn_gt_loss")
+    return loss, dq32
+
+
+def adam(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    lib = _lib.load()
+    _lib.check(lib.vdqn_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, lr, beta1, beta2, eps, _stream()), "vdqn_adam")
