@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: (s,a,r,s') TD-updates/s of one full Q-learning update
+(online forward over [s; s'], target forward over s', Double-DQN target + TD loss, backward, Adam) on
+synthetic 224x224 RGB frames — BASELINE.json's metric on its config[1] (ResNet-18 HabitatDQNMultiAction,
+5 categories x 3 actions, batch 256 per GPU, bf16, extra_capacity / real_data hyper-parameters).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One process per GPU; for N > 1 the flat gradient is all-reduced over RCCL in three buckets as the staged
+backward completes them (weak scaling: 256 samples per GPU).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GFLOP_PER_TUPLE_F1 = 17.982854656  # 3 fwd + 1 bwd, SURVEY.md §8(d) (8,991,427,328 MAC)
+PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
+    ap.add_argument("--frames", type=int, default=1, help="views per sample (12 = BASELINE config 5)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--target-update-interval", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--no-profile", action="store_true", help="skip the event-profiled steps (roofline = null)")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch: int, steps: int):
+    """The oracle (oracle/ref_cpu.py, a torch-CPU fp32 restatement of the reference path) timed on this box's
+    host cores with all cores, and once with torch.set_num_threads(1) as the reference itself runs
+    (train_q_network.py:85).  Reported, never shipped: this is the only place bench.py touches oracle/."""
+    from oracle import ref_cpu
+    from video_dqn_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tr = ref_cpu.Trainer(ref_cpu.default_config(), synth.make_state_dict(7))
+    (tup, _) = synth.make_batch(1, batch, 1)
+    tr.step(tup)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(tup)
+    dt = (time.perf_counter() - t0) / steps
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    tr.step(tup)
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(cores)
+    return {"value": round(batch / dt, 3), "unit": "tuples/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full TD updates at batch {batch} (fp32, torch-CPU oracle of the reference path), all host cores",
+            "single_thread_value": round(batch / dt1, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from video_dqn_amd import _lib, synth
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    from video_dqn_amd.dist import BucketAllReduce
+
+    B, F = args.batch, args.frames
+    net = NetEngine(3, 5, F, True, args.dtype, 2 * B, device=dev)
+    net.load_tensors(synth.make_state_dict(4, num_frames=F))  # same seed on every rank: replicas start identical
+    comm = BucketAllReduce(world) if world > 1 else None
+    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=args.target_update_interval,
+                    world_size=world, allreduce=(comm.launch if comm else None))
+
+    # synthetic minibatch, resident in HBM before the timed region: uint8 frames (normalise fused into packing)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    before = torch.randint(0, 256, (B, F, 224, 224, 3), dtype=torch.uint8, device=dev, generator=g)
+    after = torch.randint(0, 256, (B, F, 224, 224, 3), dtype=torch.uint8, device=dev, generator=g)
+    act = torch.randint(0, 3, (B,), dtype=torch.int64, device=dev, generator=g)
+    rew = (torch.rand((B, 5), device=dev, generator=g) < 0.05).float()
+    term = rew.clone()
+
+    def one_step():
+        return stp.step(before, after, 0, act, rew, term, finish_allreduce=(comm.finish if comm else None))
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_val = float(loss.item())
+
+    # ---- live per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel ----
+    roofline = None
+    kernels = None
+    if not args.no_profile and rank == 0:
+        _lib.profile_enable(True)
+        for _ in range(args.profile_steps):
+            stp.forward_backward(before, after, 0, act, rew, term)
+            if comm:
+                comm.finish()
+            stp.optimizer_step()
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+        _lib.profile_enable(False)
+        tot_ms = sum(v["ms"] for v in prof.values())
+        kernels = {k: {"launches_per_step": v["launches"] // args.profile_steps, "ms_per_step": round(v["ms"] / args.profile_steps, 4),
+                       "share": round(v["ms"] / tot_ms, 4),
+                       "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] > 0 else None,
+                       "alg_gbs": round(v["bytes"] / v["ms"] / 1e6, 1)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        name, v = dom
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        if v["flops"] > 0:
+            ach = v["flops"] / v["ms"] / 1e9
+            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None,
+                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
+                        "alg_flops_per_launch": round(v["flops"] / v["launches"]),
+                        "measured": f"HIP events around every launch, {args.profile_steps} steps right after the timed region"}
+        else:
+            ach = v["bytes"] / v["ms"] / 1e6
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"]}
+
+    if rank == 0:
+        tuples = B * world * args.steps
+        value = tuples / elapsed
+        gflop_tuple = GFLOP_PER_TUPLE_F1 * F
+        out = {
+            "metric": "(s,a,r,s') TD-updates/sec, 224x224 frames, batch 256, 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "tuples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "HabitatDQNMultiAction ResNet-18 extra_capacity, 5 categories x 3 actions, full TD update "
+                                   "(online fwd on [s;s'], target fwd on s', Double-DQN target + L2 TD loss, backward, Adam)",
+                       "batch_per_gpu": B, "global_batch": B * world, "frames_per_sample": F, "frame": "224x224x3 uint8 (normalise fused)",
+                       "parallelism": f"dp{world}", "target_update_interval": args.target_update_interval,
+                       "gamma": 0.99, "loss_clip": "rect", "lr": 1e-4},
+            "model_tflops": round(value * gflop_tuple / 1e3, 2),
+            "model_frac_of_bf16_peak": round(value * gflop_tuple / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "loss": loss_val,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,19 @@ const char* vdqn_last_error(void);
 /* ABI version; bumped on any signature change */
 int vdqn_abi_version(void);
 
+/* Launch profiler (off by default).  While enabled, every kernel launch of the library is bracketed by HIP
+ * events on its launch stream; collect() synchronises those events and returns one entry per kernel symbol:
+ * launches, summed device milliseconds, summed algorithmic FLOPs and algorithmic bytes.  Resets on collect. */
+typedef struct vdqn_prof_entry {
+  char name[48];
+  int64_t launches;
+  double ms;
+  double flops;
+  double bytes;
+} vdqn_prof_entry;
+int vdqn_profile_enable(int on);
+int vdqn_profile_collect(vdqn_prof_entry* out, int max_entries);
+
 /* ------------------------------------------------------------------------------------------------
  * Operator level (each is also what the engine below launches).
  * ------------------------------------------------------------------------------------------------ */
@@ -129,9 +142,10 @@ int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, flo
                  int32_t dtype, void* stream);
 
 /* torch.optim.Adam step (train_q_network.py:124,227) over one flat f32 range:
- *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
-int vdqn_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1,
-              float beta2, float eps, void* stream);
+ *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * Hyper-parameters are doubles like torch's python scalars (1-b2 is formed in double before rounding to f32). */
+int vdqn_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
+              double beta2, double eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Engine level: the whole HabitatDQNMultiAction network and one TD update.
@@ -178,6 +192,13 @@ int vdqn_net_stage_range(const vdqn_net* net, int stage, int64_t* begin, int64_t
 int64_t vdqn_net_packed_bytes(const vdqn_net* net);
 int64_t vdqn_net_acts_bytes(const vdqn_net* net, int32_t n_samples);
 int64_t vdqn_net_bwd_bytes(const vdqn_net* net, int32_t n_samples);
+
+/* Byte offset of a named tensor inside the `acts` / `bwd` workspaces (for layer-by-layer parity tests and
+ * debuggers); -1 if the name is unknown.  acts names: t_in c1 pool idx h0..h7 o0..o7 ds2 ds4 ds6 f8 l0 l1 q qf;
+ * bwd names: dq g_l1 g_l0 g_f8 g_o0..g_o7 g_h0..g_h7 dsg2 dsg4 dsg6 g_pool g_c1, and dw:<layer> / db:<layer>
+ * (f32 packed-layout weight-gradient accumulators, e.g. "dw:resnet.layer1.0.conv1"). */
+int64_t vdqn_net_act_offset(const vdqn_net* net, int32_t n_samples, const char* name);
+int64_t vdqn_net_bwd_offset(const vdqn_net* net, int32_t n_samples, const char* name);
 
 /* Fold eval-mode BatchNorm into the convolutions and pack the master weights (OIHW f32) into the K-contiguous
  * forward and data-gradient operands (set_train semantics: archs/HabitatDQNMultiAction.py:37-40 — in

@@ -49,6 +49,11 @@ class ParamInfo(C.Structure):
                 ("shape", c_i32 * 4), ("kind", c_i32), ("param_id", c_i32), ("stage", c_i32)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", c_i64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class StepArgs(C.Structure):
     _fields_ = [("params", c_vp), ("bnstats", c_vp), ("packed_online", c_vp), ("packed_target", c_vp),
                 ("before", c_vp), ("after", c_vp), ("src_kind", c_i32), ("batch", c_i32),
@@ -63,6 +68,8 @@ class StepArgs(C.Structure):
 _SIGS = {
     "vdqn_last_error": (C.c_char_p, []),
     "vdqn_abi_version": (C.c_int, []),
+    "vdqn_profile_enable": (C.c_int, [C.c_int]),
+    "vdqn_profile_collect": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "vdqn_conv2d": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
     "vdqn_conv2d_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
     "vdqn_pack_input": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp]),
@@ -70,7 +77,7 @@ _SIGS = {
     "vdqn_maxpool_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_td_loss": (C.c_int, [C.POINTER(TdArgs), c_vp]),
     "vdqn_gt_loss": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
-    "vdqn_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "vdqn_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_vp]),
     "vdqn_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(c_vp)]),
     "vdqn_net_destroy": (None, [c_vp]),
     "vdqn_net_num_params": (C.c_int, [c_vp]),
@@ -82,6 +89,8 @@ _SIGS = {
     "vdqn_net_packed_bytes": (c_i64, [c_vp]),
     "vdqn_net_acts_bytes": (c_i64, [c_vp, c_i32]),
     "vdqn_net_bwd_bytes": (c_i64, [c_vp, c_i32]),
+    "vdqn_net_act_offset": (c_i64, [c_vp, c_i32, C.c_char_p]),
+    "vdqn_net_bwd_offset": (c_i64, [c_vp, c_i32, C.c_char_p]),
     "vdqn_net_pack_weights": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "vdqn_net_forward": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vdqn_net_td_forward": (C.c_int, [c_vp, C.POINTER(StepArgs), c_vp]),
@@ -119,3 +128,15 @@ def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().vdqn_last_error()
         raise VdqnError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def profile_enable(on: bool) -> None:
+    load().vdqn_profile_enable(int(on))
+
+
+def profile_collect():
+    """-> {kernel: dict(launches, ms, flops, bytes)}; synchronises the recorded events and resets."""
+    buf = (ProfEntry * 64)()
+    n = load().vdqn_profile_collect(buf, 64)
+    return {buf[i].name.decode(): dict(launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops, bytes=buf[i].bytes)
+            for i in range(n)}

@@ -58,6 +58,16 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
 }
 
 void vdqn_set_error(const char* fmt, ...);
+
+// launch profiler hooks (profile.hip); no-ops unless vdqn_profile_enable(1)
+void vdqn_prof_begin(const char* tag, double flops, double bytes, hipStream_t st);
+void vdqn_prof_end(hipStream_t st);
+extern thread_local double g_prof_alg_flops;  // engine sets the algorithmic FLOPs of the next launch (padding excluded)
+struct ProfScope {
+  hipStream_t st;
+  ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : st(s) { vdqn_prof_begin(tag, flops, bytes, s); }
+  ~ProfScope() { vdqn_prof_end(st); }
+};
 #define VDQN_CHECK(cond, ...)        \
   do {                               \
     if (!(cond)) {                   \

@@ -507,6 +507,7 @@ int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, c
   a.stride = L.kind == K_CONV1_S2D ? 1 : L.stride;
   a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
   a.mode = 0; a.relu = relu; a.dtype = net->cfg.dtype;
+  g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
   return vdqn_conv2d(&a, st);
 }
 
@@ -525,6 +526,7 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
   a.ho = L.hi; a.wo = L.wi; a.co = L.k_ci; a.ldo = L.k_ci;
   a.r = L.k_r; a.s = L.k_s; a.stride = L.stride; a.pad = L.pad;
   a.mode = 1; a.relu = 0; a.dtype = net->cfg.dtype;
+  g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
   return vdqn_conv2d(&a, st);
 }
 
@@ -541,6 +543,7 @@ int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const voi
   a.stride = L.kind == K_CONV1_S2D ? 1 : L.stride;
   a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
   a.splitk = 0; a.dtype = net->cfg.dtype;
+  g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
   return vdqn_conv2d_wgrad(&a, st);
 }
 
@@ -623,9 +626,45 @@ extern "C" int64_t vdqn_net_packed_bytes(const vdqn_net* net) { return net->pack
 extern "C" int64_t vdqn_net_acts_bytes(const vdqn_net* net, int32_t n_samples) { return act_layout(net, n_samples).total; }
 extern "C" int64_t vdqn_net_bwd_bytes(const vdqn_net* net, int32_t n_samples) { return bwd_layout(net, n_samples).total; }
 
+static int64_t indexed(const char* name, const char* prefix, const int64_t* arr) {
+  const size_t n = strlen(prefix);
+  if (strncmp(name, prefix, n) != 0 || name[n] < '0' || name[n] > '7' || name[n + 1] != 0) return -2;
+  return arr[name[n] - '0'];
+}
+extern "C" int64_t vdqn_net_act_offset(const vdqn_net* net, int32_t n_samples, const char* name) {
+  if (!net || !name) return -1;
+  const ActLayout A = act_layout(net, n_samples);
+  const struct { const char* n; int64_t v; } tab[] = {{"t_in", A.t_in}, {"c1", A.c1}, {"pool", A.pool}, {"idx", A.idx}, {"f8", A.f8},
+                                                     {"l0", A.l0}, {"l1", A.l1}, {"q", A.q}, {"qf", A.qf}};
+  for (auto& t : tab)
+    if (strcmp(t.n, name) == 0) return t.v;
+  int64_t v;
+  if ((v = indexed(name, "h", A.h)) != -2) return v;
+  if ((v = indexed(name, "o", A.o)) != -2) return v;
+  if ((v = indexed(name, "ds", A.ds)) != -2) return v;
+  return -1;
+}
+extern "C" int64_t vdqn_net_bwd_offset(const vdqn_net* net, int32_t n_samples, const char* name) {
+  if (!net || !name) return -1;
+  const BwdLayout W = bwd_layout(net, n_samples);
+  const struct { const char* n; int64_t v; } tab[] = {{"dq", W.dq}, {"g_l1", W.g_l1}, {"g_l0", W.g_l0}, {"g_f8", W.g_f8},
+                                                     {"g_pool", W.g_pool}, {"g_c1", W.g_c1}};
+  for (auto& t : tab)
+    if (strcmp(t.n, name) == 0) return t.v;
+  int64_t v;
+  if ((v = indexed(name, "g_o", W.g_o)) != -2) return v;
+  if ((v = indexed(name, "g_h", W.g_h)) != -2) return v;
+  if ((v = indexed(name, "dsg", W.dsg)) != -2) return v;
+  if (strncmp(name, "dw:", 3) == 0 || strncmp(name, "db:", 3) == 0)
+    for (auto& L : net->layers)
+      if (L.name == name + 3) return name[1] == 'w' ? L.dw_off : L.db_off;
+  return -1;
+}
+
 extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad, void* stream) {
   VDQN_CHECK(net && params && bnstats && packed, "vdqn_net_pack_weights: null arg");
   dim3 grid(256, (unsigned)net->layers.size(), 2);
+  ProfScope ps_("fold_weights", 0.0, (double)net->trainable_numel * 4.0 + (double)net->packed_bytes * (with_dgrad ? 1.0 : 0.5), (hipStream_t)stream);
   if (net->cfg.dtype == VDQN_BF16)
     hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, with_dgrad);
   else
@@ -771,6 +810,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   int max_co = 0;
   for (int i = net->layer_stage_first[stage]; i < net->layer_stage_first[stage] + net->layer_stage_count[stage]; ++i)
     max_co = net->layers[i].co > max_co ? net->layers[i].co : max_co;
+  ProfScope ps_("unfold_grads", 0.0, (double)(net->stage_end[stage] - net->stage_begin[stage]) * 12.0, st);
   hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, st, net->fold, net->layer_stage_first[stage],
                      a->params, a->bnstats, (const unsigned char*)bw, a->grads);
   VDQN_LAUNCH_CHECK();

@@ -211,7 +211,13 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
     attr_set = true;
   }
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+  const double esz = sizeof(T);
+  vdqn_prof_begin(sizeof(T) == 2 ? (BN == 128 ? "igemm<bf16,128>" : "igemm<bf16,64>") : (BN == 128 ? "igemm<f32,128>" : "igemm<f32,64>"),
+                  2.0 * p.M * p.co * p.ktot,
+                  esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
+                  stream);
   hipLaunchKernelGGL((igemm_kernel<T, BN>), dim3(grid), dim3(256), smem, stream, p);
+  vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void gt_loss_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float step_size, float beta1, float beta2,
-                                                   float inv_sqrt_bc2, float eps) {
+                                                   float omb1, float omb2, float inv_sqrt_bc2, float eps) {
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     float4 mm = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
 #define VDQN_ADAM1(c)                                              \
-  mm.c = beta1 * mm.c + (1.0f - beta1) * gg.c;                     \
-  vv.c = beta2 * vv.c + (1.0f - beta2) * gg.c * gg.c;              \
+  mm.c = beta1 * mm.c + omb1 * gg.c;                     \
+  vv.c = beta2 * vv.c + omb2 * gg.c * gg.c;              \
   pp.c = pp.c - step_size * (mm.c / (sqrtf(vv.c) * inv_sqrt_bc2 + eps));
     VDQN_ADAM1(x) VDQN_ADAM1(y) VDQN_ADAM1(z) VDQN_ADAM1(w)
 #undef VDQN_ADAM1
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float gg = g[i];
-    const float mm = beta1 * m[i] + (1.0f - beta1) * gg;
-    const float vv = beta2 * v[i] + (1.0f - beta2) * gg * gg;
+    const float mm = beta1 * m[i] + omb1 * gg;
+    const float vv = beta2 * v[i] + omb2 * gg * gg;
     m[i] = mm;
     v[i] = vv;
     p[i] = p[i] - step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
@@ -297,6 +297,7 @@ extern "C" int vdqn_pack_input(const void* src, int32_t src_kind, void* dst, int
   VDQN_CHECK(src_kind == 0 || src_kind == 1, "vdqn_pack_input: src_kind %d", src_kind);
   VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_pack_input: bad dtype");
   const int g = grid_for((long)n_img * 115 * 115);
+  ProfScope ps_("pack_input", 0.0, (double)n_img * (224.0 * 224 * 3 * (src_kind == 0 ? 1 : 4) + 115.0 * 115 * 16 * (dtype == VDQN_BF16 ? 2 : 4)), (hipStream_t)stream);
   if (dtype == VDQN_BF16) hipLaunchKernelGGL((pack_input_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, src, src_kind, (bf16raw*)dst, n_img);
   else hipLaunchKernelGGL((pack_input_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, src, src_kind, (float*)dst, n_img);
   VDQN_LAUNCH_CHECK();
@@ -311,6 +312,7 @@ extern "C" int vdqn_maxpool_fwd(const void* in, void* out, uint8_t* idx, int32_t
   const int ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
   const int e16 = dtype == VDQN_BF16 ? 8 : 4;
   const int g = grid_for((long)n_img * ho * wo * (c / e16), 65536);
+  ProfScope ps_("maxpool_fwd", 0.0, (double)n_img * c * ((double)hi * wi * (16 / e16) + (double)ho * wo * (16 / e16 + 1)), (hipStream_t)stream);
   if (dtype == VDQN_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)in, (bf16raw*)out, idx, n_img, hi, wi, c);
   else hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, idx, n_img, hi, wi, c);
   VDQN_LAUNCH_CHECK();
@@ -324,6 +326,7 @@ extern "C" int vdqn_maxpool_bwd(const void* gy, const uint8_t* idx, const void* 
   VDQN_CHECK(c % 8 == 0, "vdqn_maxpool_bwd: channels must be a multiple of 8");
   const int e16 = dtype == VDQN_BF16 ? 8 : 4;
   const int g = grid_for((long)n_img * hi * wi * (c / e16), 65536);
+  ProfScope ps_("maxpool_bwd", 0.0, (double)n_img * c * (2.0 * hi * wi * (16 / e16) + (double)(hi / 2) * (wi / 2) * (16 / e16 + 1)), (hipStream_t)stream);
   if (dtype == VDQN_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)gy, idx, (const bf16raw*)x, (bf16raw*)gx, n_img, hi, wi, c);
   else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)gy, idx, (const float*)x, (float*)gx, n_img, hi, wi, c);
   VDQN_LAUNCH_CHECK();
@@ -336,6 +339,7 @@ extern "C" int vdqn_td_loss(const vdqn_td_args* a, void* stream) {
   VDQN_CHECK(a->batch > 0 && a->n_cat > 0 && a->n_act > 0 && a->ldq >= a->n_cat * a->n_act, "vdqn_td_loss: bad dims");
   VDQN_CHECK(a->dtype == VDQN_F32 || a->dtype == VDQN_BF16, "vdqn_td_loss: bad dtype");
   const int g = (a->batch * a->ldq + 255) / 256;
+  ProfScope ps_("td_loss", 0.0, (double)a->batch * a->ldq * 16.0, (hipStream_t)stream);
   if (a->dtype == VDQN_BF16) hipLaunchKernelGGL((td_loss_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL((td_loss_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, *a);
   VDQN_LAUNCH_CHECK();
@@ -348,22 +352,25 @@ extern "C" int vdqn_gt_loss(const float* q_before, const int64_t* act, const flo
   VDQN_CHECK(batch > 0 && ldq >= n_cat * n_act, "vdqn_gt_loss: bad dims");
   VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_gt_loss: bad dtype");
   const int g = (batch * ldq + 255) / 256;
+  ProfScope ps_("gt_loss", 0.0, (double)batch * ldq * 8.0, (hipStream_t)stream);
   if (dtype == VDQN_BF16) hipLaunchKernelGGL((gt_loss_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, q_before, act, gt, loss, (bf16raw*)dq, dq_f32, batch, n_cat, n_act, ldq, inv_count, value_learning);
   else hipLaunchKernelGGL((gt_loss_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, q_before, act, gt, loss, (float*)dq, dq_f32, batch, n_cat, n_act, ldq, inv_count, value_learning);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }
 
-extern "C" int vdqn_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1, float beta2, float eps,
+extern "C" int vdqn_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1, double beta2, double eps,
                          void* stream) {
   VDQN_CHECK(p && g && m && v && n > 0 && step >= 1, "vdqn_adam: bad args");
   VDQN_CHECK((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "vdqn_adam: pointers must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const int grid = grid_for(n / 4 + 1, 4096);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, inv_sqrt_bc2, eps);
+  ProfScope ps_("adam", 0.0, (double)n * 28.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, (float)beta1, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), inv_sqrt_bc2, (float)eps);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }

@@ -226,7 +226,12 @@ int launch_wgrad(const WgradParams& p, int tiles, int splitk, hipStream_t stream
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
+  const double esz = sizeof(T);
+  vdqn_prof_begin(sizeof(T) == 2 ? (BT == 128 ? "wgrad<bf16,128>" : "wgrad<bf16,64>") : (BT == 128 ? "wgrad<f32,128>" : "wgrad<f32,64>"),
+                  2.0 * p.M * p.co * p.taps * p.ci,
+                  esz * ((double)p.M * p.ldg + (double)p.n_img * p.hi * p.wi * p.ci) + 4.0 * p.co * p.taps * p.ci, stream);
   hipLaunchKernelGGL((wgrad_kernel<T, BT>), dim3(tiles, splitk), dim3(256), smem, stream, p);
+  vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }
@@ -275,10 +280,12 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
     int blocks = (p.M + 511) / 512;
     if (blocks > 1024) blocks = 1024;
     const int rpb = (p.M + blocks - 1) / blocks;
+    vdqn_prof_begin("colsum", 0.0, (double)p.M * co_pad * (a->dtype == VDQN_BF16 ? 2 : 4), st);
     if (a->dtype == VDQN_BF16)
       hipLaunchKernelGGL((colsum_kernel<bf16raw>), dim3(blocks), dim3(256), 0, st, (const bf16raw*)a->gy, a->dbias, p.M, co_pad, a->ldg, rpb);
     else
       hipLaunchKernelGGL((colsum_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)a->gy, a->dbias, p.M, co_pad, a->ldg, rpb);
+    vdqn_prof_end(st);
     VDQN_LAUNCH_CHECK();
   }
   return VDQN_OK;

@@ -1,0 +1,43 @@
+"""Data-parallel gradient exchange: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm,
+"gloo" in the CPU tests).  The reference has no distributed code (single GPU, train_q_network.py:255-259,275);
+this is the one exchange step the path needs: a SUM all-reduce of the flat f32 gradient.  Because the fused
+TD kernel already divides by the *global* batch (inv_count = 1 / (5 * B * world)), the sum is the exact
+gradient of the global-batch mean loss (train_q_network.py:180) — no extra scaling pass.
+
+The flat gradient is laid out by backward stage (head+layer4 | layer3 | layer2+layer1+stem), so each bucket is
+one contiguous slice that is complete as soon as its stage's unfold kernel has run; ``launch`` is called right
+after each stage and issues an asynchronous all-reduce that overlaps the next stage's kernels, ``finish``
+makes the compute stream wait for all buckets before Adam.  xGMI is point-to-point, 49.7 MB total: three large
+buckets rather than per-layer messages.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class BucketAllReduce:
+    def __init__(self, world_size: int, group=None):
+        self.world_size = world_size
+        self.group = group
+        self._works: List = []
+
+    def launch(self, grad_slice: torch.Tensor, stage: int) -> None:
+        if self.world_size == 1:
+            return
+        self._works.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+
+
+def shard_indices(n_items: int, rank: int, world_size: int, batch_per_rank: int, epoch_perm) -> list:
+    """Rank-strided, drop_last sharding of one shuffled epoch (mirrors DataLoader(shuffle=True, drop_last=True),
+    train_q_network.py:98,114): rank r takes perm[r::world]; every rank gets the same number of full batches."""
+    mine = epoch_perm[rank::world_size]
+    per_rank = (n_items // world_size // batch_per_rank) * batch_per_rank
+    return list(mine[:per_rank])
