@@ -194,28 +194,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// dbias[c] += sum_m gy[m][c]
+// dbias[c] += sum_m gy[m][c]: 16-byte column groups x row stripes per block, stripes reduced through LDS,
+// one atomic per column per block (<= 256 blocks).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ gy, float* __restrict__ dbias, int M, int C, int ldg,
                                                      int rows_per_block) {
   constexpr int E16 = 16 / (int)sizeof(T);
-  const int cg_n = C / E16;            // 16-byte column groups
-  const int nstripe = 256 / cg_n;      // row stripes per block (cg_n <= 256 guaranteed by the launcher)
+  __shared__ float red[256 * E16];
+  const int cg_n = C / E16;            // 16-byte column groups (<= 256, power-of-two multiples of 8)
+  const int nstripe = 256 / cg_n;      // row stripes per block
   const int cg = threadIdx.x % cg_n, stripe = threadIdx.x / cg_n;
-  if (stripe >= nstripe) return;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   float s[E16];
 #pragma unroll
   for (int e = 0; e < E16; ++e) s[e] = 0.f;
-  for (int r = r0 + stripe; r < r1; r += nstripe) {
-    const uint4 v = *reinterpret_cast<const uint4*>(gy + (size_t)r * ldg + cg * E16);
-    const T* pv = reinterpret_cast<const T*>(&v);
+  if (stripe < nstripe) {
+    for (int r = r0 + stripe; r < r1; r += nstripe) {
+      const uint4 v = *reinterpret_cast<const uint4*>(gy + (size_t)r * ldg + cg * E16);
+      const T* pv = reinterpret_cast<const T*>(&v);
 #pragma unroll
-    for (int e = 0; e < E16; ++e) s[e] += to_f32<T>(pv[e]);
+      for (int e = 0; e < E16; ++e) s[e] += to_f32<T>(pv[e]);
+    }
   }
 #pragma unroll
-  for (int e = 0; e < E16; ++e) atomicAdd(dbias + cg * E16 + e, s[e]);
+  for (int e = 0; e < E16; ++e) red[threadIdx.x * E16 + e] = s[e];
+  __syncthreads();
+  // thread t < C sums column t over the stripes
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / E16, e = c % E16;
+    float t = 0.f;
+    for (int st = 0; st < nstripe; ++st) t += red[(st * cg_n + g) * E16 + e];
+    atomicAdd(dbias + c, t);
+  }
 }
 
 template <typename T, int BT>
@@ -278,7 +289,7 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
     const int e16 = a->dtype == VDQN_BF16 ? 8 : 4;
     VDQN_CHECK(co_pad / e16 <= 256, "vdqn_conv2d_wgrad: dbias path supports up to %d channels", 256 * e16);
     int blocks = (p.M + 511) / 512;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;
     const int rpb = (p.M + blocks - 1) / blocks;
     vdqn_prof_begin("colsum", 0.0, (double)p.M * co_pad * (a->dtype == VDQN_BF16 ? 2 : 4), st);
     if (a->dtype == VDQN_BF16)
