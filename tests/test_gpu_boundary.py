@@ -1,0 +1,79 @@
+"""GPU tests of the drop-in boundary: the product HabitatDQNMultiAction module, run_train with checkpoints,
+resume, load_model_number (what evaluation/runner.py:61 calls)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import relerr  # noqa: E402
+from video_dqn_amd import synth  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_module_forward_eval_and_b1_quirk():
+    from oracle import ref_cpu
+    from video_dqn_amd.model import HabitatDQNMultiAction
+    m = HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False, dtype="f32", device="cuda")
+    sd = synth.make_state_dict(11)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    ref = ref_cpu.HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False)
+    ref.load_state_dict(sd)
+    ref.eval()
+    (tup, raw) = synth.make_batch(24, 3, 1, structured=True)
+    with torch.no_grad():
+        q = m(tup[0].cuda())
+        r = ref(tup[0])
+    assert q.shape == (3, 5, 3) and q.dtype == torch.float32
+    assert relerr(q, r) < 1e-3
+    # CPU input tensors are moved like the reference's caller would have done; B = 1 keeps the (1, 5, A) shape
+    q1 = m(tup[0][:1])
+    assert q1.shape == (1, 5, 3) and relerr(q1, r[:1]) < 1e-3
+    # uint8 frames (util/torch.py:26-36 to_imgnet semantics fused on the GPU), as evaluate.py:110-114 scores views
+    qs = m(torch.from_numpy(raw[0][:, 0]).cuda())
+    assert relerr(qs, r) < 1e-3
+    assert float(qs[0, 2, :].max()) == pytest.approx(float(r[0, 2, :].max()), rel=1e-3)
+    # state_dict round trip returns what was loaded
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+    with pytest.raises(Exception, match="bad shape"):
+        m(torch.zeros(2, 4, 3, 224, 224))
+
+
+def test_run_train_checkpoint_resume_and_load_model_number(tmp_path):
+    from oracle import ref_cpu
+    from video_dqn_amd.config import ExperimentConfig
+    from video_dqn_amd.model import load_model_number
+    from video_dqn_amd.trainer import run_train
+    folder = tmp_path / "exp"
+    folder.mkdir()
+    (folder / "config.yml").write_text(
+        "DATASET: 'synthetic'\nPANORAMA: False\nLOSS_CLIP: 'rect'\nARCHITECTURE: 'extra_capacity'\nLEARNING_RATE: 0.0001\n"
+        "GAMMA: 0.99\nCHECKPOINT_INTERVAL: 3\nNUM_STEPS: 6\nTARGET_UPDATE_INTERVAL: 2\nSEED: 4\nBATCH_SIZE: 4\nNUM_WORKERS: 0\n"
+        "COMPUTE_DTYPE: 'f32'\n")
+    cfg = ExperimentConfig(str(folder), device="cuda")
+    model, stepper, running = run_train(cfg, max_steps=3)
+    assert os.path.exists(folder / "models" / "sample3.torch") and running is not None and np.isfinite(running)
+    snap = torch.load(folder / "models" / "sample3.torch", map_location="cpu")
+    assert snap["sample_number"] == 3 and len(snap["model_state_dict"]) == 250
+    assert sorted(snap["optimizer_state_dict"]["state"].keys()) == [i for i in range(70) if i not in (60, 61)]
+    assert snap["optimizer_state_dict"]["state"][0]["step"] == 3
+    # the checkpoint loads strictly into the (oracle restatement of the) reference class
+    ref = ref_cpu.HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False)
+    ref.load_state_dict(snap["model_state_dict"], strict=True)
+    # resume: -r picks sample3, restores model + Adam and continues to NUM_STEPS = 6
+    cfg2 = ExperimentConfig(str(folder), device="cuda", resume=True)
+    model2, stepper2, _ = run_train(cfg2, resume_from=3)
+    assert stepper2.adam_step == 6 and os.path.exists(folder / "models" / "sample6.torch")
+    # evaluation-side loader (train_q_network.load_model_number, evaluation/runner.py:61)
+    cfg3 = ExperimentConfig(str(folder), device="cuda", tensorboard=False)
+    m3 = load_model_number(cfg3, 6)
+    m3.eval()
+    (tup, _) = synth.make_batch(3, 2, 1, structured=True)
+    q3 = m3(tup[0].cuda())
+    q2 = model2(tup[0].cuda())
+    assert torch.equal(q3, q2)

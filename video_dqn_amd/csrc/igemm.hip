@@ -3,14 +3,18 @@
 //   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ),   m = (img, ho, wo),  k = (r, s, c)
 //
 // * A is gathered on the fly from the NHWC activation tensor: one K-step is 128 contiguous bytes of one
-//   (r, s) tap of one input pixel (64 bf16 / 32 f32 channels), fetched as eight 16-byte lanes per row so
-//   every global request is a full 128-byte line.  Padding taps are zero-filled in registers.
+//   (r, s) tap of one input pixel (64 bf16 / 32 f32 channels).  Both operands go HBM -> LDS directly with
+//   `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB = 8 tile rows per wave-instruction): no staging VGPRs, no
+//   ds_write.  Padding taps and rows past M need no branch: their lane offset is set out of the buffer
+//   descriptor's range and the hardware writes zeros into LDS (probed: tools/probes/lds_dma_oob.hip).
 // * Tiles: 128 (M) x BN (N, 64 or 128) x 128 bytes (K); 256 threads = 4 waves in a 2x2 grid, each wave owns
 //   64 x BN/2 as 16x16 MFMA fragments (v_mfma_f32_16x16x32_bf16, or v_mfma_f32_16x16x4_f32 in the exact
 //   f32 parity mode — same staging code, only the MFMA differs).
-// * LDS: rows of 128 B, the 16-byte chunk index XOR-swizzled with (row & 7) so the ds_read_b128 fragment
-//   reads are bank-conflict free; two buffers, register-staged prefetch (global loads of step k+1 are in
-//   flight while step k's MFMAs run), one barrier per K-step.
+// * LDS: rows of 128 B; the DMA image is lane-linear, so the bank-conflict swizzle is applied on the SOURCE:
+//   lane (row, p) fetches logical chunk p ^ (row & 7) and fragment reads XOR the same term.  Two buffers;
+//   the DMA of step k+1 is in flight while step k's MFMAs run; one barrier per K-step.
+// * Epilogue: accumulators -> LDS (f32) -> 16-byte vector loads of bias/residual/mask and 16-byte stores
+//   (whole 128/256-byte output rows per 8/16 lanes).
 // * blockIdx is remapped so the N-tiles of one M-tile run on the same XCD (A rows stay in that XCD's L2).
 //
 // Reference call sites this serves: the torch conv2d/linear (+BatchNorm eval, ReLU, residual) launched
@@ -27,17 +31,25 @@ struct IgemmParams {
   const void* mask;
   void* out;
   float* out_f32;
-  int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldo, r, s, stride, pad, mode, relu;
+  int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldo, r, s, stride, pad, relu;
   int M, howo, ktot, nk, tiles_m, tiles_n;
+  long long in_bytes;
+  int wt_bytes;
+  int vec_ok;
 };
 
-template <typename T, int BN>
+constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (num_records <= 0x7fffffff)
+
+// MODE 0: forward gather (h = oh*stride - pad + kr); 1: dgrad, stride 1 (h = oh + pad - kr);
+//      2: dgrad, stride 2 (h = (oh + pad - kr) / 2 when even)
+template <typename T, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   constexpr int BM = 128;
-  constexpr int E16 = 16 / (int)sizeof(T);
-  constexpr int KC = 128 / (int)sizeof(T);
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int KC = 128 / ESZ;
   constexpr int NF = BN / 32;
   constexpr int BROWS = BN / 32;
+  constexpr int LDC = BN + 4;  // f32 row stride of the epilogue tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
   unsigned char* sB = smem + 2 * BM * 128;
@@ -47,75 +59,81 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = (int)(lb % (uint32_t)p.tiles_n), tile_m = (int)(lb / (uint32_t)p.tiles_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int lchunk = tid & 7, lrow = tid >> 3;
+  const int lrow = tid >> 3;                        // tile row this thread stages (+32 i)
+  const int lchunk = (tid & 7) ^ (lrow & 7);        // logical 16-byte chunk it fetches (source-side swizzle)
 
-  const T* __restrict__ in = (const T*)p.in;
-  const T* __restrict__ wt = (const T*)p.wt;
+  // ---- buffer descriptors: A relative to the first image of this tile, B = whole weight tensor ----
+  const int img0 = m0 / p.howo;
+  const long long img_bytes = (long long)p.hi * p.wi * p.pix_stride * ESZ;
+  const long long a_base_off = (long long)img0 * img_bytes;
+  long long a_rem = p.in_bytes - a_base_off;
+  if (a_rem > 0x7fffffffLL) a_rem = 0x7fffffffLL;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)p.in + a_base_off), (short)0, (int)a_rem, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, (short)0, p.wt_bytes, 0x00020000);
 
-  // ---- per-row gather bases (4 A rows per thread) ----
-  const T* a_ptr[4];
-  int a_h0[4], a_w0[4];
-  bool a_ok[4];
+  // ---- per-row gather state (4 A rows per thread) ----
+  uint32_t a_off[4];
+  int a_hb[4], a_wb[4];
+  const int pixB = p.pix_stride * ESZ;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + lrow + 32 * i;
     const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
+    const int mm = ok ? m : m0;
     const int img = mm / p.howo;
     const int rem = mm - img * p.howo;
     const int oh = rem / p.wo;
     const int ow = rem - oh * p.wo;
-    a_ok[i] = ok;
-    a_ptr[i] = in + (size_t)img * p.hi * p.wi * p.pix_stride + lchunk * E16;
-    if (p.mode == 0) {
-      a_h0[i] = oh * p.stride - p.pad;
-      a_w0[i] = ow * p.stride - p.pad;
+    int hb, wb, hq, wq;
+    if (MODE == 0) {
+      hb = oh * p.stride - p.pad;
+      wb = ow * p.stride - p.pad;
+      hq = hb;
+      wq = wb;
     } else {
-      a_h0[i] = oh + p.pad;
-      a_w0[i] = ow + p.pad;
+      hb = oh + p.pad;
+      wb = ow + p.pad;
+      hq = MODE == 2 ? (hb >> 1) : hb;
+      wq = MODE == 2 ? (wb >> 1) : wb;
     }
+    a_off[i] = (uint32_t)(((img - img0) * p.hi + hq) * p.wi + wq) * (uint32_t)pixB + (uint32_t)(lchunk * 16);
+    a_hb[i] = ok ? hb : -(1 << 20);
+    a_wb[i] = wb;
   }
-  const T* b_ptr[BROWS];
+  uint32_t b_off[BROWS];
 #pragma unroll
-  for (int i = 0; i < BROWS; ++i) b_ptr[i] = wt + (size_t)(n0 + lrow + 32 * i) * p.ktot + lchunk * E16;
+  for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + 32 * i) * (uint32_t)(p.ktot * ESZ) + (uint32_t)(lchunk * 16);
 
-  uint4 ra[4], rb[BROWS];
-  auto load_tile = [&](int kr, int ks, int c0, int kstep) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int h, w;
-      bool ok = a_ok[i];
-      if (p.mode == 0) {
-        h = a_h0[i] + kr;
-        w = a_w0[i] + ks;
-      } else {
-        const int th = a_h0[i] - kr, tw = a_w0[i] - ks;
-        if (p.stride == 2) {
-          ok = ok && (((th | tw) & 1) == 0);
-          h = th >> 1;
-          w = tw >> 1;
-        } else {
-          h = th;
-          w = tw;
-        }
-      }
-      ok = ok && ((unsigned)h < (unsigned)p.hi) && ((unsigned)w < (unsigned)p.wi);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *reinterpret_cast<const uint4*>(a_ptr[i] + ((h * p.wi + w) * p.pix_stride + c0));
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + kstep * KC);
-  };
-  const int swz_w = ((lchunk ^ (lrow & 7)) << 4);
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(sA + buf * (BM * 128) + (lrow + 32 * i) * 128 + swz_w) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BROWS; ++i)
-      *reinterpret_cast<uint4*>(sB + buf * (BN * 128) + (lrow + 32 * i) * 128 + swz_w) = rb[i];
-  };
+  // LDS destinations of this wave's DMA pieces: piece i of operand X covers tile rows 32 i + 8 wave .. +7
+  const int lds_piece = wave * 8 * 128;
+
+#define VDQN_ISSUE(BUF, KR, KS, C0, KSTEP)                                                                          \
+  {                                                                                                                 \
+    const int delta_ = (MODE == 0   ? (((KR)*p.wi + (KS)) * p.pix_stride + (C0))                                    \
+                        : MODE == 1 ? ((C0) - ((KR)*p.wi + (KS)) * p.pix_stride)                                    \
+                                    : ((C0) - (((KR) >> 1) * p.wi + ((KS) >> 1)) * p.pix_stride)) *                 \
+                       ESZ;                                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
+      bool ok_;                                                                                                     \
+      if (MODE == 0) {                                                                                              \
+        ok_ = ((unsigned)(a_hb[i_] + (KR)) < (unsigned)p.hi) && ((unsigned)(a_wb[i_] + (KS)) < (unsigned)p.wi);     \
+      } else if (MODE == 1) {                                                                                       \
+        ok_ = ((unsigned)(a_hb[i_] - (KR)) < (unsigned)p.hi) && ((unsigned)(a_wb[i_] - (KS)) < (unsigned)p.wi);     \
+      } else {                                                                                                      \
+        const int th_ = a_hb[i_] - (KR), tw_ = a_wb[i_] - (KS);                                                     \
+        ok_ = (((th_ | tw_) & 1) == 0) && ((unsigned)(th_ >> 1) < (unsigned)p.hi) && ((unsigned)(tw_ >> 1) < (unsigned)p.wi); \
+      }                                                                                                             \
+      const uint32_t vo_ = ok_ ? a_off[i_] + (uint32_t)delta_ : kOob;                                               \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
+          rs_a, (__attribute__((address_space(3))) void*)(sA + (BUF) * (BM * 128) + i_ * (32 * 128) + lds_piece), 16, (int)vo_, 0, 0, 0); \
+    }                                                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < BROWS; ++i_) {                                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
+          rs_b, (__attribute__((address_space(3))) void*)(sB + (BUF) * (BN * 128) + i_ * (32 * 128) + lds_piece), 16, (int)b_off[i_], \
+          (KSTEP)*128, 0, 0);                                                                                       \
+    }                                                                                                               \
+  }
 
   f32x4 acc[4][NF];
 #pragma unroll
@@ -126,7 +144,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
   const int sw = i16 & 7;
-  auto compute = [&](int buf) {
+
+  // ---- main loop: K-steps enumerate (r, s, c0) with c0 fastest ----
+  int kr = 0, ks = 0, c0 = 0;
+  VDQN_ISSUE(0, kr, ks, c0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // the first tile has landed
+  for (int k = 0; k < p.nk; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < p.nk) {
+      c0 += KC;
+      if (c0 >= p.ci) {
+        c0 = 0;
+        if (++ks == p.s) {
+          ks = 0;
+          ++kr;
+        }
+      }
+      VDQN_ISSUE(buf ^ 1, kr, ks, c0, k + 1)
+    }
     const unsigned char* a = sA + buf * (BM * 128) + (wr * 64 + i16) * 128;
     const unsigned char* b = sB + buf * (BN * 128) + (wc * (BN / 2) + i16) * 128;
 #pragma unroll
@@ -142,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
           if constexpr (sizeof(T) == 2) {
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]),
-                                                                __builtin_bit_cast(bf16x8, bfr[j]), acc[f][j], 0, 0, 0);
+            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bfr[j]),
+                                                                acc[f][j], 0, 0, 0);
           } else {
             acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].x), __uint_as_float(bfr[j].x), acc[f][j], 0, 0, 0);
             acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].y), __uint_as_float(bfr[j].y), acc[f][j], 0, 0, 0);
@@ -152,62 +188,93 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           }
         }
     }
-  };
-
-  // ---- main loop: K-steps enumerate (r, s, c0) with c0 fastest ----
-  int kr = 0, ks = 0, c0 = 0;
-  load_tile(kr, ks, c0, 0);
-  for (int k = 0; k < p.nk; ++k) {
-    const int buf = k & 1;
-    store_tile(buf);
-    __syncthreads();
-    if (k + 1 < p.nk) {
-      c0 += KC;
-      if (c0 >= p.ci) {
-        c0 = 0;
-        if (++ks == p.s) {
-          ks = 0;
-          ++kr;
-        }
-      }
-      load_tile(kr, ks, c0, k + 1);
-    }
-    compute(buf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // next tile landed and every wave is done reading this one
   }
+#undef VDQN_ISSUE
 
-  // ---- epilogue: C layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
+  // ---- epilogue: accumulators -> LDS f32 tile (C layout: col = lane & 15, row = (lane >> 4) * 4 + reg) ----
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        sC[(wr * 64 + f * 16 + g * 4 + reg) * LDC + wc * (BN / 2) + j * 16 + i16] = acc[f][j][reg];
+  __syncthreads();
+
   T* __restrict__ out = (T*)p.out;
   const T* __restrict__ resid = (const T*)p.resid;
   const T* __restrict__ mask = (const T*)p.mask;
+  constexpr int TPR = BN / 8;         // threads per tile row (8 columns each)
+  constexpr int RPP = 256 / TPR;      // rows per pass
+  const int col8 = (tid % TPR) * 8;
+  const int n = n0 + col8;
+  if (n < p.co) {
+    const bool vec = p.vec_ok && (n + 8 <= p.co);
+    float bv[8];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.co) ? p.bias[n + e] : 0.f;
+#pragma unroll 2
+    for (int r0 = tid / TPR; r0 < BM; r0 += RPP) {
+      const int m = m0 + r0;
+      if (m >= p.M) break;
+      const size_t o = (size_t)m * p.ldo + n;
+      float v[8];
+      const float4 c0v = *reinterpret_cast<const float4*>(sC + r0 * LDC + col8);
+      const float4 c1v = *reinterpret_cast<const float4*>(sC + r0 * LDC + col8 + 4);
+      v[0] = c0v.x + bv[0]; v[1] = c0v.y + bv[1]; v[2] = c0v.z + bv[2]; v[3] = c0v.w + bv[3];
+      v[4] = c1v.x + bv[4]; v[5] = c1v.y + bv[5]; v[6] = c1v.z + bv[6]; v[7] = c1v.w + bv[7];
+      if (vec) {
+        T rv[8], mv[8], ov[8];
+        if (resid) {
+          if constexpr (ESZ == 2) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(resid + o);
+          else { reinterpret_cast<uint4*>(rv)[0] = reinterpret_cast<const uint4*>(resid + o)[0]; reinterpret_cast<uint4*>(rv)[1] = reinterpret_cast<const uint4*>(resid + o)[1]; }
 #pragma unroll
-    for (int j = 0; j < NF; ++j) {
-      const int n = n0 + wc * (BN / 2) + j * 16 + i16;
-      if (n >= p.co) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+          for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(rv[e]);
+        }
+        if (p.relu) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int m = m0 + wr * 64 + f * 16 + g * 4 + reg;
-        if (m >= p.M) continue;
-        const size_t o = (size_t)m * p.ldo + n;
-        float v = acc[f][j][reg] + bv;
-        if (resid) v += to_f32<T>(resid[o]);
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (mask) v = (to_f32<T>(mask[o]) > 0.f) ? v : 0.f;
-        if (out) out[o] = from_f32<T>(v);
-        if (p.out_f32) p.out_f32[o] = v;
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (mask) {
+          if constexpr (ESZ == 2) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + o);
+          else { reinterpret_cast<uint4*>(mv)[0] = reinterpret_cast<const uint4*>(mask + o)[0]; reinterpret_cast<uint4*>(mv)[1] = reinterpret_cast<const uint4*>(mask + o)[1]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (to_f32<T>(mv[e]) > 0.f) ? v[e] : 0.f;
+        }
+        if (out) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(v[e]);
+          if constexpr (ESZ == 2) *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ov);
+          else { reinterpret_cast<uint4*>(out + o)[0] = reinterpret_cast<const uint4*>(ov)[0]; reinterpret_cast<uint4*>(out + o)[1] = reinterpret_cast<const uint4*>(ov)[1]; }
+        }
+        if (p.out_f32) {
+          *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(p.out_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      } else {
+        for (int e = 0; e < 8 && n + e < p.co; ++e) {
+          float x = v[e];
+          if (resid) x += to_f32<T>(resid[o + e]);
+          if (p.relu) x = fmaxf(x, 0.f);
+          if (mask) x = (to_f32<T>(mask[o + e]) > 0.f) ? x : 0.f;
+          if (out) out[o + e] = from_f32<T>(x);
+          if (p.out_f32) p.out_f32[o + e] = x;
+        }
       }
     }
   }
 }
 
-template <typename T, int BN>
+template <typename T, int BN, int MODE>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
-  const size_t smem = 2 * (128 + BN) * 128;
+  const size_t main_bytes = 2 * (128 + BN) * 128, epi_bytes = 128 * (BN + 4) * 4;
+  const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
@@ -216,10 +283,17 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
                   2.0 * p.M * p.co * p.ktot,
                   esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
                   stream);
-  hipLaunchKernelGGL((igemm_kernel<T, BN>), dim3(grid), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BN, MODE>), dim3(grid), dim3(256), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
+}
+
+template <typename T, int BN>
+int launch_mode(const IgemmParams& p, int mode, hipStream_t st) {
+  if (mode == 0) return launch_igemm<T, BN, 0>(p, st);
+  if (mode == 1) return launch_igemm<T, BN, 1>(p, st);
+  return launch_igemm<T, BN, 2>(p, st);
 }
 
 }  // namespace
@@ -227,19 +301,20 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
 extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   VDQN_CHECK(a != nullptr, "vdqn_conv2d: null args");
   VDQN_CHECK(a->dtype == VDQN_F32 || a->dtype == VDQN_BF16, "vdqn_conv2d: bad dtype %d", a->dtype);
-  const int kc = a->dtype == VDQN_BF16 ? 64 : 32;
+  const int esz = a->dtype == VDQN_BF16 ? 2 : 4;
+  const int kc = 128 / esz;
   VDQN_CHECK(a->in && a->wt && (a->out || a->out_f32), "vdqn_conv2d: null tensor");
   VDQN_CHECK(a->ci > 0 && a->ci % kc == 0, "vdqn_conv2d: ci=%d must be a multiple of %d", a->ci, kc);
   VDQN_CHECK(a->stride == 1 || a->stride == 2, "vdqn_conv2d: stride %d unsupported", a->stride);
   VDQN_CHECK(a->mode == 0 || a->mode == 1, "vdqn_conv2d: bad mode %d", a->mode);
   VDQN_CHECK(a->n_img > 0 && a->ho > 0 && a->wo > 0 && a->co > 0 && a->ldo >= a->co, "vdqn_conv2d: bad dims");
-  VDQN_CHECK((int64_t)a->n_img * a->ho * a->wo < (1ll << 31) && (int64_t)a->hi * a->wi * a->pix_stride < (1ll << 31),
-             "vdqn_conv2d: tensor too large");
+  VDQN_CHECK((int64_t)a->n_img * a->ho * a->wo < (1ll << 31), "vdqn_conv2d: too many output pixels");
+  VDQN_CHECK((a->pix_stride * esz) % 16 == 0 && (((uintptr_t)a->in | (uintptr_t)a->wt) & 15) == 0, "vdqn_conv2d: in/wt must be 16-byte aligned");
   IgemmParams p;
   p.in = a->in; p.wt = a->wt; p.bias = a->bias; p.resid = a->resid; p.mask = a->mask; p.out = a->out; p.out_f32 = a->out_f32;
   p.n_img = a->n_img; p.hi = a->hi; p.wi = a->wi; p.ci = a->ci; p.pix_stride = a->pix_stride;
   p.ho = a->ho; p.wo = a->wo; p.co = a->co; p.ldo = a->ldo; p.r = a->r; p.s = a->s; p.stride = a->stride; p.pad = a->pad;
-  p.mode = a->mode; p.relu = a->relu;
+  p.relu = a->relu;
   p.M = a->n_img * a->ho * a->wo;
   p.howo = a->ho * a->wo;
   p.ktot = a->r * a->s * a->ci;
@@ -247,7 +322,18 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   const int bn = (a->co % 128 == 0) ? 128 : 64;
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (a->co + bn - 1) / bn;
+  p.in_bytes = (long long)a->n_img * a->hi * a->wi * a->pix_stride * esz;
+  const long long wtb = (long long)p.tiles_n * bn * p.ktot * esz;
+  VDQN_CHECK(wtb < 0x7fffffffLL, "vdqn_conv2d: weight tensor too large");
+  p.wt_bytes = (int)wtb;
+  // a 128-row tile spans at most 128 images; its gather window must stay below 2 GiB
+  const long long img_bytes = (long long)a->hi * a->wi * a->pix_stride * esz;
+  const long long span_imgs = 128 / (p.howo > 0 ? p.howo : 1) + 2;
+  VDQN_CHECK(span_imgs * img_bytes < 0x7fffffffLL, "vdqn_conv2d: image too large for one tile's gather window");
+  const uintptr_t al = (uintptr_t)a->out | (uintptr_t)a->out_f32 | (uintptr_t)a->resid | (uintptr_t)a->mask;
+  p.vec_ok = ((a->ldo * esz) % 16 == 0) && ((al & 15) == 0) && (a->ldo % 8 == 0);
+  const int mode = a->mode == 0 ? 0 : (a->stride == 2 ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == VDQN_BF16) return bn == 128 ? launch_igemm<bf16raw, 128>(p, st) : launch_igemm<bf16raw, 64>(p, st);
-  return bn == 128 ? launch_igemm<float, 128>(p, st) : launch_igemm<float, 64>(p, st);
+  if (a->dtype == VDQN_BF16) return bn == 128 ? launch_mode<bf16raw, 128>(p, mode, st) : launch_mode<bf16raw, 64>(p, mode, st);
+  return bn == 128 ? launch_mode<float, 128>(p, mode, st) : launch_mode<float, 64>(p, mode, st);
 }

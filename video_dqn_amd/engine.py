@@ -52,7 +52,10 @@ class NetEngine:
     def __init__(self, action_dim=3, num_classes=5, num_frames=1, extra_capacity=True, dtype="bf16",
                  max_batch=512, device=None):
         self.lib = _lib.load()
-        self.device = require_gpu(device)
+        # device="cpu" gives a storage-only instance (state_dict / checkpoint plumbing); every compute entry
+        # point still requires the GPU and raises otherwise — there is no CPU arithmetic in this package.
+        self.storage_only = device is not None and torch.device(device).type == "cpu"
+        self.device = torch.device("cpu") if self.storage_only else require_gpu(device)
         if not extra_capacity:
             raise NotImplementedError("ARCHITECTURE='basic' (BatchNorm in train mode) is not implemented yet; "
                                       "use ARCHITECTURE: 'extra_capacity' (configs/experiments/real_data)")
@@ -74,10 +77,9 @@ class NetEngine:
         self.trainable_numel = self.lib.vdqn_net_trainable_numel(h)
         self.bnstats_numel = self.lib.vdqn_net_bnstats_numel(h)
         self.packed_bytes = self.lib.vdqn_net_packed_bytes(h)
-        with torch.cuda.device(self.device):
-            self.params = torch.zeros(self.params_numel, dtype=torch.float32, device=self.device)
-            self.bnstats = torch.zeros(self.bnstats_numel, dtype=torch.float32, device=self.device)
-            self.packed = torch.zeros(self.packed_bytes, dtype=torch.uint8, device=self.device)
+        self.params = torch.zeros(self.params_numel, dtype=torch.float32, device=self.device)
+        self.bnstats = torch.zeros(self.bnstats_numel, dtype=torch.float32, device=self.device)
+        self.packed = None if self.storage_only else torch.zeros(self.packed_bytes, dtype=torch.uint8, device=self.device)
         self._packed_version = -1
         self._version = 0
         self._acts: Dict[int, torch.Tensor] = {}
@@ -113,7 +115,12 @@ class NetEngine:
         self._version += 1
 
     # ---- packing + forward -----------------------------------------------------------------------
+    def _need_gpu(self):
+        if self.storage_only:
+            raise _lib.VdqnError("this NetEngine is storage-only (device='cpu'); compute needs the GPU — no CPU fallback")
+
     def pack_weights(self, packed: Optional[torch.Tensor] = None, with_dgrad: bool = False, params=None, bnstats=None):
+        self._need_gpu()
         packed = self.packed if packed is None else packed
         _lib.check(self.lib.vdqn_net_pack_weights(self.handle, _ptr(self.params if params is None else params),
                                                   _ptr(self.bnstats if bnstats is None else bnstats),
@@ -135,6 +142,7 @@ class NetEngine:
 
     def forward(self, frames: torch.Tensor, src_kind: int, n_samples: int) -> torch.Tensor:
         """frames: contiguous device tensor (uint8 NHWC frames if src_kind == 0, f32 NCHW if 1)."""
+        self._need_gpu()
         if n_samples > self.max_batch:
             raise _lib.VdqnError(f"batch {n_samples} exceeds max_batch {self.max_batch}")
         with torch.cuda.device(self.device):
@@ -158,6 +166,7 @@ class TDStepper:
                  remove_before_reward: bool = False, train_on_ground_truth: bool = False, value_learning: bool = False,
                  target_update_interval: int = 8000, betas=(0.9, 0.999), eps: float = 1e-8, world_size: int = 1,
                  allreduce=None):
+        net._need_gpu()
         self.net, self.B = net, batch
         self.lib = net.lib
         if 2 * batch > net.max_batch:

@@ -1,0 +1,216 @@
+"""``HabitatDQNMultiAction`` with the reference's Python surface, computing on the HIP engine.
+
+Mirrors ``archs/HabitatDQNMultiAction.py:8-54`` and the factory/loader of ``train_q_network.py:36-57``:
+
+  * same constructor arguments, same module tree (``resnet``, ``features``, ``top``) so ``state_dict()`` has
+    the reference's 250 keys in the reference's order (``features.N.*`` alias ``resnet.*``), and
+    ``load_state_dict(strict=True)`` accepts reference checkpoints unchanged;
+  * ``forward(inp)`` takes ``float[B,3,224,224]`` / ``float[B,F,3,224,224]`` (normalised, as the reference's
+    loader produces) and returns ``float32[B,5,A]``; raises ``Exception("bad shape")`` on a frame-count
+    mismatch (:47-48).  Extension: a uint8 ``[B,(F,)224,224,3]`` tensor is normalised on the GPU inside the
+    input-packing kernel (``util/torch.py:26-36`` semantics);
+  * ``set_train()`` / ``eval()`` / ``train()`` only set flags: in ``extra_capacity`` every BatchNorm layer runs on
+    its running statistics in both modes (:37-40), which is what the engine implements.
+
+The module's parameters and BatchNorm buffers are *views* into the engine's flat device arrays, so
+``load_state_dict`` writes straight into what the kernels read; there is no autograd graph — gradients come
+from the engine's explicit backward (``video_dqn_amd.engine.TDStepper``).  No arithmetic happens on the CPU.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .engine import NetEngine
+
+
+class _Holder(nn.Module):
+    """Parameter/buffer container that only contributes names to the state_dict (no forward)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("structure-only module: HabitatDQNMultiAction.forward runs on the HIP engine")
+
+
+def _conv(holder_params, name, has_bias=False):
+    m = _Holder()
+    m.weight = holder_params(name + ".weight")
+    m.bias = holder_params(name + ".bias") if has_bias else None
+    return m
+
+
+class _Stateless(_Holder):
+    pass
+
+
+def _init_like_reference(engine: NetEngine, seed=None):
+    """Default initialisation when no pretrained file is given: torchvision's resnet init (kaiming_normal
+    fan_out for convs, BatchNorm weight 1 / bias 0, running stats 0 / 1) and PyTorch's default Conv2d/Linear
+    init for the head, drawn from the torch CPU generator (seeded by the trainer like train_q_network.py:86)."""
+    g = None
+    if seed is not None:
+        g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, s in engine.slots.items():
+            v = engine.view(name)
+            if s.kind == 2:
+                v.zero_()
+            elif s.kind == 3:
+                v.fill_(1.0)
+            elif name.startswith("resnet.") and len(s.shape) == 4:
+                fan_out = s.shape[0] * s.shape[2] * s.shape[3]
+                v.copy_(torch.randn(s.shape, generator=g) * (2.0 / fan_out) ** 0.5)
+            elif name.startswith("resnet.") and (".bn" in name or ".downsample.1." in name):
+                v.fill_(1.0 if name.endswith("weight") else 0.0)
+            else:  # resnet.fc, features.8, top.*: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                wname = name.rsplit(".", 1)[0] + ".weight"
+                ws = engine.slots[wname].shape
+                fan_in = ws[1] * (ws[2] * ws[3] if len(ws) == 4 else 1)
+                bound = 1.0 / fan_in ** 0.5
+                v.copy_((torch.rand(s.shape, generator=g) * 2 - 1) * bound)
+    engine.mark_dirty()
+
+
+class HabitatDQNMultiAction(nn.Module):
+    def __init__(self, action_dim, num_classes=5, extra_capacity=False, panorama=True, num_frames=None,
+                 dtype=None, device=None, max_batch=64):
+        super().__init__()
+        self.extra_capacity = extra_capacity
+        self.num_classes = num_classes
+        self.action_dim = action_dim
+        self.panorama = panorama
+        if num_frames is None:  # archs/HabitatDQNMultiAction.py:16-19
+            num_frames = 4 if panorama else 1
+        self.num_frames = num_frames
+        dtype = dtype or os.environ.get("VDQN_DTYPE", "bf16")
+        if extra_capacity:
+            print("Model loading with extra_capacity")  # :28
+        self.engine = NetEngine(action_dim, num_classes, num_frames, extra_capacity, dtype, max_batch, device)
+        self._build_tree()
+        _init_like_reference(self.engine)
+        pre = os.environ.get("VDQN_RESNET18_WEIGHTS")  # torchvision resnet18 state_dict (pretrained=True analogue, :11)
+        if pre:
+            sd = torch.load(pre, map_location="cpu")
+            with torch.no_grad():
+                for k, v in sd.items():
+                    if "resnet." + k in self.engine.slots:
+                        self.engine.view("resnet." + k).copy_(v)
+            self.engine.mark_dirty()
+
+    # ---- structure ----------------------------------------------------------------------------------
+    def _build_tree(self):
+        eng = self.engine
+        cache = {}
+
+        def P(name):
+            if name not in cache:
+                cache[name] = nn.Parameter(eng.view(name), requires_grad=False)
+            return cache[name]
+
+        def bn(name):
+            m = _Holder()
+            m.weight, m.bias = P(name + ".weight"), P(name + ".bias")
+            m.register_buffer("running_mean", eng.view(name + ".running_mean"))
+            m.register_buffer("running_var", eng.view(name + ".running_var"))
+            m.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long, device=eng.device))
+            return m
+
+        resnet = _Holder()
+        resnet.conv1 = _conv(P, "resnet.conv1")
+        resnet.bn1 = bn("resnet.bn1")
+        resnet.relu = _Stateless()
+        resnet.maxpool = _Stateless()
+        inpl = 64
+        for li, planes in enumerate((64, 128, 256, 512), start=1):
+            blocks = []
+            for bi in range(2):
+                p = f"resnet.layer{li}.{bi}"
+                b = _Holder()
+                b.conv1 = _conv(P, p + ".conv1")
+                b.bn1 = bn(p + ".bn1")
+                b.relu = _Stateless()
+                b.conv2 = _conv(P, p + ".conv2")
+                b.bn2 = bn(p + ".bn2")
+                if (li > 1 and bi == 0) or inpl != planes:
+                    b.downsample = nn.Sequential(_conv(P, p + ".downsample.0"), bn(p + ".downsample.1"))
+                else:
+                    b.downsample = None
+                inpl = planes
+                blocks.append(b)
+            setattr(resnet, f"layer{li}", nn.Sequential(*blocks))
+        resnet.avgpool = _Stateless()
+        resnet.fc = _conv(P, "resnet.fc", has_bias=True)
+        self.resnet = resnet
+        # archs/HabitatDQNMultiAction.py:30-31
+        self.features = nn.Sequential(*list(self.resnet.children())[:-2], _conv(P, "features.8", has_bias=True),
+                                      _Stateless(), _Stateless())
+        self.top = nn.Sequential(_conv(P, "top.0", True), _Stateless(), _conv(P, "top.2", True), _Stateless(),
+                                 _conv(P, "top.4", True))
+
+    # ---- reference surface ----------------------------------------------------------------------------
+    def set_train(self):  # :37-40
+        self.train()
+        if self.extra_capacity:
+            self.resnet.eval()
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.engine.mark_dirty()
+        return r
+
+    def _apply(self, fn, recurse=True):
+        # parameters are views into the engine's flat arrays; moving them would break the aliasing
+        probe = fn(torch.empty(0, device=self.engine.device))
+        if probe.device != self.engine.device or probe.dtype != torch.float32:
+            raise RuntimeError("HabitatDQNMultiAction lives on its engine's device in f32 master precision; "
+                               "construct it with device=... instead of calling .to()/.half()")
+        return self
+
+    def forward(self, inp):  # :44-54
+        eng = self.engine
+        if inp.dtype == torch.uint8:  # raw frames [B,(F,)224,224,3]
+            if self.num_frames == 1 and inp.dim() == 4:
+                inp = inp.unsqueeze(1)
+            if inp.shape[1] != self.num_frames:
+                raise Exception("bad shape")
+            src_kind = 0
+        else:
+            if self.num_frames == 1 and len(inp.shape) == 4:
+                inp = inp.unsqueeze(1)
+            if inp.shape[1] != self.num_frames:
+                raise Exception("bad shape")
+            inp = inp.float()
+            src_kind = 1
+        b = inp.shape[0]
+        inp = inp.to(eng.device).contiguous()
+        if b > eng.max_batch:
+            outs = [self.forward(inp[i:i + eng.max_batch]) for i in range(0, b, eng.max_batch)]
+            return torch.cat(outs, 0)
+        q = eng.forward(inp, src_kind, b)
+        return q.view((-1, self.num_classes, self.action_dim))
+
+
+def build_model(config, max_batch=None):
+    """train_q_network.py:36-47 (config.device selects the GPU; dtype from config.COMPUTE_DTYPE)."""
+    actions = 1 if (config.VALUE_LEARNING or config.ONE_ACTION) else 3
+    nf = getattr(config, "NUM_FRAMES", 0) or None
+    return HabitatDQNMultiAction(actions, 5, extra_capacity=(config.ARCHITECTURE == "extra_capacity"),
+                                 panorama=(config.PANORAMA or config.PREVIOUS_IMAGES), num_frames=nf,
+                                 dtype=getattr(config, "COMPUTE_DTYPE", None), device=config.device,
+                                 max_batch=max_batch or max(64, 2 * getattr(config, "BATCH_SIZE", 16)))
+
+
+def load_model_number(config, number, model_loc=None):
+    """train_q_network.py:50-57."""
+    model = build_model(config)
+    if model_loc is None:
+        model_loc = f"{config.folder}/models/sample{number}.torch"
+    snapshot = torch.load(model_loc, map_location=config.device)
+    print(f"Loading model from: {model_loc}")
+    model.load_state_dict(snapshot["model_state_dict"])
+    return model

@@ -1,0 +1,186 @@
+"""The Q-learning training loop with the reference's control flow and on-disk artefacts
+(``train_q_network.py:84-250``), running every device-side step on the HIP engine.
+
+Kept from the reference: seeding (:86-87), dataset/DataLoader construction (:98-114; batch size is a config
+key here), model + target + Adam (:119-124), resume (:192-198), target sync before the update when
+``sample_number % TARGET_UPDATE_INTERVAL == 0`` (:215-216), EMA of the loss and its tensorboard scalar
+(:228-238), checkpoint dict and file name (:241-247).  Not kept: the crash after the first checkpoint
+(:248-250) and the per-step host sync of ``loss.item()`` — the loss is read back one step late
+from pinned memory so the GPU never idles.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch.utils import data
+
+from .dataset import QLearningRealDataset, SyntheticTupleDataset
+from .dist import BucketAllReduce
+from .engine import TDStepper
+from .model import build_model
+
+
+def loopLoader(loader, on_reset=None):
+    """train_q_network.py:60-67."""
+    i = iter(loader)
+    epoch = 0
+    while True:
+        try:
+            yield next(i)
+        except StopIteration:
+            print("reset iterator")
+            epoch += 1
+            if on_reset:
+                on_reset(epoch)
+            i = iter(loader)
+
+
+# ---- checkpoint: exactly the reference's dict (train_q_network.py:241-247) --------------------------------
+def optimizer_state_dict(stepper: TDStepper) -> dict:
+    """torch.optim.Adam.state_dict() layout: ids follow model.parameters() order (70 ids; resnet.fc = 60, 61
+    never receives a gradient, so it has no state — as in the reference)."""
+    net = stepper.net
+    state = {}
+    if stepper.adam_step > 0:
+        for s in net.slots.values():
+            if s.kind != 0:
+                continue
+            sl = slice(s.offset, s.offset + s.numel)
+            state[s.param_id] = {"step": stepper.adam_step,
+                                 "exp_avg": stepper.exp_avg[sl].view(s.shape).clone(),
+                                 "exp_avg_sq": stepper.exp_avg_sq[sl].view(s.shape).clone()}
+    n_params = sum(1 for s in net.slots.values() if s.kind in (0, 1))
+    group = {"lr": stepper.lr, "betas": tuple(stepper.betas), "eps": stepper.eps, "weight_decay": 0, "amsgrad": False,
+             "params": list(range(n_params))}
+    return {"state": dict(sorted(state.items())), "param_groups": [group]}
+
+
+def load_optimizer_state_dict(stepper: TDStepper, sd: dict) -> None:
+    net = stepper.net
+    by_id = {s.param_id: s for s in net.slots.values() if s.kind == 0}
+    step = 0
+    with torch.no_grad():
+        for pid, st in sd["state"].items():
+            s = by_id[int(pid)]
+            sl = slice(s.offset, s.offset + s.numel)
+            stepper.exp_avg[sl].copy_(st["exp_avg"].reshape(-1))
+            stepper.exp_avg_sq[sl].copy_(st["exp_avg_sq"].reshape(-1))
+            step = int(st["step"])
+    stepper.adam_step = step
+    g = sd["param_groups"][0]
+    stepper.lr, stepper.betas, stepper.eps = g["lr"], tuple(g["betas"]), g["eps"]
+
+
+def save_checkpoint(path, sample_number, model, stepper):
+    torch.save({"sample_number": sample_number,
+                "model_state_dict": model.state_dict(),
+                "optimizer_state_dict": optimizer_state_dict(stepper)}, path)
+
+
+def _to_device_batch(batch, device, num_classes=5):
+    before, after, act, rew, term, gt, valid = batch
+    nb = dict(non_blocking=True)
+    before, after = before.to(device, **nb), after.to(device, **nb)
+    src_kind = 0 if before.dtype == torch.uint8 else 1
+    if src_kind == 1:
+        before, after = before.float().contiguous(), after.float().contiguous()
+    act = torch.as_tensor(act).to(torch.int64).to(device, **nb)
+    rew = torch.as_tensor(rew).float().to(device, **nb)
+    term = torch.as_tensor(term).float().to(device, **nb)
+    valid = torch.as_tensor(valid).float().to(device, **nb)
+    gt = torch.as_tensor(gt).float()
+    if gt.dim() == 1:
+        gt = gt.view(-1, 1).expand(-1, num_classes)
+    gt = gt.contiguous().to(device, **nb)
+    return before.contiguous(), after.contiguous(), src_kind, act, rew, term, valid, gt
+
+
+def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=print):
+    """train_q_network.py:84-250."""
+    torch.manual_seed(config.SEED)
+    np.random.seed(config.SEED)
+    log(f"Using: {config.device}")
+    B = int(config.BATCH_SIZE)
+    params = {"batch_size": B, "num_workers": int(config.NUM_WORKERS), "drop_last": True}
+    if config.SYNTHETIC_DATA or config.DATASET in ("none", "synthetic"):
+        nf = config.NUM_FRAMES or (4 if (config.PANORAMA or config.PREVIOUS_IMAGES) else 1)
+        dataset = SyntheticTupleDataset(length=max(4 * B * world_size, 1024), num_frames=nf,
+                                        action_dim=1 if (config.VALUE_LEARNING or config.ONE_ACTION) else 3, seed=config.SEED)
+    else:
+        dataset = QLearningRealDataset(config.DATASET, one_action=True, confidence_reward=config.CONFIDENCE_REWARD,
+                                       value_learning=config.VALUE_LEARNING, inverse_actions=config.USE_INVERSE_ACTIONS,
+                                       previous_images=config.PREVIOUS_IMAGES, as_uint8=True)
+        log(f"Load data from {config.DATASET}")
+        log(f"Reward Ratio: {dataset.reward_percentage()}")
+    sampler = None
+    if world_size > 1:
+        sampler = data.distributed.DistributedSampler(dataset, num_replicas=world_size, rank=rank, shuffle=True,
+                                                      seed=config.SEED, drop_last=True)
+    loader = data.DataLoader(dataset, **params, shuffle=(sampler is None), sampler=sampler, pin_memory=True,
+                             persistent_workers=params["num_workers"] > 0)
+    log(len(dataset))
+
+    model = build_model(config, max_batch=2 * B)
+    comm = BucketAllReduce(world_size) if world_size > 1 else None
+    stepper = TDStepper(model.engine, B, lr=config.LEARNING_RATE, gamma=config.GAMMA,
+                        clip_rect=(config.LOSS_CLIP == "rect"), linear=config.LINEAR,
+                        remove_before_reward=config.REMOVE_BEFORE_REWARD,
+                        train_on_ground_truth=config.TRAIN_ON_GROUND_TRUTH, value_learning=config.VALUE_LEARNING,
+                        target_update_interval=config.TARGET_UPDATE_INTERVAL, world_size=world_size,
+                        allreduce=(comm.launch if comm else None))
+    iterator = loopLoader(loader, on_reset=(sampler.set_epoch if sampler else None))
+    os.makedirs(f"{config.folder}/models", exist_ok=True)
+    sample_number = resume_from + 1
+    if resume_from > -1:  # :192-198
+        model_loc = f"{config.folder}/models/sample{resume_from}.torch"
+        snapshot = torch.load(model_loc, map_location=config.device)
+        log(f"Loading model from: {model_loc}")
+        model.load_state_dict(snapshot["model_state_dict"])
+        load_optimizer_state_dict(stepper, snapshot["optimizer_state_dict"])
+    stepper.sync_target()  # :208
+    stepper.sample_number = sample_number
+
+    running_loss = None
+    host_loss = torch.zeros(2, dtype=torch.float32).pin_memory()
+    pending = None  # (slot, event) of the previous step's loss copy
+    num_steps = config.NUM_STEPS if max_steps is None else min(config.NUM_STEPS, sample_number + max_steps)
+
+    def consume(p):
+        nonlocal running_loss
+        slot, ev = p
+        ev.synchronize()
+        v = float(host_loss[slot])
+        running_loss = v if running_loss is None else running_loss * 0.99 + v * 0.01  # :228-231
+
+    while sample_number < num_steps:
+        sample_number += 1
+        model.set_train()  # :221 (flags only; the engine's BatchNorm is always in eval mode in extra_capacity)
+        before, after, src_kind, act, rew, term, valid, gt = _to_device_batch(next(iterator), model.engine.device)
+        # the stepper performs the :215-216 target refresh itself (sample_number % TARGET_UPDATE_INTERVAL == 0)
+        loss = stepper.step(before, after, src_kind, act, rew, term,
+                            valid if config.REMOVE_BEFORE_REWARD else None,
+                            gt if config.TRAIN_ON_GROUND_TRUTH else None,
+                            finish_allreduce=(comm.finish if comm else None))
+        if world_size > 1:
+            torch.distributed.all_reduce(loss)  # per-rank partial sums of the global mean
+        slot = sample_number & 1
+        host_loss[slot:slot + 1].copy_(loss, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if pending is not None:
+            consume(pending)
+        pending = (slot, ev)
+        if rank == 0 and running_loss is not None:
+            print(f"\rbatch:{sample_number}/{config.NUM_STEPS} avg_loss: {running_loss}", end="")
+        if sample_number % 100 == 0 and rank == 0 and running_loss is not None and hasattr(config, "writer"):
+            config.writer.add_scalar("avg_q_loss/train", running_loss, sample_number)  # :236-238
+        if sample_number % config.CHECKPOINT_INTERVAL == 0 and rank == 0:  # :241-247
+            torch.cuda.synchronize()
+            save_checkpoint(f"{config.folder}/models/sample{sample_number}.torch", sample_number, model, stepper)
+    if pending is not None:
+        consume(pending)
+    torch.cuda.synchronize()
+    return model, stepper, running_loss
