@@ -21,7 +21,13 @@
 // from archs/HabitatDQNMultiAction.py:30-31,49-53 and their backward (train_q_network.py:226).
 #include "common.h"
 
+#ifndef VDQN_IGEMM_STAGES
+#define VDQN_IGEMM_STAGES 2
+#endif
+
 namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmParams {
   const void* in;
@@ -42,8 +48,8 @@ constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (
 
 // MODE 0: forward gather (h = oh*stride - pad + kr); 1: dgrad, stride 1 (h = oh + pad - kr);
 //      2: dgrad, stride 2 (h = (oh + pad - kr) / 2 when even)
-template <typename T, int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+template <typename T, int BN, int MODE, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_kernel(const IgemmParams p) {
   constexpr int BM = 128;
   constexpr int ESZ = (int)sizeof(T);
   constexpr int KC = 128 / ESZ;
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   constexpr int LDC = BN + 4;  // f32 row stride of the epilogue tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
-  unsigned char* sB = smem + 2 * BM * 128;
+  unsigned char* sB = smem + NSTAGE * BM * 128;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -62,15 +68,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int lrow = tid >> 3;                        // tile row this thread stages (+32 i)
   const int lchunk = (tid & 7) ^ (lrow & 7);        // logical 16-byte chunk it fetches (source-side swizzle)
 
-  // ---- buffer descriptors: A relative to the first image of this tile, B = whole weight tensor ----
+  // ---- buffer descriptors (4 SGPRs each): A relative to the first image of this tile, B = whole weight tensor.
+  // The DMA is issued from inline asm: hipcc would otherwise wait vmcnt(0) before the first ds_read that follows
+  // a pending LDS-DMA (it cannot prove the buffers distinct), which serialises the copy behind the MFMAs.
   const int img0 = m0 / p.howo;
   const long long img_bytes = (long long)p.hi * p.wi * p.pix_stride * ESZ;
   const long long a_base_off = (long long)img0 * img_bytes;
   long long a_rem = p.in_bytes - a_base_off;
   if (a_rem > 0x7fffffffLL) a_rem = 0x7fffffffLL;
-  const __amdgpu_buffer_rsrc_t rs_a =
-      __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)p.in + a_base_off), (short)0, (int)a_rem, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, (short)0, p.wt_bytes, 0x00020000);
+  const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.in + a_base_off);
+  const unsigned long long b_ptr = (unsigned long long)p.wt;
+  const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane((int)a_rem), 0x00020000};
+  const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
 
   // ---- per-row gather state (4 A rows per thread) ----
   uint32_t a_off[4];
@@ -105,8 +116,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
   for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + 32 * i) * (uint32_t)(p.ktot * ESZ) + (uint32_t)(lchunk * 16);
 
-  // LDS destinations of this wave's DMA pieces: piece i of operand X covers tile rows 32 i + 8 wave .. +7
-  const int lds_piece = wave * 8 * 128;
+  // LDS byte addresses (wave-uniform) of this wave's DMA pieces: piece i of an operand covers tile rows 32 i + 8 wave .. +7
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t lds_wave = lds_base + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (8 * 128);
 
 #define VDQN_ISSUE(BUF, KR, KS, C0, KSTEP)                                                                          \
   {                                                                                                                 \
@@ -114,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                         : MODE == 1 ? ((C0) - ((KR)*p.wi + (KS)) * p.pix_stride)                                    \
                                     : ((C0) - (((KR) >> 1) * p.wi + ((KS) >> 1)) * p.pix_stride)) *                 \
                        ESZ;                                                                                         \
+    uint32_t vo_[4];                                                                                                \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
       bool ok_;                                                                                                     \
       if (MODE == 0) {                                                                                              \
@@ -124,15 +137,47 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         const int th_ = a_hb[i_] - (KR), tw_ = a_wb[i_] - (KS);                                                     \
         ok_ = (((th_ | tw_) & 1) == 0) && ((unsigned)(th_ >> 1) < (unsigned)p.hi) && ((unsigned)(tw_ >> 1) < (unsigned)p.wi); \
       }                                                                                                             \
-      const uint32_t vo_ = ok_ ? a_off[i_] + (uint32_t)delta_ : kOob;                                               \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
-          rs_a, (__attribute__((address_space(3))) void*)(sA + (BUF) * (BM * 128) + i_ * (32 * 128) + lds_piece), 16, (int)vo_, 0, 0, 0); \
+      vo_[i_] = ok_ ? a_off[i_] + (uint32_t)delta_ : kOob;                                                          \
     }                                                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < BROWS; ++i_) {                                                          \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
-          rs_b, (__attribute__((address_space(3))) void*)(sB + (BUF) * (BN * 128) + i_ * (32 * 128) + lds_piece), 16, (int)b_off[i_], \
-          (KSTEP)*128, 0, 0);                                                                                       \
+    const uint32_t la_ = lds_wave + (uint32_t)(BUF) * (BM * 128);                                                   \
+    asm volatile(                                                                                                   \
+        "s_nop 4\n\t"                                                                                               \
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, 0 offen lds\n\t"                               \
+        "s_add_u32 m0, %4, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"                       \
+        "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"                       \
+        "s_add_u32 m0, %4, 0x3000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds"                            \
+        ::"v"(vo_[0]), "v"(vo_[1]), "v"(vo_[2]), "v"(vo_[3]), "s"(la_), "s"(rs_a)                                   \
+        : "memory", "scc");                                                                                         \
+    const uint32_t lb_ = lds_wave + (uint32_t)(NSTAGE * BM * 128) + (uint32_t)(BUF) * (BN * 128);                   \
+    const int so_ = (KSTEP)*128;                                                                                    \
+    if constexpr (BROWS == 4) {                                                                                     \
+      asm volatile(                                                                                                 \
+          "s_nop 4\n\t"                                                                                             \
+          "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, %6 offen lds\n\t"                            \
+          "s_add_u32 m0, %4, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"                    \
+          "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"                    \
+          "s_add_u32 m0, %4, 0x3000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                         \
+          ::"v"(b_off[0]), "v"(b_off[1]), "v"(b_off[BROWS > 2 ? 2 : 0]), "v"(b_off[BROWS > 2 ? 3 : 0]), "s"(lb_), "s"(rs_b), "s"(so_) \
+          : "memory", "scc");                                                                                       \
+    } else {                                                                                                        \
+      asm volatile(                                                                                                 \
+          "s_nop 4\n\t"                                                                                             \
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %4 offen lds\n\t"                            \
+          "s_add_u32 m0, %2, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds"                         \
+          ::"v"(b_off[0]), "v"(b_off[1]), "s"(lb_), "s"(rs_b), "s"(so_)                                             \
+          : "memory", "scc");                                                                                       \
     }                                                                                                               \
+  }
+#define VDQN_ADVANCE()       \
+  {                          \
+    ic0 += KC;               \
+    if (ic0 >= p.ci) {       \
+      ic0 = 0;               \
+      if (++iks == p.s) {    \
+        iks = 0;             \
+        ++ikr;               \
+      }                      \
+    }                        \
   }
 
   f32x4 acc[4][NF];
@@ -145,23 +190,31 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int i16 = lane & 15, g = lane >> 4;
   const int sw = i16 & 7;
 
-  // ---- main loop: K-steps enumerate (r, s, c0) with c0 fastest ----
-  int kr = 0, ks = 0, c0 = 0;
-  VDQN_ISSUE(0, kr, ks, c0, 0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // the first tile has landed
+  // ---- main loop: K-steps enumerate (r, s, c0) with c0 fastest; NSTAGE LDS buffers, NSTAGE-1 tiles in flight ----
+  int ikr = 0, iks = 0, ic0 = 0;  // coordinates of the next K-step to issue
+  int issued = 0;
+#pragma unroll
+  for (int s_ = 0; s_ < NSTAGE - 1; ++s_) {
+    if (issued < p.nk) {
+      VDQN_ISSUE(s_, ikr, iks, ic0, issued)
+      VDQN_ADVANCE()
+      ++issued;
+    }
+  }
+  int buf = 0, ibuf = NSTAGE - 1;
   for (int k = 0; k < p.nk; ++k) {
-    const int buf = k & 1;
-    if (k + 1 < p.nk) {
-      c0 += KC;
-      if (c0 >= p.ci) {
-        c0 = 0;
-        if (++ks == p.s) {
-          ks = 0;
-          ++kr;
-        }
-      }
-      VDQN_ISSUE(buf ^ 1, kr, ks, c0, k + 1)
+    // tile k has landed once at most (issued - k - 1) younger tiles are still outstanding
+    if (NSTAGE == 3 && issued - k - 1 >= 1) {
+      if constexpr (BROWS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile k are visible; every wave is done with tile k-1
+    if (issued < p.nk) {
+      VDQN_ISSUE(ibuf, ikr, iks, ic0, issued)
+      VDQN_ADVANCE()
+      ++issued;
     }
     const unsigned char* a = sA + buf * (BM * 128) + (wr * 64 + i16) * 128;
     const unsigned char* b = sB + buf * (BN * 128) + (wc * (BN / 2) + i16) * 128;
@@ -188,10 +241,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // next tile landed and every wave is done reading this one
+    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    ibuf = (ibuf + 1 == NSTAGE) ? 0 : ibuf + 1;
   }
+  __syncthreads();  // all waves done reading LDS before the epilogue reuses it
 #undef VDQN_ISSUE
+#undef VDQN_ADVANCE
 
   // ---- epilogue: accumulators -> LDS f32 tile (C layout: col = lane & 15, row = (lane >> 4) * 4 + reg) ----
   float* sC = reinterpret_cast<float*>(smem);
@@ -270,11 +325,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
 template <typename T, int BN, int MODE>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
-  const size_t main_bytes = 2 * (128 + BN) * 128, epi_bytes = 128 * (BN + 4) * 4;
+  constexpr int NSTAGE = VDQN_IGEMM_STAGES;
+  const size_t main_bytes = NSTAGE * (128 + BN) * 128, epi_bytes = 128 * (BN + 4) * 4;
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BN, MODE, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
@@ -283,7 +339,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
                   2.0 * p.M * p.co * p.ktot,
                   esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
                   stream);
-  hipLaunchKernelGGL((igemm_kernel<T, BN, MODE>), dim3(grid), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BN, MODE, NSTAGE>), dim3(grid), dim3(256), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;

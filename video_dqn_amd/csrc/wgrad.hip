@@ -24,7 +24,7 @@ struct WgradParams {
   const void* x;
   float* dw;
   int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldg, r, s, stride, pad;
-  int M, kchunk, taps, ci_tiles;
+  int M, kchunk, taps, ci_tiles, gy_bytes, x_bytes;
   FastDiv d_howo, d_wo;
 };
 
@@ -37,14 +37,24 @@ template <typename T, int BT> __device__ __forceinline__ int wg_swz(int row) {
   }
 }
 
+// pixels per staged K-step / 32: sized so each barrier covers >= 16 MFMAs per wave within 64 KiB of LDS
+template <typename T, int BT> constexpr int wg_ksub() {
+  return sizeof(T) == 2 ? (BT == 64 ? 4 : 2) : (BT == 64 ? 2 : 1);
+}
+
 template <typename T, int BT>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   constexpr int E16 = 16 / (int)sizeof(T);
   constexpr int RB = BT * (int)sizeof(T);  // bytes per LDS row (one pixel)
   constexpr int CPR = RB / 16;             // 16-byte chunks per row
-  constexpr int NL = (32 * CPR) / 256;     // chunks per thread per operand per K-step
-  constexpr int NFR = BT / 32;             // 16-wide fragments per wave per dim
-  constexpr int KP = 32;
+  constexpr int KSUB = wg_ksub<T, BT>();   // 32-pixel MFMA sub-steps per staged K-step
+  constexpr int KP = 32 * KSUB;            // pixels staged per K-step (one barrier per KP pixels)
+  constexpr int NL = (KP * CPR) / 256;     // 16-byte chunks per thread per operand per K-step
+  // WSPLIT (bf16, 64x64 tile): instead of a 2x2 wave grid of 32x32 sub-tiles (4 MFMAs per 8 transposing reads: LDS
+  // bandwidth bound), every wave owns the whole 64x64 tile for ONE of the four 32-pixel sub-steps of a staged K-step
+  // (16 MFMAs per 16 reads) and the four partial tiles are summed through LDS before the atomics.
+  constexpr bool WSPLIT = (sizeof(T) == 2 && BT == 64);
+  constexpr int NFR = WSPLIT ? BT / 16 : BT / 32;  // 16-wide fragments per wave per dim
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;                 // [2][KP*RB]
   unsigned char* sB = smem + 2 * KP * RB;   // [2][KP*RB]
@@ -65,43 +75,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const T* __restrict__ gy = (const T*)p.gy;
   const T* __restrict__ x = (const T*)p.x;
 
-  int l_row[NL], l_ch[NL];
+  // HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) issued from inline asm (see igemm.hip): the LDS image is
+  // lane-linear ([32 pixels][RB bytes], thread q stages 16-byte slot q), so the XOR swizzle is applied to the
+  // SOURCE chunk; rows past the split range and padding taps get an out-of-range offset -> zero fill.
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long g_ptr = (unsigned long long)p.gy, x_ptr = (unsigned long long)p.x;
+  const i32x4 rs_g = {__builtin_amdgcn_readfirstlane((int)(unsigned)g_ptr), __builtin_amdgcn_readfirstlane((int)((g_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane(p.gy_bytes), 0x00020000};
+  const i32x4 rs_x = {__builtin_amdgcn_readfirstlane((int)(unsigned)x_ptr), __builtin_amdgcn_readfirstlane((int)((x_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane(p.x_bytes), 0x00020000};
+  constexpr unsigned kOobW = 0x80000000u;
+  int l_row[NL];
+  uint32_t l_goff[NL], l_xoff[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int q = tid + 256 * i;
     l_row[i] = q / CPR;
-    l_ch[i] = q % CPR;
+    const int ch = (q % CPR) ^ wg_swz<T, BT>(l_row[i]);
+    l_goff[i] = (uint32_t)((co0 + ch * E16) * (int)sizeof(T));
+    l_xoff[i] = (uint32_t)((ci0 + ch * E16) * (int)sizeof(T));
   }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t lds_wave = lds_base + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+  const uint32_t ldg_b = (uint32_t)p.ldg * (uint32_t)sizeof(T);
+  const uint32_t pix_b = (uint32_t)p.pix_stride * (uint32_t)sizeof(T);
 
-  uint4 ra[NL], rb[NL];
-  auto load_tile = [&](int kb) {
+  auto issue_tile = [&](int kb, int buf) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int pm = kb + l_row[i];
       const bool ok = pm < kend;
-      uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) {
-        va = *reinterpret_cast<const uint4*>(gy + (size_t)pm * p.ldg + co0 + l_ch[i] * E16);
-        const uint32_t img = fastdiv((uint32_t)pm, p.d_howo);
-        const uint32_t rem = (uint32_t)pm - img * p.d_howo.div;
-        const uint32_t oh = fastdiv(rem, p.d_wo);
-        const uint32_t ow = rem - oh * p.d_wo.div;
-        const int h = (int)oh * p.stride - p.pad + kr;
-        const int w = (int)ow * p.stride - p.pad + ks;
-        if ((unsigned)h < (unsigned)p.hi && (unsigned)w < (unsigned)p.wi)
-          vb = *reinterpret_cast<const uint4*>(x + ((size_t)img * p.hi * p.wi + (size_t)(h * p.wi + w)) * p.pix_stride + ci0 +
-                                               l_ch[i] * E16);
-      }
-      ra[i] = va;
-      rb[i] = vb;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int off = l_row[i] * RB + ((l_ch[i] ^ wg_swz<T, BT>(l_row[i])) << 4);
-      *reinterpret_cast<uint4*>(sA + buf * (KP * RB) + off) = ra[i];
-      *reinterpret_cast<uint4*>(sB + buf * (KP * RB) + off) = rb[i];
+      const uint32_t img = fastdiv((uint32_t)pm, p.d_howo);
+      const uint32_t rem = (uint32_t)pm - img * p.d_howo.div;
+      const uint32_t oh = fastdiv(rem, p.d_wo);
+      const uint32_t ow = rem - oh * p.d_wo.div;
+      const int h = (int)oh * p.stride - p.pad + kr;
+      const int w = (int)ow * p.stride - p.pad + ks;
+      const bool okx = ok && ((unsigned)h < (unsigned)p.hi) && ((unsigned)w < (unsigned)p.wi);
+      const uint32_t vg = ok ? (uint32_t)pm * ldg_b + l_goff[i] : kOobW;
+      const uint32_t vx = okx ? ((img * (uint32_t)p.hi + (uint32_t)h) * (uint32_t)p.wi + (uint32_t)w) * pix_b + l_xoff[i] : kOobW;
+      const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RB) + i * 4096);
+      const uint32_t lb = la + (uint32_t)(2 * KP * RB);
+      asm volatile(
+          "s_nop 4\n\t"
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %4, 0 offen lds\n\t"
+          "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds"
+          ::"v"(vg), "v"(vx), "s"(la), "s"(lb), "s"(rs_g), "s"(rs_x)
+          : "memory");
     }
   };
 
@@ -111,12 +131,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int j = 0; j < NFR; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = WSPLIT ? 0 : (wave >> 1), wc = WSPLIT ? 0 : (wave & 1);
   const int grp = lane >> 4, i16 = lane & 15;
 
   auto compute = [&](int buf) {
-    const unsigned char* a = sA + buf * (KP * RB);
-    const unsigned char* b = sB + buf * (KP * RB);
+#pragma unroll
+   for (int sub0 = 0; sub0 < (WSPLIT ? 1 : KSUB); ++sub0) {
+    const int sub = WSPLIT ? wave : sub0;
+    const unsigned char* a = sA + buf * (KP * RB) + sub * (32 * RB);
+    const unsigned char* b = sB + buf * (KP * RB) + sub * (32 * RB);
     if constexpr (sizeof(T) == 2) {
       // transposing read: lane 4q+pp of a 16-lane group addresses pixel row (4*grp + q), channels 4pp..4pp+3
       const int q = i16 >> 2, pp = i16 & 3;
@@ -168,30 +191,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
           for (int j = 0; j < NFR; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f], bv[j], acc[f][j], 0, 0, 0);
       }
     }
+   }
   };
 
-  load_tile(kbeg);
+  issue_tile(kbeg, 0);
   for (int k = 0; k < nk; ++k) {
     const int buf = k & 1;
-    store_tile(buf);
-    __syncthreads();
-    if (k + 1 < nk) load_tile(kbeg + (k + 1) * KP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile k landed for every wave; every wave is done with tile k-1
+    if (k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
     compute(buf);
   }
 
   // C layout: col (lane & 15) -> ci, row ((lane >> 4) * 4 + reg) -> co
   const size_t row_len = (size_t)p.taps * p.ci;
+  if constexpr (WSPLIT) {
+    static_assert(!WSPLIT || KSUB == 4, "wave split needs 4 sub-steps");
+    __syncthreads();  // everyone is done with the staging buffers: reuse them as 4 x [64][64] f32
+    float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int f = 0; f < NFR; ++f)
+    for (int f = 0; f < NFR; ++f)
 #pragma unroll
-    for (int j = 0; j < NFR; ++j) {
-      const int ci = ci0 + wc * (BT / 2) + j * 16 + i16;
+      for (int j = 0; j < NFR; ++j)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int co = co0 + wr * (BT / 2) + f * 16 + grp * 4 + reg;
-        if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, acc[f][j][reg]);
-      }
+        for (int reg = 0; reg < 4; ++reg) red[wave * 4096 + (f * 16 + grp * 4 + reg) * 64 + j * 16 + i16] = acc[f][j][reg];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int o = tid + 256 * e;
+      const float v = red[o] + red[4096 + o] + red[8192 + o] + red[12288 + o];
+      const int co = co0 + (o >> 6), ci = ci0 + (o & 63);
+      if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, v);
     }
+  } else {
+#pragma unroll
+    for (int f = 0; f < NFR; ++f)
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) {
+        const int ci = ci0 + wc * (BT / 2) + j * 16 + i16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int co = co0 + wr * (BT / 2) + f * 16 + grp * 4 + reg;
+          if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, acc[f][j][reg]);
+        }
+      }
+  }
 }
 
 // dbias[c] += sum_m gy[m][c]: 16-byte column groups x row stripes per block, stripes reduced through LDS,
@@ -231,7 +275,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ gy, f
 
 template <typename T, int BT>
 int launch_wgrad(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
-  const size_t smem = 4 * 32 * BT * sizeof(T);
+  const size_t smem = 4 * 32 * wg_ksub<T, BT>() * BT * sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -267,6 +311,12 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   p.ho = a->ho; p.wo = a->wo; p.co = a->co; p.ldg = a->ldg; p.r = a->r; p.s = a->s; p.stride = a->stride; p.pad = a->pad;
   p.M = (int)M64;
   p.taps = a->r * a->s;
+  const long long gyb = M64 * a->ldg * (a->dtype == VDQN_BF16 ? 2 : 4);
+  const long long xb = (long long)a->n_img * a->hi * a->wi * a->pix_stride * (a->dtype == VDQN_BF16 ? 2 : 4);
+  VDQN_CHECK(gyb < 0x7fffffffLL && xb < 0x7fffffffLL, "vdqn_conv2d_wgrad: operand larger than 2 GiB (split the batch)");
+  VDQN_CHECK(((uintptr_t)a->gy & 15) == 0 && ((uintptr_t)a->x & 15) == 0, "vdqn_conv2d_wgrad: operands must be 16-byte aligned");
+  p.gy_bytes = (int)gyb;
+  p.x_bytes = (int)xb;
   p.d_howo = make_fastdiv((uint32_t)(a->ho * a->wo));
   p.d_wo = make_fastdiv((uint32_t)a->wo);
   const int bt = (co_pad % 128 == 0 && a->ci % 128 == 0) ? 128 : 64;
@@ -274,13 +324,13 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   const int tiles = (co_pad / bt) * p.taps * p.ci_tiles;
   int splitk = a->splitk;
   if (splitk <= 0) {
-    splitk = (1024 + tiles - 1) / tiles;
+    splitk = 1024 / tiles;  // <= 1024 blocks: two full rounds at 2 blocks per CU, no third (tail) round
     const int max_split = (p.M + 255) / 256;  // at least 8 K-steps per block
     if (splitk > max_split) splitk = max_split;
     if (splitk < 1) splitk = 1;
   }
   VDQN_CHECK(splitk <= 65535, "vdqn_conv2d_wgrad: splitk too large");
-  p.kchunk = ((p.M + splitk - 1) / splitk + 31) / 32 * 32;
+  p.kchunk = ((p.M + splitk - 1) / splitk + 127) / 128 * 128;  // multiple of every kernel variant's K-step
   int rc;
   if (a->dtype == VDQN_BF16) rc = bt == 128 ? launch_wgrad<bf16raw, 128>(p, tiles, splitk, st) : launch_wgrad<bf16raw, 64>(p, tiles, splitk, st);
   else rc = bt == 128 ? launch_wgrad<float, 128>(p, tiles, splitk, st) : launch_wgrad<float, 64>(p, tiles, splitk, st);
