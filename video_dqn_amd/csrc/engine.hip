@@ -10,6 +10,7 @@
 //   dL/dW = dW' * s,   dL/dbeta = sum(gy),   dL/dgamma = rstd * ( <dW'[co,:], W[co,:]> - mean * dL/dbeta ).
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -92,9 +93,54 @@ struct vdqn_net {
   // layer indices
   int l_conv1, l_f8, l_top0, l_top2, l_top4;
   int l_b_conv1[8], l_b_conv2[8], l_b_ds[8];
+  // A second HIP stream for work that is independent of the main dependency chain: the weight gradients (they only
+  // need gy, the data-gradient chain does not wait for them) and the target-network forward.  Blocks of the side
+  // kernels fill the tail rounds of the main kernels (784..3136-block grids on 512 resident blocks).
+  int overlap = 1;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t ev_next = 0;
 };
 
 namespace {
+
+bool side_ready(vdqn_net* net) {
+  if (!net->overlap) return false;
+  if (!net->side) {
+    if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess) {
+      net->overlap = 0;
+      net->side = nullptr;
+      return false;
+    }
+    net->events.resize(64);
+    for (auto& e : net->events)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        net->overlap = 0;
+        return false;
+      }
+  }
+  return true;
+}
+hipEvent_t next_event(vdqn_net* net) {
+  hipEvent_t e = net->events[net->ev_next];
+  net->ev_next = (net->ev_next + 1) % net->events.size();
+  return e;
+}
+// the side stream waits for everything queued on `main` so far; returns the stream to launch the side work on
+hipStream_t fork_side(vdqn_net* net, hipStream_t main) {
+  if (!side_ready(net)) return main;
+  hipEvent_t e = next_event(net);
+  (void)hipEventRecord(e, main);
+  (void)hipStreamWaitEvent(net->side, e, 0);
+  return net->side;
+}
+// `main` waits for everything queued on the side stream so far
+void join_side(vdqn_net* net, hipStream_t main) {
+  if (!net->overlap || !net->side) return;
+  hipEvent_t e = next_event(net);
+  (void)hipEventRecord(e, net->side);
+  (void)hipStreamWaitEvent(main, e, 0);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // fold / unfold kernels
@@ -595,6 +641,10 @@ extern "C" int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out) {
   vdqn_net* net = new vdqn_net();
   net->cfg = *cfg;
   net->esz = cfg->dtype == VDQN_BF16 ? 2 : 4;
+  {
+    const char* no = getenv("VDQN_NO_OVERLAP");
+    net->overlap = (no && no[0] == '1') ? 0 : 1;
+  }
   build_layers(net);
   if ((int)net->layers.size() > kMaxLayers) {
     delete net;
@@ -605,7 +655,16 @@ extern "C" int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out) {
   return VDQN_OK;
 }
 
-extern "C" void vdqn_net_destroy(vdqn_net* net) { delete net; }
+extern "C" void vdqn_net_destroy(vdqn_net* net) {
+  if (!net) return;
+  if (net->side) {
+    (void)hipStreamSynchronize(net->side);
+    for (auto& e : net->events)
+      if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(net->side);
+  }
+  delete net;
+}
 
 extern "C" int vdqn_net_num_params(const vdqn_net* net) { return net ? (int)net->params.size() : 0; }
 extern "C" int vdqn_net_param_info(const vdqn_net* net, int index, vdqn_param_info* out) {
@@ -707,7 +766,14 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   const int64_t frame_bytes = (int64_t)115 * 115 * 16 * net->esz;
   RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, st));
   if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, st));
+  hipStream_t tst = st;  // stream of the target-network forward
+  if (!gtb) {
+    tst = fork_side(net, st);  // the packed input is ready; the target pass only reads it and its own weights
+    const ActLayout T = act_layout(net, B);
+    RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst));
+  }
   RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st));
+  if (tst != st) join_side(net, st);
 
   hipError_t e = hipMemsetAsync(bw + W.zero_begin, 0, (size_t)W.zero_bytes, st);
   VDQN_CHECK(e == hipSuccess, "vdqn_net_td_forward: memset failed: %s", hipGetErrorString(e));
@@ -718,7 +784,6 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   if (!gtb) {
     const ActLayout T = act_layout(net, B);
     unsigned char* at = (unsigned char*)a->acts_target;
-    RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, at, T, st));
     vdqn_td_args t;
     memset(&t, 0, sizeof(t));
     t.q_before = qf_online;
@@ -746,7 +811,7 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
 namespace {
 
 // backward of BasicBlock b (gradient of its output, already ReLU-masked, is in g_o[b])
-int block_backward(const vdqn_net* net, const vdqn_step_args* a, int b, const ActLayout& A, const BwdLayout& W, int n, hipStream_t st) {
+int block_backward(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayout& A, const BwdLayout& W, int n, hipStream_t st) {
   const unsigned char* pk = (const unsigned char*)a->packed_online;
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
@@ -756,13 +821,15 @@ int block_backward(const vdqn_net* net, const vdqn_step_args* a, int b, const Ac
   unsigned char* gx = b == 0 ? bw + W.g_pool : bw + W.g_o[b - 1];
   const void* g_out = bw + W.g_o[b];
   // conv2: weight gradient, then data gradient into g_h masked by relu(h)
-  RC(run_wgrad(net, c2, bw, g_out, ao + A.h[b], n, st));
+  hipStream_t ws = fork_side(net, st);  // g_out is complete on `st`
+  RC(run_wgrad(net, c2, bw, g_out, ao + A.h[b], n, ws));
+  if (net->l_b_ds[b] >= 0) RC(run_wgrad(net, net->layers[net->l_b_ds[b]], bw, g_out, x, n, ws));
   RC(run_dgrad(net, c2, pk, g_out, bw + W.g_h[b], n, nullptr, ao + A.h[b], st));
-  RC(run_wgrad(net, c1, bw, bw + W.g_h[b], x, n, st));
+  ws = fork_side(net, st);  // g_h is complete
+  RC(run_wgrad(net, c1, bw, bw + W.g_h[b], x, n, ws));
   const void* resid = g_out;  // identity shortcut
   if (net->l_b_ds[b] >= 0) {
     const Layer& ds = net->layers[net->l_b_ds[b]];
-    RC(run_wgrad(net, ds, bw, g_out, x, n, st));
     RC(run_dgrad(net, ds, pk, g_out, bw + W.dsg[b], n, nullptr, nullptr, st));
     resid = bw + W.dsg[b];
   }
@@ -789,13 +856,13 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     const Layer& t2 = net->layers[net->l_top2];
     const Layer& t0 = net->layers[net->l_top0];
     const Layer& f8 = net->layers[net->l_f8];
-    RC(run_wgrad(net, t4, bw, bw + W.dq, ao + A.l1, B, st));
+    RC(run_wgrad(net, t4, bw, bw + W.dq, ao + A.l1, B, fork_side(net, st)));
     RC(run_dgrad(net, t4, pk, bw + W.dq, bw + W.g_l1, B, nullptr, ao + A.l1, st));
-    RC(run_wgrad(net, t2, bw, bw + W.g_l1, ao + A.l0, B, st));
+    RC(run_wgrad(net, t2, bw, bw + W.g_l1, ao + A.l0, B, fork_side(net, st)));
     RC(run_dgrad(net, t2, pk, bw + W.g_l1, bw + W.g_l0, B, nullptr, ao + A.l0, st));
-    RC(run_wgrad(net, t0, bw, bw + W.g_l0, ao + A.f8, B, st));
+    RC(run_wgrad(net, t0, bw, bw + W.g_l0, ao + A.f8, B, fork_side(net, st)));
     RC(run_dgrad(net, t0, pk, bw + W.g_l0, bw + W.g_f8, B, nullptr, ao + A.f8, st));
-    RC(run_wgrad(net, f8, bw, bw + W.g_f8, ao + A.o[7], n, st));
+    RC(run_wgrad(net, f8, bw, bw + W.g_f8, ao + A.o[7], n, fork_side(net, st)));
     RC(run_dgrad(net, f8, pk, bw + W.g_f8, bw + W.g_o[7], n, nullptr, ao + A.o[7], st));
     RC(block_backward(net, a, 7, A, W, n, st));
     RC(block_backward(net, a, 6, A, W, n, st));
@@ -805,8 +872,9 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   } else {
     for (int b = 3; b >= 0; --b) RC(block_backward(net, a, b, A, W, n, st));
     RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, ao + A.c1, bw + W.g_c1, n, 112, 112, 64, dt, st));
-    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, st));
+    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
   }
+  join_side(net, st);  // every weight gradient of this stage is complete before it is unfolded
   int max_co = 0;
   for (int i = net->layer_stage_first[stage]; i < net->layer_stage_first[stage] + net->layer_stage_count[stage]; ++i)
     max_co = net->layers[i].co > max_co ? net->layers[i].co : max_co;

@@ -24,7 +24,7 @@ struct WgradParams {
   const void* x;
   float* dw;
   int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldg, r, s, stride, pad;
-  int M, kchunk, taps, ci_tiles, gy_bytes, x_bytes;
+  int M, kchunk, taps, ci_tiles, gy_bytes, x_bytes, splitk;
   FastDiv d_howo, d_wo;
 };
 
@@ -60,14 +60,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   unsigned char* sB = smem + 2 * KP * RB;   // [2][KP*RB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int t = blockIdx.x;
+  // 1-D grid, XCD-aware: the blocks of one pixel range (all taps / channel tiles of one split) get consecutive
+  // logical ids on ONE XCD, so the 9 taps re-read their gy / x rows from that XCD's L2 instead of the fabric.
+  const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int n_tiles = (int)(gridDim.x / (uint32_t)p.splitk);
+  const int split = (int)(lb / (uint32_t)n_tiles);
+  int t = (int)(lb - (uint32_t)split * (uint32_t)n_tiles);
   const int ci_tile = t % p.ci_tiles;
   t /= p.ci_tiles;
   const int tap = t % p.taps;
   const int co_tile = t / p.taps;
   const int kr = tap / p.s, ks = tap - kr * p.s;
   const int co0 = co_tile * BT, ci0 = ci_tile * BT;
-  const int kbeg = blockIdx.y * p.kchunk;
+  const int kbeg = split * p.kchunk;
   const int kend = min(p.M, kbeg + p.kchunk);
   if (kbeg >= kend) return;
   const int nk = (kend - kbeg + KP - 1) / KP;
@@ -285,7 +290,7 @@ int launch_wgrad(const WgradParams& p, int tiles, int splitk, hipStream_t stream
   vdqn_prof_begin(sizeof(T) == 2 ? (BT == 128 ? "wgrad<bf16,128>" : "wgrad<bf16,64>") : (BT == 128 ? "wgrad<f32,128>" : "wgrad<f32,64>"),
                   2.0 * p.M * p.co * p.taps * p.ci,
                   esz * ((double)p.M * p.ldg + (double)p.n_img * p.hi * p.wi * p.ci) + 4.0 * p.co * p.taps * p.ci, stream);
-  hipLaunchKernelGGL((wgrad_kernel<T, BT>), dim3(tiles, splitk), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((wgrad_kernel<T, BT>), dim3(tiles * splitk), dim3(256), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
@@ -329,7 +334,7 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
     if (splitk > max_split) splitk = max_split;
     if (splitk < 1) splitk = 1;
   }
-  VDQN_CHECK(splitk <= 65535, "vdqn_conv2d_wgrad: splitk too large");
+  p.splitk = splitk;
   p.kchunk = ((p.M + splitk - 1) / splitk + 127) / 128 * 128;  // multiple of every kernel variant's K-step
   int rc;
   if (a->dtype == VDQN_BF16) rc = bt == 128 ? launch_wgrad<bf16raw, 128>(p, tiles, splitk, st) : launch_wgrad<bf16raw, 64>(p, tiles, splitk, st);
