@@ -145,6 +145,10 @@ def main():
     roofline = None
     kernels = None
     if not args.no_profile and rank == 0:
+        # per-kernel roofline timing: serialise the engine's side stream so every kernel has the chip to itself
+        # (in the timed region above weight gradients / the target forward overlap the main chain)
+        net.lib.vdqn_net_set_overlap(net.handle, 0)
+        torch.cuda.synchronize()
         _lib.profile_enable(True)
         for _ in range(args.profile_steps):
             stp.forward_backward(before, after, 0, act, rew, term)
@@ -154,6 +158,7 @@ def main():
         torch.cuda.synchronize()
         prof = _lib.profile_collect()
         _lib.profile_enable(False)
+        net.lib.vdqn_net_set_overlap(net.handle, 1)
         tot_ms = sum(v["ms"] for v in prof.values())
         kernels = {k: {"launches_per_step": v["launches"] // args.profile_steps, "ms_per_step": round(v["ms"] / args.profile_steps, 4),
                        "share": round(v["ms"] / tot_ms, 4),
@@ -168,7 +173,7 @@ def main():
                         "frac": round(ach / peak, 4), "traffic": None,
                         "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
                         "alg_flops_per_launch": round(v["flops"] / v["launches"]),
-                        "measured": f"HIP events around every launch, {args.profile_steps} steps right after the timed region"}
+                        "measured": f"HIP events around every launch, {args.profile_steps} steps right after the timed region, side-stream overlap off"}
         else:
             ach = v["bytes"] / v["ms"] / 1e6
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -60,7 +60,8 @@ int vdqn_profile_collect(vdqn_prof_entry* out, int max_entries);
  *   out[m, n] = epilogue( sum_{r,s,c} in[pix(m,r,s), c] * wt[n][r][s][c] )
  *   mode 0 (forward gather):  hi = ho*stride - pad + r,           wi likewise
  *   mode 1 (dgrad gather):    hi = (ho + pad - r) / stride if divisible and in range (transposed conv)
- *   epilogue: v += bias[n]; v += resid[m,n]; relu; v = mask[m,n] > 0 ? v : 0   (each optional)
+ *   epilogue: v += bias[n]; v += resid[m,n]; relu; v = mask[m,n] > 0 ? v : 0   (each optional);
+ *             optional per-tile column sums of the stored values (colsum_part)
  * Replaces: torch conv2d/linear (+ folded eval BatchNorm, ReLU, residual add) reached from
  * archs/HabitatDQNMultiAction.py:30-31,49-53 and their autograd backward (train_q_network.py:226).
  * `ci` must be a multiple of 128 bytes / sizeof(elem); `wt` holds co_pad = roundup(co, 64 or 128) rows. */
@@ -72,6 +73,9 @@ typedef struct vdqn_conv_args {
   const void* mask;    /* [m][ldo] or NULL */
   void* out;           /* [m][ldo], dtype; may be NULL if out_f32 is given */
   float* out_f32;      /* optional f32 copy of the result [m][ldo] */
+  float* colsum_part;  /* optional [ceil(m/128)][ldo] f32: per 128-row tile, column sums of the stored `out` values
+                          (summed over tiles they are the bias / BatchNorm-shift gradient of the layer that `out`
+                          is the output-gradient of) */
   int32_t n_img, hi, wi, ci, pix_stride;
   int32_t ho, wo, co, ldo;
   int32_t r, s, stride, pad;
@@ -162,6 +166,11 @@ typedef struct vdqn_net_config {
 typedef struct vdqn_net vdqn_net;
 
 int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out);
+/* The engine runs weight gradients and the target-network forward on a second, internal HIP stream (joined back
+ * into the caller's stream before their results are consumed).  on = 0 serialises everything on the caller's
+ * stream (used for per-kernel roofline timing, where each kernel must have the chip to itself).  Default: on
+ * (or off when the environment has VDQN_NO_OVERLAP=1). */
+int vdqn_net_set_overlap(vdqn_net* net, int on);
 void vdqn_net_destroy(vdqn_net* net);
 
 /* Parameter table: the reference's named_parameters()/buffers as slices of two flat f32 arrays.

@@ -89,10 +89,12 @@ def test_conv_dgrad(case, dtype):
     ref = F.grad.conv2d_input((n, ci, h, h), w, gy, stride, pad)
     ref = (ref + res) * (xact > 0)
     wd = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)  # [ci][r][s][co]
-    got = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=h, co=ci, r=k, s=k, stride=stride, pad=pad, mode=1,
-                     resid=nhwc(res, dtype), mask=nhwc(xact, dtype))
+    got, part = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=h, co=ci, r=k, s=k, stride=stride, pad=pad, mode=1,
+                           resid=nhwc(res, dtype), mask=nhwc(xact, dtype), want_colsum=True)
     torch.cuda.synchronize()
     assert relerr(got.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    # per-tile column sums of the stored values (feeds the bias / BatchNorm-shift gradients)
+    assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -11,14 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvdqn.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 
 class ConvArgs(C.Structure):
     _fields_ = [("in_", c_vp), ("wt", c_vp), ("bias", c_vp), ("resid", c_vp), ("mask", c_vp), ("out", c_vp),
-                ("out_f32", c_vp),
+                ("out_f32", c_vp), ("colsum_part", c_vp),
                 ("n_img", c_i32), ("hi", c_i32), ("wi", c_i32), ("ci", c_i32), ("pix_stride", c_i32),
                 ("ho", c_i32), ("wo", c_i32), ("co", c_i32), ("ldo", c_i32),
                 ("r", c_i32), ("s", c_i32), ("stride", c_i32), ("pad", c_i32),
@@ -82,6 +82,7 @@ _SIGS = {
     "vdqn_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_vp]),
     "vdqn_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(c_vp)]),
     "vdqn_net_destroy": (None, [c_vp]),
+    "vdqn_net_set_overlap": (C.c_int, [c_vp, C.c_int]),
     "vdqn_net_num_params": (C.c_int, [c_vp]),
     "vdqn_net_param_info": (C.c_int, [c_vp, C.c_int, C.POINTER(ParamInfo)]),
     "vdqn_net_params_numel": (c_i64, [c_vp]),

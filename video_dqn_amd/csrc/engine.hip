@@ -28,7 +28,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 1; }
+extern "C" int vdqn_abi_version(void) { return 2; }
 
 namespace {
 
@@ -63,6 +63,12 @@ struct FoldTable {
   int n;
   FoldDesc d[kMaxLayers];
 };
+// where unfold finds dL/dbias of layer i: tiles > 0 -> sum of dgrad-epilogue partials
+//   sum_t sum_g part[t * ld + g * gstride + co]   (g < groups), else the colsum kernel's db[co]
+struct PartTable {
+  int64_t off[kMaxLayers];
+  int tiles[kMaxLayers], ld[kMaxLayers], groups[kMaxLayers], gstride[kMaxLayers];
+};
 
 struct ActLayout {
   int64_t t_in, c1, pool, idx;
@@ -73,6 +79,7 @@ struct ActLayout {
 struct BwdLayout {
   int64_t zero_begin, zero_bytes;  // region cleared every step: dW', dbias', loss scratch
   int64_t dq, g_l1, g_l0, g_f8, g_o[8], g_h[8], dsg[8], g_pool, g_c1;
+  int64_t p_l1, p_l0, p_f8, p_o[8], p_h[8];  // per-128-row-tile column sums written by the dgrad epilogues
   int64_t total;
 };
 
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const fl
 }
 
 // grid: (max co, layers of the stage): one block per output channel
-__global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, int first_layer, const float* __restrict__ params,
+__global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, const PartTable pt, int first_layer, const float* __restrict__ params,
                                                      const float* __restrict__ bnstats, const unsigned char* __restrict__ bwd,
                                                      float* __restrict__ grads) {
   const FoldDesc& d = tab.d[first_layer + blockIdx.y];
@@ -227,6 +234,17 @@ __global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, int fi
   if (co >= d.co) return;
   const float* dw = reinterpret_cast<const float*>(bwd + d.dw_off) + (long)co * d.kf;
   const float* db = reinterpret_cast<const float*>(bwd + d.db_off);
+  const int li = first_layer + blockIdx.y;
+  float dbsum = 0.f;
+  if (pt.tiles[li] > 0) {
+    const float* part = reinterpret_cast<const float*>(bwd + pt.off[li]);
+    const int per_tile = pt.groups[li];
+    const int total = pt.tiles[li] * per_tile;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int t = i / per_tile, g = i - t * per_tile;
+      dbsum += part[(long)t * pt.ld[li] + g * pt.gstride[li] + co];
+    }
+  }
   float rstd = 1.f, sc = 1.f;
   if (d.has_bn) {
     rstd = 1.0f / sqrtf(bnstats[d.var_off + co] + kBnEps);
@@ -241,14 +259,20 @@ __global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, int fi
       dot += g * params[d.w_off + src];
     }
   }
-  __shared__ float red[4];
+  __shared__ float red[8];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  for (int o = 32; o > 0; o >>= 1) {
+    dot += __shfl_down(dot, o, 64);
+    dbsum += __shfl_down(dbsum, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = dot;
+    red[4 + (threadIdx.x >> 6)] = dbsum;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     const float tot = red[0] + red[1] + red[2] + red[3];
-    const float dbp = db[co];
+    const float dbp = pt.tiles[li] > 0 ? (red[4] + red[5] + red[6] + red[7]) : db[co];
     if (d.has_bn) {
       grads[d.g_off + co] = rstd * (tot - bnstats[d.mean_off + co] * dbp);
       grads[d.b_off + co] = dbp;
@@ -529,6 +553,15 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
   }
   L.g_pool = take(n * 56 * 56 * 64 * e);
   L.g_c1 = take(n * 112 * 112 * 64 * e);
+  auto tiles = [](int64_t rows) { return (rows + 127) / 128; };
+  L.p_l1 = take(tiles(n_samples) * 256 * 4);
+  L.p_l0 = take(tiles(n_samples) * 512 * 4);
+  L.p_f8 = take(tiles(n_samples) * 1600 * F * 4);
+  for (int b = 0; b < 8; ++b) {
+    const int64_t planes = 64 << (b / 2), sp = 56 >> (b / 2);
+    L.p_o[b] = take(tiles(n * sp * sp) * planes * 4);
+    L.p_h[b] = take(tiles(n * sp * sp) * planes * 4);
+  }
   L.total = off;
   return L;
 }
@@ -559,7 +592,7 @@ int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, c
 
 // data gradient: gx = (dgrad(gy) + resid) masked by (mask > 0)
 int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* gy, void* gx, int n_units, const void* resid,
-              const void* mask, hipStream_t st) {
+              const void* mask, hipStream_t st, void* colsum_part = nullptr) {
   vdqn_conv_args a;
   memset(&a, 0, sizeof(a));
   a.in = gy;
@@ -568,6 +601,7 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
   a.resid = resid;
   a.mask = mask;
   a.out = gx;
+  a.colsum_part = reinterpret_cast<float*>(colsum_part);
   a.n_img = n_units; a.hi = L.ho; a.wi = L.wo; a.ci = L.co_pad; a.pix_stride = L.co_pad;
   a.ho = L.hi; a.wo = L.wi; a.co = L.k_ci; a.ldo = L.k_ci;
   a.r = L.k_r; a.s = L.k_s; a.stride = L.stride; a.pad = L.pad;
@@ -576,13 +610,14 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
   return vdqn_conv2d(&a, st);
 }
 
-int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const void* gy, const void* x, int n_units, hipStream_t st) {
+int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const void* gy, const void* x, int n_units, hipStream_t st,
+              bool colsum_kernel = false) {
   vdqn_wgrad_args a;
   memset(&a, 0, sizeof(a));
   a.gy = gy;
   a.x = x;
   a.dw = reinterpret_cast<float*>(bwd + L.dw_off);
-  a.dbias = reinterpret_cast<float*>(bwd + L.db_off);
+  a.dbias = colsum_kernel ? reinterpret_cast<float*>(bwd + L.db_off) : nullptr;  // else: dgrad-epilogue partials
   a.n_img = n_units; a.hi = L.hi; a.wi = L.wi; a.ci = L.k_ci; a.pix_stride = L.pix_stride;
   a.ho = L.ho; a.wo = L.wo; a.co = L.co_pad; a.ldg = L.co_pad;
   a.r = L.k_r; a.s = L.k_s;
@@ -652,6 +687,13 @@ extern "C" int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out) {
     return VDQN_ERR_INVALID;
   }
   *out = net;
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_net_set_overlap(vdqn_net* net, int on) {
+  VDQN_CHECK(net, "vdqn_net_set_overlap: null net");
+  if (net->side) (void)hipStreamSynchronize(net->side);
+  net->overlap = on ? 1 : 0;
   return VDQN_OK;
 }
 
@@ -824,7 +866,7 @@ int block_backward(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayou
   hipStream_t ws = fork_side(net, st);  // g_out is complete on `st`
   RC(run_wgrad(net, c2, bw, g_out, ao + A.h[b], n, ws));
   if (net->l_b_ds[b] >= 0) RC(run_wgrad(net, net->layers[net->l_b_ds[b]], bw, g_out, x, n, ws));
-  RC(run_dgrad(net, c2, pk, g_out, bw + W.g_h[b], n, nullptr, ao + A.h[b], st));
+  RC(run_dgrad(net, c2, pk, g_out, bw + W.g_h[b], n, nullptr, ao + A.h[b], st, bw + W.p_h[b]));
   ws = fork_side(net, st);  // g_h is complete
   RC(run_wgrad(net, c1, bw, bw + W.g_h[b], x, n, ws));
   const void* resid = g_out;  // identity shortcut
@@ -833,7 +875,7 @@ int block_backward(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayou
     RC(run_dgrad(net, ds, pk, g_out, bw + W.dsg[b], n, nullptr, nullptr, st));
     resid = bw + W.dsg[b];
   }
-  RC(run_dgrad(net, c1, pk, bw + W.g_h[b], gx, n, resid, x, st));
+  RC(run_dgrad(net, c1, pk, bw + W.g_h[b], gx, n, resid, x, st, b > 0 ? bw + W.p_o[b - 1] : nullptr));
   return VDQN_OK;
 }
 
@@ -856,14 +898,14 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     const Layer& t2 = net->layers[net->l_top2];
     const Layer& t0 = net->layers[net->l_top0];
     const Layer& f8 = net->layers[net->l_f8];
-    RC(run_wgrad(net, t4, bw, bw + W.dq, ao + A.l1, B, fork_side(net, st)));
-    RC(run_dgrad(net, t4, pk, bw + W.dq, bw + W.g_l1, B, nullptr, ao + A.l1, st));
+    RC(run_wgrad(net, t4, bw, bw + W.dq, ao + A.l1, B, fork_side(net, st), true));
+    RC(run_dgrad(net, t4, pk, bw + W.dq, bw + W.g_l1, B, nullptr, ao + A.l1, st, bw + W.p_l1));
     RC(run_wgrad(net, t2, bw, bw + W.g_l1, ao + A.l0, B, fork_side(net, st)));
-    RC(run_dgrad(net, t2, pk, bw + W.g_l1, bw + W.g_l0, B, nullptr, ao + A.l0, st));
+    RC(run_dgrad(net, t2, pk, bw + W.g_l1, bw + W.g_l0, B, nullptr, ao + A.l0, st, bw + W.p_l0));
     RC(run_wgrad(net, t0, bw, bw + W.g_l0, ao + A.f8, B, fork_side(net, st)));
-    RC(run_dgrad(net, t0, pk, bw + W.g_l0, bw + W.g_f8, B, nullptr, ao + A.f8, st));
+    RC(run_dgrad(net, t0, pk, bw + W.g_l0, bw + W.g_f8, B, nullptr, ao + A.f8, st, bw + W.p_f8));
     RC(run_wgrad(net, f8, bw, bw + W.g_f8, ao + A.o[7], n, fork_side(net, st)));
-    RC(run_dgrad(net, f8, pk, bw + W.g_f8, bw + W.g_o[7], n, nullptr, ao + A.o[7], st));
+    RC(run_dgrad(net, f8, pk, bw + W.g_f8, bw + W.g_o[7], n, nullptr, ao + A.o[7], st, bw + W.p_o[7]));
     RC(block_backward(net, a, 7, A, W, n, st));
     RC(block_backward(net, a, 6, A, W, n, st));
   } else if (stage == 1) {
@@ -872,14 +914,32 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   } else {
     for (int b = 3; b >= 0; --b) RC(block_backward(net, a, b, A, W, n, st));
     RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, ao + A.c1, bw + W.g_c1, n, 112, 112, 64, dt, st));
-    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
+    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st), true));
   }
   join_side(net, st);  // every weight gradient of this stage is complete before it is unfolded
   int max_co = 0;
   for (int i = net->layer_stage_first[stage]; i < net->layer_stage_first[stage] + net->layer_stage_count[stage]; ++i)
     max_co = net->layers[i].co > max_co ? net->layers[i].co : max_co;
   ProfScope ps_("unfold_grads", 0.0, (double)(net->stage_end[stage] - net->stage_begin[stage]) * 12.0, st);
-  hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, st, net->fold, net->layer_stage_first[stage],
+  PartTable pt;
+  memset(&pt, 0, sizeof(pt));
+  {
+    auto tiles = [](int64_t rows) { return (int)((rows + 127) / 128); };
+    auto set = [&](int li, int64_t off, int64_t rows, int ld, int groups, int gstride) {
+      if (li < 0) return;
+      pt.off[li] = off; pt.tiles[li] = tiles(rows); pt.ld[li] = ld; pt.groups[li] = groups; pt.gstride[li] = gstride;
+    };
+    set(net->l_top2, W.p_l1, B, 256, 1, 0);
+    set(net->l_top0, W.p_l0, B, 512, 1, 0);
+    set(net->l_f8, W.p_f8, B, 1600 * F, 25 * F, 64);
+    for (int b = 0; b < 8; ++b) {
+      const int planes = 64 << (b / 2), sp = 56 >> (b / 2);
+      set(net->l_b_conv2[b], W.p_o[b], (int64_t)n * sp * sp, planes, 1, 0);
+      set(net->l_b_ds[b], W.p_o[b], (int64_t)n * sp * sp, planes, 1, 0);
+      set(net->l_b_conv1[b], W.p_h[b], (int64_t)n * sp * sp, planes, 1, 0);
+    }
+  }
+  hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, st, net->fold, pt, net->layer_stage_first[stage],
                      a->params, a->bnstats, (const unsigned char*)bw, a->grads);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;

@@ -37,6 +37,7 @@ struct IgemmParams {
   const void* mask;
   void* out;
   float* out_f32;
+  float* colsum_part;
   int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldo, r, s, stride, pad, relu;
   int M, howo, ktot, nk, tiles_m, tiles_n;
   long long in_bytes;
@@ -266,6 +267,9 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
   constexpr int RPP = 256 / TPR;      // rows per pass
   const int col8 = (tid % TPR) * 8;
   const int n = n0 + col8;
+  float cs[8];  // per-thread column sums of the values this tile stores (for the BN-shift / bias gradient)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
   if (n < p.co) {
     const bool vec = p.vec_ok && (n + 8 <= p.co);
     float bv[8];
@@ -301,7 +305,10 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
         }
         if (out) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(v[e]);
+          for (int e = 0; e < 8; ++e) {
+            ov[e] = from_f32<T>(v[e]);
+            cs[e] += to_f32<T>(ov[e]);
+          }
           if constexpr (ESZ == 2) *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ov);
           else { reinterpret_cast<uint4*>(out + o)[0] = reinterpret_cast<const uint4*>(ov)[0]; reinterpret_cast<uint4*>(out + o)[1] = reinterpret_cast<const uint4*>(ov)[1]; }
         }
@@ -315,10 +322,25 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
           if (resid) x += to_f32<T>(resid[o + e]);
           if (p.relu) x = fmaxf(x, 0.f);
           if (mask) x = (to_f32<T>(mask[o + e]) > 0.f) ? x : 0.f;
-          if (out) out[o + e] = from_f32<T>(x);
+          if (out) {
+            out[o + e] = from_f32<T>(x);
+            cs[e] += to_f32<T>(from_f32<T>(x));
+          }
           if (p.out_f32) p.out_f32[o + e] = x;
         }
       }
+    }
+  }
+  if (p.colsum_part) {  // uniform branch: partial column sums of this 128-row tile -> colsum_part[tile_m][ldo]
+    float* sR = reinterpret_cast<float*>(smem + BM * LDC * 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sR[(tid / TPR) * BN + col8 + e] = cs[e];
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.co) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPP; ++r) t += sR[r * BN + tid];
+      p.colsum_part[(size_t)tile_m * p.ldo + n0 + tid] = t;
     }
   }
 }
@@ -326,7 +348,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
 template <typename T, int BN, int MODE>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   constexpr int NSTAGE = VDQN_IGEMM_STAGES;
-  const size_t main_bytes = NSTAGE * (128 + BN) * 128, epi_bytes = 128 * (BN + 4) * 4;
+  const size_t main_bytes = NSTAGE * (128 + BN) * 128, epi_bytes = 128 * (BN + 4) * 4 + 256 * 8 * 4;
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   static bool attr_set = false;
   if (!attr_set) {
@@ -367,7 +389,7 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   VDQN_CHECK((int64_t)a->n_img * a->ho * a->wo < (1ll << 31), "vdqn_conv2d: too many output pixels");
   VDQN_CHECK((a->pix_stride * esz) % 16 == 0 && (((uintptr_t)a->in | (uintptr_t)a->wt) & 15) == 0, "vdqn_conv2d: in/wt must be 16-byte aligned");
   IgemmParams p;
-  p.in = a->in; p.wt = a->wt; p.bias = a->bias; p.resid = a->resid; p.mask = a->mask; p.out = a->out; p.out_f32 = a->out_f32;
+  p.in = a->in; p.wt = a->wt; p.bias = a->bias; p.resid = a->resid; p.mask = a->mask; p.out = a->out; p.out_f32 = a->out_f32; p.colsum_part = a->colsum_part;
   p.n_img = a->n_img; p.hi = a->hi; p.wi = a->wi; p.ci = a->ci; p.pix_stride = a->pix_stride;
   p.ho = a->ho; p.wo = a->wo; p.co = a->co; p.ldo = a->ldo; p.r = a->r; p.s = a->s; p.stride = a->stride; p.pad = a->pad;
   p.relu = a->relu;

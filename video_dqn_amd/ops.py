@@ -25,7 +25,7 @@ def dtype_code(t: torch.Tensor) -> int:
 def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: int, s: int, stride: int, pad: int,
            bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
            relu: bool = False, mode: int = 0, pix_stride: Optional[int] = None, ci: Optional[int] = None,
-           want_f32: bool = False, ldo: Optional[int] = None):
+           want_f32: bool = False, ldo: Optional[int] = None, want_colsum: bool = False):
     """x: [n, hi, wi, c] NHWC; wt: [co_pad, r, s, ci].  Returns out [n, ho, wo, ldo] (and the f32 copy)."""
     lib = _lib.load()
     require_gpu()
@@ -37,12 +37,15 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
     out_f32 = torch.empty((n, ho, wo, ldo), dtype=torch.float32, device=x.device) if want_f32 else None
     a = _lib.ConvArgs()
     a.in_, a.wt, a.bias, a.resid, a.mask = _ptr(x), _ptr(wt), _ptr(bias), _ptr(resid), _ptr(mask)
-    a.out, a.out_f32 = _ptr(out), _ptr(out_f32)
+    part = torch.empty(((n * ho * wo + 127) // 128, ldo), dtype=torch.float32, device=x.device) if want_colsum else None
+    a.out, a.out_f32, a.colsum_part = _ptr(out), _ptr(out_f32), _ptr(part)
     a.n_img, a.hi, a.wi, a.ci, a.pix_stride = n, hi, wi, ci, pix_stride
     a.ho, a.wo, a.co, a.ldo = ho, wo, co, ldo
     a.r, a.s, a.stride, a.pad = r, s, stride, pad
     a.mode, a.relu, a.dtype = mode, int(relu), dtype_code(x)
     _lib.check(lib.vdqn_conv2d(C.byref(a), _stream()), "vdqn_conv2d")
+    if want_colsum:
+        return out, part
     return (out, out_f32) if want_f32 else out
 
 
