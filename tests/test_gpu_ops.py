@@ -49,6 +49,8 @@ CONV_CASES = [
     (2, 256, 512, 7, 3, 2, 1),
     (3, 512, 64, 7, 3, 1, 0),
     (1, 128, 256, 28, 3, 2, 1),
+    (3, 64, 64, 24, 3, 1, 1),   # halo-tile kernel (igemm_halo.hip): 27 8x8 sub-tiles -> a partial last block
+    (2, 64, 64, 56, 3, 1, 1),   # layer1 geometry
 ]
 
 
