@@ -81,6 +81,20 @@ def cpu_baseline(batch: int, budget_s: float = 25.0):
             "multi_threads": threads, "host_cores_visible": avail}
 
 
+def pmc_traffic(kernel: str, batch: int, frames: int, dtype: str):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_latest.json: rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes).
+    PMC collection cannot run inside this process; the figure is only quoted for the configuration it was
+    collected on (batch 256, 1 frame, bf16), otherwise null."""
+    if (batch, frames, dtype) != (256, 1, "bf16"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f)["per_launch"][kernel]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,9 +184,10 @@ def main():
         if v["flops"] > 0:
             ach = v["flops"] / v["ms"] / 1e9
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None,
+                        "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B, F, args.dtype),
                         "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
                         "alg_flops_per_launch": round(v["flops"] / v["launches"]),
+                        "alg_bytes_per_launch": round(v["bytes"] / v["launches"]),
                         "measured": f"HIP events around every launch, {args.profile_steps} steps right after the timed region, side-stream overlap off"}
         else:
             ach = v["bytes"] / v["ms"] / 1e6

@@ -357,7 +357,12 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   }
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
   const double esz = sizeof(T);
-  vdqn_prof_begin(sizeof(T) == 2 ? (BN == 128 ? "igemm<bf16,128>" : "igemm<bf16,64>") : (BN == 128 ? "igemm<f32,128>" : "igemm<f32,64>"),
+  // one tag per kernel symbol (T, BN, MODE), so bench.py rows line up with rocprofv3's kernel names
+  static const char* const kTag[2][2][3] = {{{"igemm<bf16,64,fwd>", "igemm<bf16,64,dgrad>", "igemm<bf16,64,dgrad_s2>"},
+                                             {"igemm<bf16,128,fwd>", "igemm<bf16,128,dgrad>", "igemm<bf16,128,dgrad_s2>"}},
+                                            {{"igemm<f32,64,fwd>", "igemm<f32,64,dgrad>", "igemm<f32,64,dgrad_s2>"},
+                                             {"igemm<f32,128,fwd>", "igemm<f32,128,dgrad>", "igemm<f32,128,dgrad_s2>"}}};
+  vdqn_prof_begin(kTag[sizeof(T) == 2 ? 0 : 1][BN == 128 ? 1 : 0][MODE],
                   2.0 * p.M * p.co * p.ktot,
                   esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
                   stream);
