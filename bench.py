@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=1, help="views per sample (12 = BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--target-update-interval", type=int, default=1000)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="skip the event-profiled steps (roofline = null)")
@@ -105,12 +106,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("VDQN_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0  # functional test of the N > 1 path on a 1-GPU box (use --backend gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if args.backend == "nccl" else {}))
 
     from video_dqn_amd import _lib, synth
     from video_dqn_amd.engine import NetEngine, TDStepper
@@ -158,21 +161,24 @@ def main():
     # ---- live per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel ----
     roofline = None
     kernels = None
-    if not args.no_profile and rank == 0:
+    if not args.no_profile:
         # per-kernel roofline timing: serialise the engine's side stream so every kernel has the chip to itself
-        # (in the timed region above weight gradients / the target forward overlap the main chain)
+        # (in the timed region above weight gradients / the target forward overlap the main chain).  Every rank
+        # runs these steps (they contain the gradient all-reduce); only rank 0 records and reports.
         net.lib.vdqn_net_set_overlap(net.handle, 0)
         torch.cuda.synchronize()
-        _lib.profile_enable(True)
+        if rank == 0:
+            _lib.profile_enable(True)
         for _ in range(args.profile_steps):
             stp.forward_backward(before, after, 0, act, rew, term)
             if comm:
                 comm.finish()
             stp.optimizer_step()
         torch.cuda.synchronize()
+        net.lib.vdqn_net_set_overlap(net.handle, 1)
+    if not args.no_profile and rank == 0:
         prof = _lib.profile_collect()
         _lib.profile_enable(False)
-        net.lib.vdqn_net_set_overlap(net.handle, 1)
         tot_ms = sum(v["ms"] for v in prof.values())
         kernels = {k: {"launches_per_step": v["launches"] // args.profile_steps, "ms_per_step": round(v["ms"] / args.profile_steps, 4),
                        "share": round(v["ms"] / tot_ms, 4),
