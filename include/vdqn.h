@@ -112,7 +112,9 @@ int vdqn_pack_input(const void* src, int32_t src_kind, void* dst, int32_t n_img,
  * the arg-max tap (kh*3+kw, first maximum wins as in torch). */
 int vdqn_maxpool_fwd(const void* in, void* out, uint8_t* idx, int32_t n_img, int32_t hi, int32_t wi, int32_t c,
                      int32_t dtype, void* stream);
-/* gx[n,h,w,c] = (x[n,h,w,c] > 0) * sum over windows whose arg-max is (h,w) of gy  (pool + ReLU backward) */
+/* gx[n,h,w,c] = (x[n,h,w,c] > 0) * sum over windows whose arg-max is (h,w) of gy  (pool + ReLU backward).
+ * x may be NULL when gy is already zero wherever the pooled value is <= 0 (the engine's case: the producing dgrad
+ * masks with the pooled activation; the arg-max of a window holds exactly that value), which saves the read of x. */
 int vdqn_maxpool_bwd(const void* gy, const uint8_t* idx, const void* x, void* gx, int32_t n_img, int32_t hi,
                      int32_t wi, int32_t c, int32_t dtype, void* stream);
 

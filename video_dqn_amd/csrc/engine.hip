@@ -913,7 +913,8 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     RC(block_backward(net, a, 4, A, W, n, st));
   } else {
     for (int b = 3; b >= 0; --b) RC(block_backward(net, a, b, A, W, n, st));
-    RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, ao + A.c1, bw + W.g_c1, n, 112, 112, 64, dt, st));
+    // g_pool is already masked by (pool > 0) in block 0's dgrad epilogue and c1[argmax] == pool, so the ReLU mask of c1 is implied
+    RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
     RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st), true));
   }
   join_side(net, st);  // every weight gradient of this stage is complete before it is unfolded

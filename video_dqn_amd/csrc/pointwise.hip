@@ -146,11 +146,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
           if (iv[e] == tap) s[e] += to_f32<T>(pg[e]);
       }
     const size_t xo = (((size_t)n * hi + h) * wi + w) * c + cg * E16;
-    const uint4 xv = *reinterpret_cast<const uint4*>(x + xo);
-    const T* px = reinterpret_cast<const T*>(&xv);
     T ov[E16];
+    if (x) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(x + xo);
+      const T* px = reinterpret_cast<const T*>(&xv);
 #pragma unroll
-    for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(to_f32<T>(px[e]) > 0.f ? s[e] : 0.f);
+      for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(to_f32<T>(px[e]) > 0.f ? s[e] : 0.f);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(s[e]);
+    }
     *reinterpret_cast<uint4*>(gx + xo) = *reinterpret_cast<const uint4*>(ov);
   }
 }
@@ -321,12 +326,12 @@ extern "C" int vdqn_maxpool_fwd(const void* in, void* out, uint8_t* idx, int32_t
 
 extern "C" int vdqn_maxpool_bwd(const void* gy, const uint8_t* idx, const void* x, void* gx, int32_t n_img, int32_t hi, int32_t wi,
                                 int32_t c, int32_t dtype, void* stream) {
-  VDQN_CHECK(gy && idx && x && gx && n_img > 0, "vdqn_maxpool_bwd: bad args");
+  VDQN_CHECK(gy && idx && gx && n_img > 0, "vdqn_maxpool_bwd: bad args");
   VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_maxpool_bwd: bad dtype");
   VDQN_CHECK(c % 8 == 0, "vdqn_maxpool_bwd: channels must be a multiple of 8");
   const int e16 = dtype == VDQN_BF16 ? 8 : 4;
   const int g = grid_for((long)n_img * hi * wi * (c / e16), 65536);
-  ProfScope ps_("maxpool_bwd", 0.0, (double)n_img * c * (2.0 * hi * wi * (16 / e16) + (double)(hi / 2) * (wi / 2) * (16 / e16 + 1)), (hipStream_t)stream);
+  ProfScope ps_("maxpool_bwd", 0.0, (double)n_img * c * ((x ? 2.0 : 1.0) * hi * wi * (16 / e16) + (double)(hi / 2) * (wi / 2) * (16 / e16 + 1)), (hipStream_t)stream);
   if (dtype == VDQN_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)gy, idx, (const bf16raw*)x, (bf16raw*)gx, n_img, hi, wi, c);
   else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)gy, idx, (const float*)x, (float*)gx, n_img, hi, wi, c);
   VDQN_LAUNCH_CHECK();
