@@ -73,7 +73,8 @@ typedef struct vdqn_conv_args {
   const void* mask;    /* [m][ldo] or NULL */
   void* out;           /* [m][ldo], dtype; may be NULL if out_f32 is given */
   float* out_f32;      /* optional f32 copy of the result [m][ldo] */
-  float* colsum_part;  /* optional [ceil(m/128)][ldo] f32: per 128-row tile, column sums of the stored `out` values
+  float* colsum_part;  /* optional [T][ldo] f32, T = ceil(m/128) (stride-2 dgrad: 4*ceil(m/4/128), one run of tiles per output
+                          parity class): per 128-row tile, column sums of the stored `out` values
                           (summed over tiles they are the bias / BatchNorm-shift gradient of the layer that `out`
                           is the output-gradient of) */
   int32_t n_img, hi, wi, ci, pix_stride;

@@ -79,7 +79,7 @@ struct ActLayout {
 struct BwdLayout {
   int64_t zero_begin, zero_bytes;  // region cleared every step: dW', dbias', loss scratch
   int64_t dq, g_l1, g_l0, g_f8, g_o[8], g_h[8], dsg[8], g_pool, g_c1;
-  int64_t p_l1, p_l0, p_f8, p_o[8], p_h[8];  // per-128-row-tile column sums written by the dgrad epilogues
+  int64_t p_l1, p_l0, p_f8, p_o[8], p_h[8], p_pool;  // per-128-row-tile column sums written by the dgrad epilogues
   int64_t total;
 };
 
@@ -557,9 +557,10 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
   L.p_l1 = take(tiles(n_samples) * 256 * 4);
   L.p_l0 = take(tiles(n_samples) * 512 * 4);
   L.p_f8 = take(tiles(n_samples) * 1600 * F * 4);
+  L.p_pool = take(tiles(n * 56 * 56) * 64 * 4);
   for (int b = 0; b < 8; ++b) {
     const int64_t planes = 64 << (b / 2), sp = 56 >> (b / 2);
-    L.p_o[b] = take(tiles(n * sp * sp) * planes * 4);
+    L.p_o[b] = take((tiles(n * sp * sp) + 4) * planes * 4);  // +4: stride-2 dgrad rounds tiles per parity class
     L.p_h[b] = take(tiles(n * sp * sp) * planes * 4);
   }
   L.total = off;
@@ -875,7 +876,7 @@ int block_backward(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayou
     RC(run_dgrad(net, ds, pk, g_out, bw + W.dsg[b], n, nullptr, nullptr, st));
     resid = bw + W.dsg[b];
   }
-  RC(run_dgrad(net, c1, pk, bw + W.g_h[b], gx, n, resid, x, st, b > 0 ? bw + W.p_o[b - 1] : nullptr));
+  RC(run_dgrad(net, c1, pk, bw + W.g_h[b], gx, n, resid, x, st, b > 0 ? bw + W.p_o[b - 1] : bw + W.p_pool));
   return VDQN_OK;
 }
 
@@ -915,7 +916,9 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     for (int b = 3; b >= 0; --b) RC(block_backward(net, a, b, A, W, n, st));
     // g_pool is already masked by (pool > 0) in block 0's dgrad epilogue and c1[argmax] == pool, so the ReLU mask of c1 is implied
     RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
-    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st), true));
+    // bn1's shift gradient = column sums of g_c1 = column sums of g_pool (max-pool routes every pooled gradient element
+    // to exactly one input position), which block 0's dgrad epilogue already produced as partials
+    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
   }
   join_side(net, st);  // every weight gradient of this stage is complete before it is unfolded
   int max_co = 0;
@@ -933,10 +936,16 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     set(net->l_top2, W.p_l1, B, 256, 1, 0);
     set(net->l_top0, W.p_l0, B, 512, 1, 0);
     set(net->l_f8, W.p_f8, B, 1600 * F, 25 * F, 64);
+    set(net->l_conv1, W.p_pool, (int64_t)n * 56 * 56, 64, 1, 0);
     for (int b = 0; b < 8; ++b) {
       const int planes = 64 << (b / 2), sp = 56 >> (b / 2);
       set(net->l_b_conv2[b], W.p_o[b], (int64_t)n * sp * sp, planes, 1, 0);
       set(net->l_b_ds[b], W.p_o[b], (int64_t)n * sp * sp, planes, 1, 0);
+      if (b + 1 < 8 && net->l_b_ds[b + 1] >= 0) {  // g_o[b] comes from a stride-2 dgrad: 4 parity classes of tiles
+        const int t4 = 4 * tiles((int64_t)n * sp * sp / 4);
+        pt.tiles[net->l_b_conv2[b]] = t4;
+        if (net->l_b_ds[b] >= 0) pt.tiles[net->l_b_ds[b]] = t4;
+      }
       set(net->l_b_conv1[b], W.p_h[b], (int64_t)n * sp * sp, planes, 1, 0);
     }
   }

@@ -40,6 +40,7 @@ struct IgemmParams {
   float* colsum_part;
   int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldo, r, s, stride, pad, relu;
   int M, howo, ktot, nk, tiles_m, tiles_n;
+  int cls_tile0[5], cls_h[2], cls_w[2];  // MODE 2: first tile of each output-parity class; class heights / widths
   long long in_bytes;
   int wt_bytes;
   int vec_ok;
@@ -65,14 +66,32 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
   const int lane = tid & 63, wave = tid >> 6;
   const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = (int)(lb % (uint32_t)p.tiles_n), tile_m = (int)(lb / (uint32_t)p.tiles_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int n0 = tile_n * BN;
+  // MODE 2 (stride-2 data gradient): an output pixel (oh, ow) only receives the taps with kr = oh + pad (mod 2) and
+  // ks = ow + pad (mod 2).  Rows are therefore enumerated parity class by parity class ((oh & 1, ow & 1): 4 classes
+  // of Ho/2 x Wo/2 pixels, tiles never straddle classes) and each tile walks only ITS taps: 9 tap-classes in total
+  // instead of 4 x 9 with three quarters of the A rows zero.
+  int m0 = tile_m * BM, nk = p.nk, kr0 = 0, ks0 = 0, cls_ph = 0, cls_pw = 0;
+  if constexpr (MODE == 2) {
+    const int cls = (tile_m >= p.cls_tile0[1]) + (tile_m >= p.cls_tile0[2]) + (tile_m >= p.cls_tile0[3]);
+    m0 = (tile_m - p.cls_tile0[cls]) * BM;  // first row inside the class
+    cls_ph = cls >> 1;
+    cls_pw = cls & 1;
+    kr0 = (cls_ph + p.pad) & 1;
+    ks0 = (cls_pw + p.pad) & 1;
+    const int nkr = p.r > kr0 ? (p.r - kr0 + 1) / 2 : 0, nks = p.s > ks0 ? (p.s - ks0 + 1) / 2 : 0;
+    nk = nkr * nks * (p.ci / KC);
+  }
+  const int row_w = MODE == 2 ? p.cls_w[cls_pw] : p.wo;
+  const int pix_per_img = MODE == 2 ? p.cls_h[cls_ph] * row_w : p.howo;
+  const int rows_total = MODE == 2 ? p.n_img * pix_per_img : p.M;
   const int lrow = tid >> 3;                        // tile row this thread stages (+32 i)
   const int lchunk = (tid & 7) ^ (lrow & 7);        // logical 16-byte chunk it fetches (source-side swizzle)
 
   // ---- buffer descriptors (4 SGPRs each): A relative to the first image of this tile, B = whole weight tensor.
   // The DMA is issued from inline asm: hipcc would otherwise wait vmcnt(0) before the first ds_read that follows
   // a pending LDS-DMA (it cannot prove the buffers distinct), which serialises the copy behind the MFMAs.
-  const int img0 = m0 / p.howo;
+  const int img0 = m0 / pix_per_img;
   const long long img_bytes = (long long)p.hi * p.wi * p.pix_stride * ESZ;
   const long long a_base_off = (long long)img0 * img_bytes;
   long long a_rem = p.in_bytes - a_base_off;
@@ -91,12 +110,16 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + lrow + 32 * i;
-    const bool ok = m < p.M;
+    const bool ok = m < rows_total;
     const int mm = ok ? m : m0;
-    const int img = mm / p.howo;
-    const int rem = mm - img * p.howo;
-    const int oh = rem / p.wo;
-    const int ow = rem - oh * p.wo;
+    const int img = mm / pix_per_img;
+    const int rem = mm - img * pix_per_img;
+    int oh = rem / row_w;
+    int ow = rem - oh * row_w;
+    if constexpr (MODE == 2) {
+      oh = 2 * oh + cls_ph;
+      ow = 2 * ow + cls_pw;
+    }
     int hb, wb, hq, wq;
     if (MODE == 0) {
       hb = oh * p.stride - p.pad;
@@ -136,7 +159,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
         ok_ = ((unsigned)(a_hb[i_] - (KR)) < (unsigned)p.hi) && ((unsigned)(a_wb[i_] - (KS)) < (unsigned)p.wi);     \
       } else {                                                                                                      \
         const int th_ = a_hb[i_] - (KR), tw_ = a_wb[i_] - (KS);                                                     \
-        ok_ = (((th_ | tw_) & 1) == 0) && ((unsigned)(th_ >> 1) < (unsigned)p.hi) && ((unsigned)(tw_ >> 1) < (unsigned)p.wi); \
+        ok_ = ((unsigned)(th_ >> 1) < (unsigned)p.hi) && ((unsigned)(tw_ >> 1) < (unsigned)p.wi); /* parity holds by class */ \
       }                                                                                                             \
       vo_[i_] = ok_ ? a_off[i_] + (uint32_t)delta_ : kOob;                                                          \
     }                                                                                                               \
@@ -169,17 +192,20 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
           : "memory", "scc");                                                                                       \
     }                                                                                                               \
   }
-#define VDQN_ADVANCE()       \
-  {                          \
-    ic0 += KC;               \
-    if (ic0 >= p.ci) {       \
-      ic0 = 0;               \
-      if (++iks == p.s) {    \
-        iks = 0;             \
-        ++ikr;               \
-      }                      \
-    }                        \
+#define VDQN_ADVANCE()                 \
+  {                                    \
+    ic0 += KC;                         \
+    if (ic0 >= p.ci) {                 \
+      ic0 = 0;                         \
+      iks += (MODE == 2 ? 2 : 1);      \
+      if (iks >= p.s) {                \
+        iks = ks0;                     \
+        ikr += (MODE == 2 ? 2 : 1);    \
+      }                                \
+    }                                  \
   }
+  // index of a K-step inside a weight row ([r][s][ci], 128-byte steps)
+#define VDQN_WSTEP() (MODE == 2 ? ((ikr * p.s + iks) * (p.ci / KC) + ic0 / KC) : issued)
 
   f32x4 acc[4][NF];
 #pragma unroll
@@ -192,18 +218,18 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
   const int sw = i16 & 7;
 
   // ---- main loop: K-steps enumerate (r, s, c0) with c0 fastest; NSTAGE LDS buffers, NSTAGE-1 tiles in flight ----
-  int ikr = 0, iks = 0, ic0 = 0;  // coordinates of the next K-step to issue
+  int ikr = kr0, iks = ks0, ic0 = 0;  // coordinates of the next K-step to issue
   int issued = 0;
 #pragma unroll
   for (int s_ = 0; s_ < NSTAGE - 1; ++s_) {
-    if (issued < p.nk) {
-      VDQN_ISSUE(s_, ikr, iks, ic0, issued)
+    if (issued < nk) {
+      VDQN_ISSUE(s_, ikr, iks, ic0, VDQN_WSTEP())
       VDQN_ADVANCE()
       ++issued;
     }
   }
   int buf = 0, ibuf = NSTAGE - 1;
-  for (int k = 0; k < p.nk; ++k) {
+  for (int k = 0; k < nk; ++k) {
     // tile k has landed once at most (issued - k - 1) younger tiles are still outstanding
     if (NSTAGE == 3 && issued - k - 1 >= 1) {
       if constexpr (BROWS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -212,8 +238,8 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // every wave's pieces of tile k are visible; every wave is done with tile k-1
-    if (issued < p.nk) {
-      VDQN_ISSUE(ibuf, ikr, iks, ic0, issued)
+    if (issued < nk) {
+      VDQN_ISSUE(ibuf, ikr, iks, ic0, VDQN_WSTEP())
       VDQN_ADVANCE()
       ++issued;
     }
@@ -248,6 +274,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
   __syncthreads();  // all waves done reading LDS before the epilogue reuses it
 #undef VDQN_ISSUE
 #undef VDQN_ADVANCE
+#undef VDQN_WSTEP
 
   // ---- epilogue: accumulators -> LDS f32 tile (C layout: col = lane & 15, row = (lane >> 4) * 4 + reg) ----
   float* sC = reinterpret_cast<float*>(smem);
@@ -277,8 +304,14 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
     for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.co) ? p.bias[n + e] : 0.f;
 #pragma unroll 2
     for (int r0 = tid / TPR; r0 < BM; r0 += RPP) {
-      const int m = m0 + r0;
-      if (m >= p.M) break;
+      int m = m0 + r0;
+      if (m >= rows_total) break;
+      if constexpr (MODE == 2) {  // class-local row -> output pixel
+        const int img = m / pix_per_img;
+        const int rem = m - img * pix_per_img;
+        const int ohc = rem / row_w;
+        m = (img * p.ho + 2 * ohc + cls_ph) * p.wo + 2 * (rem - ohc * row_w) + cls_pw;
+      }
       const size_t o = (size_t)m * p.ldo + n;
       float v[8];
       const float4 c0v = *reinterpret_cast<const float4*>(sC + r0 * LDC + col8);
@@ -404,6 +437,14 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   p.nk = p.ktot / kc;
   const int bn = (a->co % 128 == 0) ? 128 : 64;
   p.tiles_m = (p.M + 127) / 128;
+  memset(p.cls_tile0, 0, sizeof(p.cls_tile0));
+  p.cls_h[0] = p.cls_h[1] = p.cls_w[0] = p.cls_w[1] = 0;
+  if (a->mode == 1 && a->stride == 2) {  // tiles are laid out parity class by parity class (see the kernel)
+    p.cls_h[0] = (a->ho + 1) / 2; p.cls_h[1] = a->ho / 2;
+    p.cls_w[0] = (a->wo + 1) / 2; p.cls_w[1] = a->wo / 2;
+    for (int c = 0; c < 4; ++c) p.cls_tile0[c + 1] = p.cls_tile0[c] + (a->n_img * p.cls_h[c >> 1] * p.cls_w[c & 1] + 127) / 128;
+    p.tiles_m = p.cls_tile0[4];
+  }
   p.tiles_n = (a->co + bn - 1) / bn;
   p.in_bytes = (long long)a->n_img * a->hi * a->wi * a->pix_stride * esz;
   const long long wtb = (long long)p.tiles_n * bn * p.ktot * esz;
