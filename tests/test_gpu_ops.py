@@ -49,7 +49,7 @@ CONV_CASES = [
     (2, 256, 512, 7, 3, 2, 1),
     (3, 512, 64, 7, 3, 1, 0),
     (1, 128, 256, 28, 3, 2, 1),
-    (3, 64, 64, 24, 3, 1, 1),   # halo-tile kernel (igemm_halo.hip): 27 8x8 sub-tiles -> a partial last block
+    (3, 64, 64, 24, 3, 1, 1),   # 64-column layer, M not a multiple of the tile
     (2, 64, 64, 56, 3, 1, 1),   # layer1 geometry
 ]
 
@@ -266,3 +266,17 @@ def test_adam_matches_torch():
         assert (d_got - d_ref).abs().max().item() < 2e-3 * 1e-4 * step  # 0.2 % of one lr-sized step
         st = opt.state[pt]
         assert relerr(m, st["exp_avg"]) < 1e-6 and relerr(v, st["exp_avg_sq"]) < 1e-6
+
+
+def test_conv_256_row_tile_variant():
+    """The 256x64-tile / 8-wave igemm variant is only selected for >= 256 Ki output rows; re-run the 64-column conv
+    cases in a child process with the threshold lowered so it is covered at test sizes."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VDQN_BM256_MIN_ROWS="256")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "(conv_forward or conv_dgrad or stem or linear) and not variant"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -19,6 +19,8 @@
 //
 // Reference call sites this serves: the torch conv2d/linear (+BatchNorm eval, ReLU, residual) launched
 // from archs/HabitatDQNMultiAction.py:30-31,49-53 and their backward (train_q_network.py:226).
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifndef VDQN_IGEMM_STAGES
@@ -50,13 +52,16 @@ constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (
 
 // MODE 0: forward gather (h = oh*stride - pad + kr); 1: dgrad, stride 1 (h = oh + pad - kr);
 //      2: dgrad, stride 2 (h = (oh + pad - kr) / 2 when even)
-template <typename T, int BN, int MODE, int NSTAGE>
-__global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_kernel(const IgemmParams p) {
-  constexpr int BM = 128;
+template <typename T, int BM, int BN, int MODE, int NSTAGE>
+__global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_kernel(const IgemmParams p) {
+  constexpr int NT = 2 * BM;    // threads: BM/64 x 2 waves, each owning 64 x BN/2 (BM = 256 is used for the 64-column
+                                // layers: 16 waves per CU and half the weight traffic per MFMA)
+  constexpr int RPS = NT / 8;   // tile rows staged per pass (8 lanes x 16 B per 128-byte row)
   constexpr int ESZ = (int)sizeof(T);
   constexpr int KC = 128 / ESZ;
   constexpr int NF = BN / 32;
-  constexpr int BROWS = BN / 32;
+  constexpr int BROWS = BN / RPS;
+  constexpr int PSTR = RPS * 128;  // LDS byte distance between a thread's consecutive DMA pieces
   constexpr int LDC = BN + 4;  // f32 row stride of the epilogue tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
   const int pixB = p.pix_stride * ESZ;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + lrow + 32 * i;
+    const int m = m0 + lrow + RPS * i;
     const bool ok = m < rows_total;
     const int mm = ok ? m : m0;
     const int img = mm / pix_per_img;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
   }
   uint32_t b_off[BROWS];
 #pragma unroll
-  for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + 32 * i) * (uint32_t)(p.ktot * ESZ) + (uint32_t)(lchunk * 16);
+  for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + RPS * i) * (uint32_t)(p.ktot * ESZ) + (uint32_t)(lchunk * 16);
 
   // LDS byte addresses (wave-uniform) of this wave's DMA pieces: piece i of an operand covers tile rows 32 i + 8 wave .. +7
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -167,10 +172,10 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
     asm volatile(                                                                                                   \
         "s_nop 4\n\t"                                                                                               \
         "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, 0 offen lds\n\t"                               \
-        "s_add_u32 m0, %4, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"                       \
-        "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"                       \
-        "s_add_u32 m0, %4, 0x3000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds"                            \
-        ::"v"(vo_[0]), "v"(vo_[1]), "v"(vo_[2]), "v"(vo_[3]), "s"(la_), "s"(rs_a)                                   \
+        "s_add_u32 m0, %4, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"                           \
+        "s_add_u32 m0, %4, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"                           \
+        "s_add_u32 m0, %4, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds"                                \
+        ::"v"(vo_[0]), "v"(vo_[1]), "v"(vo_[2]), "v"(vo_[3]), "s"(la_), "s"(rs_a), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
         : "memory", "scc");                                                                                         \
     const uint32_t lb_ = lds_wave + (uint32_t)(NSTAGE * BM * 128) + (uint32_t)(BUF) * (BN * 128);                   \
     const int so_ = (KSTEP)*128;                                                                                    \
@@ -178,18 +183,23 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
       asm volatile(                                                                                                 \
           "s_nop 4\n\t"                                                                                             \
           "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, %6 offen lds\n\t"                            \
-          "s_add_u32 m0, %4, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"                    \
-          "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"                    \
-          "s_add_u32 m0, %4, 0x3000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                         \
-          ::"v"(b_off[0]), "v"(b_off[1]), "v"(b_off[BROWS > 2 ? 2 : 0]), "v"(b_off[BROWS > 2 ? 3 : 0]), "s"(lb_), "s"(rs_b), "s"(so_) \
+          "s_add_u32 m0, %4, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"                        \
+          "s_add_u32 m0, %4, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"                        \
+          "s_add_u32 m0, %4, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                             \
+          ::"v"(b_off[0]), "v"(b_off[BROWS > 1 ? 1 : 0]), "v"(b_off[BROWS > 2 ? 2 : 0]), "v"(b_off[BROWS > 2 ? 3 : 0]), "s"(lb_),    \
+          "s"(rs_b), "s"(so_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR)                                              \
           : "memory", "scc");                                                                                       \
-    } else {                                                                                                        \
+    } else if constexpr (BROWS == 2) {                                                                              \
       asm volatile(                                                                                                 \
           "s_nop 4\n\t"                                                                                             \
           "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %4 offen lds\n\t"                            \
-          "s_add_u32 m0, %2, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds"                         \
-          ::"v"(b_off[0]), "v"(b_off[1]), "s"(lb_), "s"(rs_b), "s"(so_)                                             \
+          "s_add_u32 m0, %2, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds"                             \
+          ::"v"(b_off[0]), "v"(b_off[BROWS > 1 ? 1 : 0]), "s"(lb_), "s"(rs_b), "s"(so_), "n"(PSTR)                  \
           : "memory", "scc");                                                                                       \
+    } else {                                                                                                        \
+      asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"             \
+                   ::"v"(b_off[0]), "s"(lb_), "s"(rs_b), "s"(so_)                                                   \
+                   : "memory");                                                                                     \
     }                                                                                                               \
   }
 #define VDQN_ADVANCE()                 \
@@ -233,7 +243,8 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
     // tile k has landed once at most (issued - k - 1) younger tiles are still outstanding
     if (NSTAGE == 3 && issued - k - 1 >= 1) {
       if constexpr (BROWS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (BROWS == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
   const T* __restrict__ resid = (const T*)p.resid;
   const T* __restrict__ mask = (const T*)p.mask;
   constexpr int TPR = BN / 8;         // threads per tile row (8 columns each)
-  constexpr int RPP = 256 / TPR;      // rows per pass
+  constexpr int RPP = NT / TPR;       // rows per pass
   const int col8 = (tid % TPR) * 8;
   const int n = n0 + col8;
   float cs[8];  // per-thread column sums of the values this tile stores (for the BN-shift / bias gradient)
@@ -364,8 +375,9 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
       }
     }
   }
-  if (p.colsum_part) {  // uniform branch: partial column sums of this 128-row tile -> colsum_part[tile_m][ldo]
-    float* sR = reinterpret_cast<float*>(smem + BM * LDC * 4);
+  if (p.colsum_part) {  // uniform branch: partial column sums of this tile -> colsum_part[tile_m][ldo]
+    __syncthreads();    // everyone has read the staging tile: reuse its head for the reduction
+    float* sR = sC;
 #pragma unroll
     for (int e = 0; e < 8; ++e) sR[(tid / TPR) * BN + col8 + e] = cs[e];
     __syncthreads();
@@ -373,43 +385,51 @@ __global__ __launch_bounds__(256, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_k
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < RPP; ++r) t += sR[r * BN + tid];
-      p.colsum_part[(size_t)tile_m * p.ldo + n0 + tid] = t;
+      if constexpr (BM == 256) {  // consumers sum ceil(M/128) entries: this tile covers two of them
+        p.colsum_part[(size_t)(2 * tile_m) * p.ldo + n0 + tid] = t;
+        if ((2 * tile_m + 1) * 128 < p.M) p.colsum_part[(size_t)(2 * tile_m + 1) * p.ldo + n0 + tid] = 0.f;
+      } else {
+        p.colsum_part[(size_t)tile_m * p.ldo + n0 + tid] = t;
+      }
     }
   }
 }
 
-template <typename T, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   constexpr int NSTAGE = VDQN_IGEMM_STAGES;
-  const size_t main_bytes = NSTAGE * (128 + BN) * 128, epi_bytes = 128 * (BN + 4) * 4 + 256 * 8 * 4;
+  const size_t main_bytes = NSTAGE * (BM + BN) * 128, epi_bytes = BM * (BN + 4) * 4;
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BN, MODE, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, MODE, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
   const double esz = sizeof(T);
-  // one tag per kernel symbol (T, BN, MODE), so bench.py rows line up with rocprofv3's kernel names
-  static const char* const kTag[2][2][3] = {{{"igemm<bf16,64,fwd>", "igemm<bf16,64,dgrad>", "igemm<bf16,64,dgrad_s2>"},
-                                             {"igemm<bf16,128,fwd>", "igemm<bf16,128,dgrad>", "igemm<bf16,128,dgrad_s2>"}},
+  // one tag per kernel symbol (T, BM, BN, MODE), so bench.py rows line up with rocprofv3's kernel names
+  static const char* const kTag[2][3][3] = {{{"igemm<bf16,64,fwd>", "igemm<bf16,64,dgrad>", "igemm<bf16,64,dgrad_s2>"},
+                                             {"igemm<bf16,128,fwd>", "igemm<bf16,128,dgrad>", "igemm<bf16,128,dgrad_s2>"},
+                                             {"igemm<bf16,256x64,fwd>", "igemm<bf16,256x64,dgrad>", "igemm<bf16,256x64,dgrad_s2>"}},
                                             {{"igemm<f32,64,fwd>", "igemm<f32,64,dgrad>", "igemm<f32,64,dgrad_s2>"},
-                                             {"igemm<f32,128,fwd>", "igemm<f32,128,dgrad>", "igemm<f32,128,dgrad_s2>"}}};
-  vdqn_prof_begin(kTag[sizeof(T) == 2 ? 0 : 1][BN == 128 ? 1 : 0][MODE],
+                                             {"igemm<f32,128,fwd>", "igemm<f32,128,dgrad>", "igemm<f32,128,dgrad_s2>"},
+                                             {"igemm<f32,256x64,fwd>", "igemm<f32,256x64,dgrad>", "igemm<f32,256x64,dgrad_s2>"}}};
+  vdqn_prof_begin(kTag[sizeof(T) == 2 ? 0 : 1][BM == 256 ? 2 : (BN == 128 ? 1 : 0)][MODE],
                   2.0 * p.M * p.co * p.ktot,
                   esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
                   stream);
-  hipLaunchKernelGGL((igemm_kernel<T, BN, MODE, NSTAGE>), dim3(grid), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, MODE, NSTAGE>), dim3(grid), dim3(2 * BM), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN>
 int launch_mode(const IgemmParams& p, int mode, hipStream_t st) {
-  if (mode == 0) return launch_igemm<T, BN, 0>(p, st);
-  if (mode == 1) return launch_igemm<T, BN, 1>(p, st);
-  return launch_igemm<T, BN, 2>(p, st);
+  if (mode == 0) return launch_igemm<T, BM, BN, 0>(p, st);
+  if (mode == 1) return launch_igemm<T, BM, BN, 1>(p, st);
+  if constexpr (BM == 128) return launch_igemm<T, BM, BN, 2>(p, st);
+  return VDQN_ERR_INVALID;
 }
 
 }  // namespace
@@ -458,6 +478,13 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   p.vec_ok = ((a->ldo * esz) % 16 == 0) && ((al & 15) == 0) && (a->ldo % 8 == 0);
   const int mode = a->mode == 0 ? 0 : (a->stride == 2 ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == VDQN_BF16) return bn == 128 ? launch_mode<bf16raw, 128>(p, mode, st) : launch_mode<bf16raw, 64>(p, mode, st);
-  return bn == 128 ? launch_mode<float, 128>(p, mode, st) : launch_mode<float, 64>(p, mode, st);
+  // 64-column layers with many rows: 256-row tiles, 8 waves (more MFMA work per DMA round trip, half the weight traffic)
+  // (VDQN_BM256_MIN_ROWS overrides the row threshold: tests lower it to reach this variant with small tensors, a huge value disables it)
+  static const long long min256 = [] { const char* e = getenv("VDQN_BM256_MIN_ROWS"); return e ? atoll(e) : 256ll * 1024; }();
+  if (bn == 64 && mode != 2 && p.M >= min256) {
+    p.tiles_m = (p.M + 255) / 256;
+    return a->dtype == VDQN_BF16 ? launch_mode<bf16raw, 256, 64>(p, mode, st) : launch_mode<float, 256, 64>(p, mode, st);
+  }
+  if (a->dtype == VDQN_BF16) return bn == 128 ? launch_mode<bf16raw, 128, 128>(p, mode, st) : launch_mode<bf16raw, 128, 64>(p, mode, st);
+  return bn == 128 ? launch_mode<float, 128, 128>(p, mode, st) : launch_mode<float, 128, 64>(p, mode, st);
 }
