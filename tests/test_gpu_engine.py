@@ -321,3 +321,26 @@ def test_td_step_multi_frame_matches_oracle_f32():
         if l2err(g, p.grad) > tol_l2 or relerr(g, p.grad) > tol_max:
             bad.append((name, l2err(g, p.grad), relerr(g, p.grad)))
     assert not bad, bad
+
+
+def test_side_stream_overlap_matches_serial():
+    """The weight gradients / target forward run on a second HIP stream; from the same parameters and batch the flat
+    gradient must equal the serialised run up to f32 summation order (a race would show as O(1) differences)."""
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    B = 16
+    net = NetEngine(3, 5, 1, True, "f32", 2 * B)
+    net.load_tensors(synth.make_state_dict(7))
+    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True)
+    for rep in range(6):
+        (tup, raw) = synth.make_batch(400 + rep, B, 1, structured=True, reward_p=0.3)
+        args = (torch.from_numpy(raw[0]).to(DEV), torch.from_numpy(raw[1]).to(DEV), 0, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV))
+        res = []
+        for overlap in (0, 1, 1):
+            net.lib.vdqn_net_set_overlap(net.handle, overlap)
+            stp.forward_backward(*args)
+            torch.cuda.synchronize()
+            res.append((stp.grads.clone(), stp.loss.item()))
+        for g, l in res[1:]:
+            assert abs(l - res[0][1]) <= 1e-6 * abs(res[0][1])
+            assert relerr(g, res[0][0]) < 1e-5, rep
+    net.lib.vdqn_net_set_overlap(net.handle, 1)

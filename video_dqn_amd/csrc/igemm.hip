@@ -395,9 +395,8 @@ __global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igem
   }
 }
 
-template <typename T, int BM, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE, int NSTAGE = VDQN_IGEMM_STAGES>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
-  constexpr int NSTAGE = VDQN_IGEMM_STAGES;
   const size_t main_bytes = NSTAGE * (BM + BN) * 128, epi_bytes = BM * (BN + 4) * 4;
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   static bool attr_set = false;
@@ -424,11 +423,11 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   return VDQN_OK;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NSTAGE = VDQN_IGEMM_STAGES>
 int launch_mode(const IgemmParams& p, int mode, hipStream_t st) {
-  if (mode == 0) return launch_igemm<T, BM, BN, 0>(p, st);
-  if (mode == 1) return launch_igemm<T, BM, BN, 1>(p, st);
-  if constexpr (BM == 128) return launch_igemm<T, BM, BN, 2>(p, st);
+  if (mode == 0) return launch_igemm<T, BM, BN, 0, NSTAGE>(p, st);
+  if (mode == 1) return launch_igemm<T, BM, BN, 1, NSTAGE>(p, st);
+  if constexpr (BM == 128) return launch_igemm<T, BM, BN, 2, NSTAGE>(p, st);
   return VDQN_ERR_INVALID;
 }
 
