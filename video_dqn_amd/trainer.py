@@ -21,6 +21,7 @@ from .dataset import QLearningRealDataset, SyntheticTupleDataset
 from .dist import BucketAllReduce
 from .engine import TDStepper
 from .model import build_model
+from .shards import ShardDataset, is_shard_dir
 
 
 def loopLoader(loader, on_reset=None):
@@ -110,9 +111,12 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
         dataset = SyntheticTupleDataset(length=max(4 * B * world_size, 1024), num_frames=nf,
                                         action_dim=1 if (config.VALUE_LEARNING or config.ONE_ACTION) else 3, seed=config.SEED)
     else:
-        dataset = QLearningRealDataset(config.DATASET, one_action=True, confidence_reward=config.CONFIDENCE_REWARD,
-                                       value_learning=config.VALUE_LEARNING, inverse_actions=config.USE_INVERSE_ACTIONS,
-                                       previous_images=config.PREVIOUS_IMAGES, as_uint8=True)
+        kw = dict(one_action=True, confidence_reward=config.CONFIDENCE_REWARD, value_learning=config.VALUE_LEARNING,
+                  inverse_actions=config.USE_INVERSE_ACTIONS, previous_images=config.PREVIOUS_IMAGES)
+        if is_shard_dir(config.DATASET):  # pre-decoded uint8 frames (python -m video_dqn_amd.shards)
+            dataset = ShardDataset(config.DATASET, **kw)
+        else:
+            dataset = QLearningRealDataset(config.DATASET, as_uint8=True, **kw)
         log(f"Load data from {config.DATASET}")
         log(f"Reward Ratio: {dataset.reward_percentage()}")
     sampler = None
