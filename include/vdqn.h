@@ -154,6 +154,27 @@ int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, flo
 int vdqn_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
               double beta2, double eps, void* stream);
 
+/* torch.nn.BatchNorm2d in train mode over an NHWC conv output y[n_img][hw][c] (ARCHITECTURE='basic':
+ * archs/HabitatDQNMultiAction.py:32-34,37-40 keeps the ResNet in train mode).  Images are sample-major, frame-minor;
+ * image i belongs to statistic group (i / imgs_per_half) * num_frames + i % num_frames — one group per model call and
+ * frame slot, the minibatches the reference normalises over (:49-51; train_q_network.py:131,142).
+ *   z = relu?( (y - mean_g) * rstd_g * gamma + beta (+ resid) );   biased variance, eps inside the sqrt
+ *   running_* (may be NULL): updated once per group, in group order, with `momentum` and the unbiased variance
+ * work: f32 [groups][6][c] = mean, rstd, scale, shift and two sums; the forward fills it, the backward reads it. */
+int vdqn_bn_train_fwd(const void* y, const void* resid, void* z, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float* work, int32_t n_img, int32_t hw, int32_t c,
+                      int32_t num_frames, int32_t imgs_per_half, int32_t relu, float momentum, float eps, int32_t dtype,
+                      void* stream);
+/* dy = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) per group; dgamma/dbeta (may be NULL) = sums over all
+ * groups of g*xhat / g.  dy may alias g.  `work` must be the array the forward of the same tensor filled. */
+int vdqn_bn_train_bwd(const void* g, const void* y, void* dy, float* work, float* dgamma, float* dbeta, int32_t n_img,
+                      int32_t hw, int32_t c, int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* stream);
+/* AdaptiveAvgPool2d(1) of the ResNet (torchvision resnet.py avgpool) on NHWC x[n_img][hw][c] -> out[n_img][c], and its
+ * backward fused with the mask of the ReLU that produced x: gx = (x > 0) * g / hw. */
+int vdqn_avgpool_fwd(const void* x, void* out, int32_t n_img, int32_t hw, int32_t c, int32_t dtype, void* stream);
+int vdqn_avgpool_bwd(const void* g, const void* x, void* gx, int32_t n_img, int32_t hw, int32_t c, int32_t dtype,
+                     void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Engine level: the whole HabitatDQNMultiAction network and one TD update.
  * ------------------------------------------------------------------------------------------------ */
@@ -161,7 +182,8 @@ typedef struct vdqn_net_config {
   int32_t action_dim;      /* A: 3, or 1 for VALUE_LEARNING/ONE_ACTION (train_q_network.py:38-41) */
   int32_t num_classes;     /* 5 */
   int32_t num_frames;      /* F: 1, or 4 for PANORAMA/PREVIOUS_IMAGES (archs/...:16-19); any F >= 1 accepted */
-  int32_t extra_capacity;  /* ARCHITECTURE == 'extra_capacity' (only 1 is implemented in this round) */
+  int32_t extra_capacity;  /* 1: ARCHITECTURE 'extra_capacity' (BatchNorm on running stats, conv+MLP head);
+                              0: 'basic' (defaults.py:14 — train-mode BatchNorm, average pool + one Linear) */
   int32_t dtype;           /* VDQN_F32 | VDQN_BF16 */
   int32_t max_batch;       /* largest per-call sample count B the workspaces are sized for */
 } vdqn_net_config;
@@ -217,11 +239,20 @@ int64_t vdqn_net_bwd_offset(const vdqn_net* net, int32_t n_samples, const char* 
  * extra_capacity all 20 BatchNorm layers run on running statistics). */
 int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad,
                           void* stream);
+/* with_dgrad is a flag word: bit 0 = also pack the data-gradient operands, bit 1 = do NOT fold BatchNorm (the
+ * convolutions then produce the raw pre-BatchNorm output; used by the train-mode BatchNorm path of 'basic'). */
 
 /* Forward of `n_samples` samples (n_samples * F frames).  frames: see vdqn_pack_input (src_kind).
  * q_out: f32 [n_samples][num_classes*action_dim] (HabitatDQNMultiAction.forward, archs/...:44-54). */
 int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples,
                      void* acts, float* q_out, void* stream);
+
+/* ARCHITECTURE='basic' with the module in train mode (model.train(); archs/HabitatDQNMultiAction.py:37-40 leaves the
+ * ResNet's BatchNorm layers in train mode): one model call over n_samples samples with batch statistics per frame
+ * slot (features is applied slot by slot, :49-51); updates `bnstats` (momentum 0.1, unbiased variance) F times per
+ * BatchNorm layer.  `packed` is a workspace of vdqn_net_packed_bytes that receives the un-folded weights. */
+int vdqn_net_forward_train(vdqn_net* net, const float* params, float* bnstats, void* packed, const void* frames,
+                           int32_t src_kind, int32_t n_samples, void* acts, float* q_out, void* stream);
 
 /* One TD update's device work up to the flat gradient (train_q_network.py:222-226):
  *   online forward over [before; after] (2B samples, one pass — legal because BatchNorm is in eval mode),
@@ -230,7 +261,7 @@ int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int3
  *   vdqn_net_td_forward -> vdqn_net_backward_stage(0..2)  (-> all-reduce) -> vdqn_adam on the flat range. */
 typedef struct vdqn_step_args {
   const float* params;        /* online master parameters (flat) */
-  const float* bnstats;
+  float* bnstats;             /* running statistics; updated in place by every update when ARCHITECTURE='basic' */
   void* packed_online;        /* workspace: vdqn_net_packed_bytes */
   const void* packed_target;  /* packed target-network weights (refreshed by the caller on target sync) */
   const void* before;         /* frames of s  : [B][F] frames, src_kind layout */

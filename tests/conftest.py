@@ -24,3 +24,9 @@ def g1():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "g1_state_dict.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_basic():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_basic.npz"), allow_pickle=False)

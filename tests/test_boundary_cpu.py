@@ -35,8 +35,9 @@ def test_compute_fails_loudly_without_gpu():
         net.forward(torch.zeros(1, 3, 224, 224), 1, 1)
     with pytest.raises(_lib.VdqnError):
         TDStepper(net, 4, 1e-4, 0.99, True)
-    with pytest.raises(NotImplementedError):
-        NetEngine(3, 5, 1, False, "bf16", 8, device="cpu")  # basic arch: not implemented, says so
+    basic = NetEngine(3, 5, 4, False, "bf16", 8, device="cpu")  # ARCHITECTURE='basic': storage-only as well
+    with pytest.raises(_lib.VdqnError):
+        basic.forward_train(torch.zeros(1, 4, 3, 224, 224), 1, 1)
 
 
 def test_config_defaults_and_merge(tmp_path):
@@ -68,9 +69,9 @@ def test_config_defaults_and_merge(tmp_path):
 def test_model_state_dict_matches_reference_layout(g1):
     """Key set, order, shapes and aliasing of the product model == the reference class (golden G1)."""
     from video_dqn_amd.model import HabitatDQNMultiAction
-    for pano in (False, True):
-        ref = g1[f"ec1_pano{int(pano)}"]
-        m = HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=pano, device="cpu")
+    for ec, pano in ((True, False), (True, True), (False, False), (False, True)):
+        ref = g1[f"ec{int(ec)}_pano{int(pano)}"]
+        m = HabitatDQNMultiAction(3, 5, extra_capacity=ec, panorama=pano, device="cpu")
         sd = m.state_dict()
         assert list(sd.keys()) == ref["keys"]
         assert [list(v.shape) for v in sd.values()] == ref["shapes"]

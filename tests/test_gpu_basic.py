@@ -1,0 +1,221 @@
+"""ARCHITECTURE='basic' (defaults.py:14): train-mode BatchNorm with per-frame-slot batch statistics, average-pool head.
+Operator parity against torch.nn.functional.batch_norm, engine parity against the CPU oracle and against the goldens
+produced by the reference's own class / process_batch (tests/golden/make_golden_basic.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+pytestmark = pytest.mark.gpu
+
+from helpers import relerr  # noqa: E402
+from video_dqn_amd import synth  # noqa: E402
+
+DEV = "cuda"
+
+
+def l2err(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def cosine(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("n,hw,c,F,halves", [(6, 14, 256, 1, 1), (8, 7, 512, 2, 2), (12, 56, 64, 3, 2), (4, 28, 128, 4, 1)])
+def test_bn_train_fwd_bwd_match_torch(dtype, tol, n, hw, c, F, halves):
+    """Per-group batch statistics (group = model call x frame slot), residual + ReLU epilogue, running-stat update order,
+    and the backward (dy, dgamma, dbeta) against autograd through F.batch_norm applied group by group."""
+    from video_dqn_amd import ops
+    seed = n * 1000 + c
+    y = torch.from_numpy(synth.uniform(seed, "y", (n, hw, hw, c), -1.0, 2.0)).to(dtype)
+    res = torch.from_numpy(synth.uniform(seed, "r", (n, hw, hw, c), -1.0, 1.0)).to(dtype)
+    g_out = torch.from_numpy(synth.uniform(seed, "g", (n, hw, hw, c), -1.0, 1.0)).to(dtype)
+    gamma = torch.from_numpy(synth.uniform(seed, "ga", (c,), 0.5, 1.5))
+    beta = torch.from_numpy(synth.uniform(seed, "be", (c,), -0.5, 0.5))
+    rm0 = torch.from_numpy(synth.uniform(seed, "rm", (c,), -0.2, 0.2))
+    rv0 = torch.from_numpy(synth.uniform(seed, "rv", (c,), 0.5, 1.5))
+    iph = n // halves
+    rm, rv = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    z, work = ops.bn_train_fwd(y.to(DEV), gamma.to(DEV), beta.to(DEV), rm, rv, resid=res.to(DEV), relu=True, num_frames=F, imgs_per_half=iph)
+    # the engine masks the incoming gradient with the ReLU before the BatchNorm backward
+    gm = (g_out.to(DEV).float() * (z.float() > 0)).to(dtype)
+    dy, dgamma, dbeta = ops.bn_train_bwd(gm, y.to(DEV), work, num_frames=F, imgs_per_half=iph)
+    torch.cuda.synchronize()
+
+    # torch reference in f64 on the (dtype-rounded) inputs, group by group in the reference's call order
+    yd = y.double().permute(0, 3, 1, 2).requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rmr, rvr = rm0.double().clone(), rv0.double().clone()
+    zr = torch.zeros_like(yd)
+    img = torch.arange(n)
+    pieces = []
+    for half in range(halves):
+        for f in range(F):
+            sel = img[(img // iph == half) & (img % F == f)]
+            o = Fn.batch_norm(yd[sel], rmr, rvr, gd, bd, training=True, momentum=0.1, eps=1e-5)
+            pieces.append((sel, o))
+    zr = torch.zeros_like(yd)
+    for sel, o in pieces:
+        zr = zr.index_add(0, sel, o)
+    zr = torch.relu(zr + res.double().permute(0, 3, 1, 2))
+    assert relerr(z.float().cpu().permute(0, 3, 1, 2), zr.detach()) < tol
+    np.testing.assert_allclose(rm.cpu().numpy(), rmr.numpy(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), rvr.numpy(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-4, atol=1e-5)
+    zr.backward(gm.double().cpu().permute(0, 3, 1, 2))
+    assert relerr(dy.float().cpu().permute(0, 3, 1, 2), yd.grad) < max(tol, 1e-4)
+    assert relerr(dgamma, gd.grad) < max(tol, 1e-4)
+    assert relerr(dbeta, bd.grad) < max(tol, 1e-4)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_avgpool_fwd_bwd(dtype, tol):
+    from video_dqn_amd import ops
+    x = torch.relu(torch.from_numpy(synth.uniform(5, "x", (6, 7, 7, 512), -1.0, 1.0))).to(dtype)
+    g = torch.from_numpy(synth.uniform(5, "g", (6, 512), -1.0, 1.0)).to(dtype)
+    out = ops.avgpool_fwd(x.to(DEV))
+    gx = ops.avgpool_bwd(g.to(DEV), x.to(DEV))
+    torch.cuda.synchronize()
+    assert relerr(out, x.float().mean(dim=(1, 2))) < tol
+    ref = (x.float() > 0) * g.float()[:, None, None, :] / 49
+    assert relerr(gx, ref) < tol
+
+
+def make_basic(dtype, seed, F, max_batch):
+    from video_dqn_amd.engine import NetEngine
+    net = NetEngine(3, 5, F, False, dtype, max_batch)
+    net.load_tensors(synth.make_state_dict(seed, extra_capacity=False, num_frames=F))
+    return net
+
+
+def test_basic_eval_forward_matches_reference_golden(golden):
+    """Eval-mode forward (running statistics folded, average pool, one Linear) against G2's ec0 cases."""
+    n = 0
+    for ec, pano, B, st in golden["g2_cases"]:
+        if ec:
+            continue
+        F = 4 if pano else 1
+        net = make_basic("f32", 11, F, 8)
+        (tup, raw) = synth.make_batch(21 + int(B), int(B), F, structured=True)
+        ref = torch.from_numpy(golden[f"g2_q_ec0_pano{int(pano)}_B{int(B)}_eval"]).reshape(int(B), 15)
+        q = net.forward(tup[0].contiguous().to(DEV), 1, int(B))
+        q0 = net.forward(torch.from_numpy(raw[0]).to(DEV), 0, int(B))
+        torch.cuda.synchronize()
+        assert relerr(q, ref) < 1e-3 and relerr(q0, ref) < 1e-3
+        n += 1
+    assert n == 2
+
+
+@pytest.mark.parametrize("F,B", [(1, 5), (4, 3)])
+def test_basic_model_train_forward_matches_oracle(F, B):
+    """model(x) under model.train(): batch statistics per frame slot, running statistics and num_batches_tracked
+    advance exactly like torch's BatchNorm2d; a following eval forward uses the updated statistics."""
+    from oracle import ref_cpu
+    from video_dqn_amd.model import HabitatDQNMultiAction
+    sd = synth.make_state_dict(11, extra_capacity=False, num_frames=F)
+    m = HabitatDQNMultiAction(3, 5, extra_capacity=False, panorama=F > 1, num_frames=F, dtype="f32", device=DEV, max_batch=8)
+    m.load_state_dict(sd, strict=True)
+    ref = ref_cpu.HabitatDQNMultiAction(3, 5, extra_capacity=False, panorama=F > 1, num_frames=F)
+    ref.load_state_dict(sd)
+    (tup, _) = synth.make_batch(77, B, F, structured=True)
+    m.set_train()
+    ref.set_train()
+    with torch.no_grad():
+        for _ in range(2):
+            q = m(tup[0])
+            qr = ref(tup[0])
+            assert q.shape == qr.shape == (B, 5, 3)
+            assert relerr(q, qr) < 1e-3
+    got, want = m.state_dict(), ref.state_dict()
+    assert list(got.keys()) == list(want.keys())
+    for k, v in want.items():
+        if "num_batches_tracked" in k:
+            assert int(got[k]) == int(v) == 2 * F, k
+        elif "running_" in k:
+            assert relerr(got[k], v) < 1e-4, k
+    m.eval()
+    ref.eval()
+    with torch.no_grad():
+        assert relerr(m(tup[0]), ref(tup[0])) < 1e-3
+    assert int(m.state_dict()["resnet.bn1.num_batches_tracked"]) == 2 * F  # eval forward does not advance it
+
+
+def _basic_steps(dtype, F, B, steps, pano):
+    from video_dqn_amd.engine import TDStepper
+    net = make_basic(dtype, 7, F, 2 * B)
+    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True)
+    tnet = make_basic(dtype, 8, F, 2 * B)
+    tnet.pack_weights(stp.packed_target)
+    out = []
+    for step in range(1, steps + 1):
+        (tup, _) = synth.make_batch(400 + 10 * F + step, B, F, structured=True, reward_p=0.3)
+        before, after, act, rew, term, gt, vm = tup
+        loss = stp.step(before.contiguous().to(DEV), after.contiguous().to(DEV), 1, act.to(DEV), rew.float().to(DEV), term.float().to(DEV))
+        torch.cuda.synchronize()
+        out.append(dict(loss=loss.item(), q_before=stp.q_before.cpu().clone(), grads=stp.grads.cpu().clone(),
+                        params=net.params.cpu().clone(), bnstats=net.bnstats.cpu().clone(), nbt=net.num_batches_tracked.cpu().clone()))
+    return net, out
+
+
+@pytest.mark.parametrize("tag,pano,F,B,steps", [("F1", False, 1, 6, 2), ("F4", True, 4, 3, 1)])
+def test_basic_td_steps_match_reference_golden_f32(golden_basic, tag, pano, F, B, steps):
+    """Full updates of ARCHITECTURE='basic' against G5 (reference class + reference process_batch + torch Adam): loss, Q(s),
+    every parameter's gradient (norm 1e-3 strict on step 1, sampled elements), post-Adam parameters, running statistics,
+    num_batches_tracked.  Batch-statistics BatchNorm couples all activations of a group, so a ReLU flip is not local;
+    the sampled-element gate is the same 3e-3-of-max as in the extra_capacity test."""
+    g = golden_basic
+    net, out = _basic_steps("f32", F, B, steps, pano)
+    lr = 1e-4
+    for step, o in enumerate(out, start=1):
+        k = f"g5_{tag}_s{step}"
+        np.testing.assert_allclose(o["loss"], float(g[f"{k}_loss"]), rtol=1e-3)
+        assert relerr(o["q_before"], torch.from_numpy(g[f"{k}_qbefore"]).reshape(B, 15)) < 1e-3
+        assert int(o["nbt"][0]) == int(o["nbt"][-1]) == 2 * F * step
+        for name, s in net.slots.items():
+            if s.kind in (2, 3):
+                got = o["bnstats"][s.offset:s.offset + s.numel]
+                assert relerr(got, torch.from_numpy(g[f"{k}_bn_{name}"])) < 1e-3, (step, name)
+            if s.kind != 0:
+                continue
+            gr = o["grads"][s.offset:s.offset + s.numel]
+            idx = synth.randint(1234, "idx." + name, (min(16, s.numel),), s.numel)
+            amax = float(g[f"{k}_gabsmax_{name}"])
+            pdiff = np.abs(o["params"][s.offset:s.offset + s.numel][idx].numpy() - g[f"{k}_psamp_{name}"])
+            if step == 1:
+                assert np.abs(gr[idx].numpy() - g[f"{k}_gsamp_{name}"]).max() <= 3e-3 * amax + 1e-12, (step, name)
+                np.testing.assert_allclose(gr.double().norm().item(), float(g[f"{k}_gnorm_{name}"]), rtol=1e-3, err_msg=name)
+                assert pdiff.max() <= 0.02 * lr + 1e-9, (step, name)
+            else:  # trajectory check (see test_gpu_engine.py::test_td_steps_match_reference_golden_f32)
+                np.testing.assert_allclose(gr.double().norm().item(), float(g[f"{k}_gnorm_{name}"]), rtol=5e-2, err_msg=name)
+                assert pdiff.max() <= 2.5 * lr * step, (step, name)
+
+
+def test_basic_td_step_bf16_direction_and_scale():
+    """bf16 throughput mode of the basic arch against the fp32 oracle: cosine / norm-ratio gate per tensor."""
+    from oracle import ref_cpu
+    B, F = 8, 1
+    net, out = _basic_steps("bf16", F, B, 1, False)
+    cfg = ref_cpu.default_config(ARCHITECTURE="basic")
+    tr = ref_cpu.Trainer(cfg, synth.make_state_dict(7, extra_capacity=False))
+    tr.target_net.load_state_dict(synth.make_state_dict(8, extra_capacity=False))
+    (tup, _) = synth.make_batch(400 + 10 * F + 1, B, F, structured=True, reward_p=0.3)
+    d = {}
+    loss = tr.step(tup, d)
+    assert abs(out[0]["loss"] - loss) <= 0.2 * abs(loss)
+    assert relerr(out[0]["q_before"], d["before_values"].detach().reshape(B, 15)) < 6e-2
+    bad = []
+    for name, p in tr.model.named_parameters():
+        if p.grad is None:
+            continue
+        s = net.slots[name]
+        gr = out[0]["grads"][s.offset:s.offset + s.numel].view(s.shape)
+        c, ratio = cosine(gr, p.grad), (gr.double().norm() / p.grad.double().norm()).item()
+        if c < 0.95 or abs(ratio - 1.0) > 0.15:
+            bad.append((name, c, ratio))
+    assert not bad, bad
+    for name, s in net.slots.items():
+        if s.kind in (2, 3):
+            assert relerr(out[0]["bnstats"][s.offset:s.offset + s.numel], tr.model.state_dict()[name]) < 3e-2, name

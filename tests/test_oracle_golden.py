@@ -83,3 +83,39 @@ def test_g4_loss_branches_match_reference(golden):
         np.testing.assert_allclose(loss.item(), float(golden[f"g4_loss_{int(cid)}"]), rtol=1e-6)
         np.testing.assert_allclose(dq.numpy(), golden[f"g4_dq_{int(cid)}"], rtol=1e-6, atol=1e-8)
         assert best[0, 0].item() == 0 and best[1, 1].item() == 1  # first max wins
+
+
+BASIC_CASES = (("F1", False, 1, 6, 2), ("F4", True, 4, 3, 1))  # tests/golden/make_golden_basic.py
+
+
+def test_g5_basic_arch_td_steps_match_reference(golden_basic):
+    """ARCHITECTURE='basic' (train-mode BatchNorm, per-frame-slot batch statistics, running-stat updates): the oracle
+    restatement against goldens produced by the reference class + the reference's process_batch."""
+    torch.set_num_threads(8)
+    g = golden_basic
+    for tag, pano, F, B, steps in BASIC_CASES:
+        cfg = ref_cpu.default_config(ARCHITECTURE="basic", PANORAMA=pano)
+        tr = ref_cpu.Trainer(cfg, synth.make_state_dict(7, extra_capacity=False, num_frames=F))
+        tr.target_net.load_state_dict(synth.make_state_dict(8, extra_capacity=False, num_frames=F))
+        for step in range(1, steps + 1):
+            (tup, _) = synth.make_batch(400 + 10 * F + step, B, F, structured=True, reward_p=0.3)
+            d = {}
+            loss = tr.step(tup, d)
+            k = f"g5_{tag}_s{step}"
+            np.testing.assert_allclose(loss, float(g[f"{k}_loss"]), rtol=1e-5)
+            np.testing.assert_allclose(d["before_values"].detach().numpy(), g[f"{k}_qbefore"], rtol=1e-4, atol=1e-6)
+            for n, v in tr.model.state_dict().items():
+                if n.startswith("features."):
+                    continue
+                if "running_" in n:
+                    np.testing.assert_allclose(v.numpy(), g[f"{k}_bn_{n}"], rtol=1e-5, atol=1e-7, err_msg=n)
+                elif "num_batches_tracked" in n:
+                    assert int(v) == int(g[f"{k}_nbt_{n}"]) == 2 * F * step
+            for n, p in tr.model.named_parameters():
+                if p.grad is None:
+                    continue
+                np.testing.assert_allclose(p.grad.double().norm().item(), float(g[f"{k}_gnorm_{n}"]), rtol=1e-4)
+        tr.model.eval()
+        with torch.no_grad():
+            (tup, _) = synth.make_batch(499, 2, F, structured=True)
+            np.testing.assert_allclose(tr.model(tup[0]).numpy(), g[f"g5_{tag}_eval_q_after_training"], rtol=1e-4, atol=1e-6)

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvdqn.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -80,6 +80,11 @@ _SIGS = {
     "vdqn_td_loss": (C.c_int, [C.POINTER(TdArgs), c_vp]),
     "vdqn_gt_loss": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
     "vdqn_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_vp]),
+    "vdqn_bn_train_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                    c_f32, c_f32, c_i32, c_vp]),
+    "vdqn_bn_train_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vdqn_avgpool_fwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "vdqn_avgpool_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(c_vp)]),
     "vdqn_net_destroy": (None, [c_vp]),
     "vdqn_net_set_overlap": (C.c_int, [c_vp, C.c_int]),
@@ -96,6 +101,7 @@ _SIGS = {
     "vdqn_net_bwd_offset": (c_i64, [c_vp, c_i32, C.c_char_p]),
     "vdqn_net_pack_weights": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "vdqn_net_forward": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "vdqn_net_forward_train": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vdqn_net_td_forward": (C.c_int, [c_vp, C.POINTER(StepArgs), c_vp]),
     "vdqn_net_backward_stage": (C.c_int, [c_vp, C.POINTER(StepArgs), c_i32, c_vp]),
 }

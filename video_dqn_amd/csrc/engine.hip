@@ -28,12 +28,13 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 2; }
+extern "C" int vdqn_abi_version(void) { return 3; }
 
 namespace {
 
 constexpr int kMaxLayers = 24;
 constexpr float kBnEps = 1e-5f;
+constexpr float kBnMomentum = 0.1f;
 
 enum LayerKind { K_CONV = 0, K_CONV1_S2D = 1, K_LINEAR = 2, K_LINEAR_PERM = 3 };
 
@@ -74,12 +75,15 @@ struct ActLayout {
   int64_t t_in, c1, pool, idx;
   int64_t h[8], o[8], ds[8];
   int64_t f8, l0, l1, q, qf;
+  // ARCHITECTURE='basic' only: pooled features, raw (pre-BatchNorm) conv outputs, per-layer BatchNorm work areas
+  int64_t avg, r_c1, r_h[8], r_o[8], r_ds[8], bnw[kMaxLayers], bnw_begin, bnw_bytes;
   int64_t total;
 };
 struct BwdLayout {
   int64_t zero_begin, zero_bytes;  // region cleared every step: dW', dbias', loss scratch
   int64_t dq, g_l1, g_l0, g_f8, g_o[8], g_h[8], dsg[8], g_pool, g_c1;
   int64_t p_l1, p_l0, p_f8, p_o[8], p_h[8], p_pool;  // per-128-row-tile column sums written by the dgrad epilogues
+  int64_t g_avg, g_or[8], g_dsr[8];  // 'basic' only: gradient of the pooled features / of the raw conv2, downsample outputs
   int64_t total;
 };
 
@@ -98,7 +102,8 @@ struct vdqn_net {
   int64_t dw_bytes;  // total f32 dW' + dbias' bytes
   FoldTable fold;
   // layer indices
-  int l_conv1, l_f8, l_top0, l_top2, l_top4;
+  int l_conv1, l_f8, l_top0, l_top2, l_top4;  // 'basic': l_top4 is the single `top` Linear, the other head layers are -1
+  bool basic() const { return cfg.extra_capacity == 0; }
   int l_b_conv1[8], l_b_conv2[8], l_b_ds[8];
   // A second HIP stream for work that is independent of the main dependency chain: the weight gradients (they only
   // need gy, the data-gradient chain does not wait for them) and the target-network forward.  Blocks of the side
@@ -171,15 +176,16 @@ __device__ __forceinline__ long fold_src_index(const FoldDesc& d, int co, int k)
   }
 }
 
-__device__ __forceinline__ float fold_scale(const FoldDesc& d, const float* params, const float* bnstats, int co) {
-  if (!d.has_bn) return 1.0f;
+__device__ __forceinline__ float fold_scale(const FoldDesc& d, const float* params, const float* bnstats, int co, int raw) {
+  if (!d.has_bn || raw) return 1.0f;
   return params[d.g_off + co] / sqrtf(bnstats[d.var_off + co] + kBnEps);
 }
 
-// grid: (blocks, layers, 2): z = 0 packs Wf (+bias, scale), z = 1 packs Wd
+// grid: (blocks, layers, 2): z = 0 packs Wf (+bias, scale), z = 1 packs Wd.  raw = 1: BatchNorm is NOT folded
+// (train-mode BatchNorm of ARCHITECTURE='basic': the convs produce the raw output, bias 0)
 template <typename T>
 __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const float* __restrict__ params, const float* __restrict__ bnstats,
-                                                   unsigned char* __restrict__ packed, int with_dgrad) {
+                                                   unsigned char* __restrict__ packed, int with_dgrad, int raw) {
   const FoldDesc& d = tab.d[blockIdx.y];
   const int which = blockIdx.z;
   if (which == 1 && (!with_dgrad || d.wd_off < 0)) return;
@@ -193,13 +199,13 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const fl
       const int row = (int)(i / d.kf), k = (int)(i - (long)row * d.kf);
       float v = 0.f;
       if (row < d.co) {
-        const float sc = fold_scale(d, params, bnstats, row);
+        const float sc = fold_scale(d, params, bnstats, row, raw);
         const long src = fold_src_index(d, row, k);
         if (src >= 0) v = params[d.w_off + src] * sc;
         if (k == 0) {
           scale[row] = sc;
           float b = 0.f;
-          if (d.has_bn) b = params[d.b_off + row] - bnstats[d.mean_off + row] * sc;
+          if (d.has_bn) b = raw ? 0.f : params[d.b_off + row] - bnstats[d.mean_off + row] * sc;
           else if (d.has_bias) b = params[d.b_off + row];
           bias[row] = b;
         }
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const fl
       float v = 0.f;
       if (co < d.co) {
         const long src = fold_src_index(d, co, tap * d.k_ci + n);
-        if (src >= 0) v = params[d.w_off + src] * fold_scale(d, params, bnstats, co);
+        if (src >= 0) v = params[d.w_off + src] * fold_scale(d, params, bnstats, co, raw);
       }
       wd[i] = from_f32<T>(v);
     }
@@ -226,9 +232,11 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const fl
 }
 
 // grid: (max co, layers of the stage): one block per output channel
+// raw = 1: the weights were packed without BatchNorm folding; the BatchNorm parameter gradients were already written
+// by the train-mode BatchNorm backward
 __global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, const PartTable pt, int first_layer, const float* __restrict__ params,
                                                      const float* __restrict__ bnstats, const unsigned char* __restrict__ bwd,
-                                                     float* __restrict__ grads) {
+                                                     float* __restrict__ grads, int raw) {
   const FoldDesc& d = tab.d[first_layer + blockIdx.y];
   const int co = blockIdx.x;
   if (co >= d.co) return;
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, const 
     }
   }
   float rstd = 1.f, sc = 1.f;
-  if (d.has_bn) {
+  if (d.has_bn && !raw) {
     rstd = 1.0f / sqrtf(bnstats[d.var_off + co] + kBnEps);
     sc = params[d.g_off + co] * rstd;
   }
@@ -274,8 +282,10 @@ __global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, const 
     const float tot = red[0] + red[1] + red[2] + red[3];
     const float dbp = pt.tiles[li] > 0 ? (red[4] + red[5] + red[6] + red[7]) : db[co];
     if (d.has_bn) {
-      grads[d.g_off + co] = rstd * (tot - bnstats[d.mean_off + co] * dbp);
-      grads[d.b_off + co] = dbp;
+      if (!raw) {
+        grads[d.g_off + co] = rstd * (tot - bnstats[d.mean_off + co] * dbp);
+        grads[d.b_off + co] = dbp;
+      }
     } else if (d.has_bias) {
       grads[d.b_off + co] = dbp;
     }
@@ -368,10 +378,14 @@ void build_layers(vdqn_net* net) {
       sp = sp_out;
     }
   }
-  fwd.push_back(make_conv("features.8", "", 64, 512, 3, 1, 0, 7, 0));
-  fwd.push_back(make_linear("top.0", 512, 1600 * F, 0, true));
-  fwd.push_back(make_linear("top.2", 256, 512, 0, false));
-  fwd.push_back(make_linear("top.4", net->cfg.action_dim * net->cfg.num_classes, 256, 0, false));
+  if (!net->basic()) {  // archs/HabitatDQNMultiAction.py:27-31
+    fwd.push_back(make_conv("features.8", "", 64, 512, 3, 1, 0, 7, 0));
+    fwd.push_back(make_linear("top.0", 512, 1600 * F, 0, true));
+    fwd.push_back(make_linear("top.2", 256, 512, 0, false));
+    fwd.push_back(make_linear("top.4", net->cfg.action_dim * net->cfg.num_classes, 256, 0, false));
+  } else {  // :32-34: global average pool, then one Linear over the F concatenated 512-vectors
+    fwd.push_back(make_linear("top", net->cfg.action_dim * net->cfg.num_classes, 512 * F, 0, false));
+  }
 
   // store layers ordered by backward stage (stable), so each stage's gradients are one contiguous range
   net->layers.clear();
@@ -391,7 +405,7 @@ void build_layers(vdqn_net* net) {
   net->l_f8 = find("features.8");
   net->l_top0 = find("top.0");
   net->l_top2 = find("top.2");
-  net->l_top4 = find("top.4");
+  net->l_top4 = net->basic() ? find("top") : find("top.4");
   for (int b = 0; b < 8; ++b) {
     char pfx[64];
     snprintf(pfx, sizeof(pfx), "resnet.layer%d.%d", b / 2 + 1, b % 2);
@@ -474,9 +488,14 @@ void build_layers(vdqn_net* net) {
     }
     order.push_back("resnet.fc.weight");
     order.push_back("resnet.fc.bias");
-    for (const char* n : {"features.8", "top.0", "top.2", "top.4"}) {
-      order.push_back(std::string(n) + ".weight");
-      order.push_back(std::string(n) + ".bias");
+    if (!net->basic()) {
+      for (const char* n : {"features.8", "top.0", "top.2", "top.4"}) {
+        order.push_back(std::string(n) + ".weight");
+        order.push_back(std::string(n) + ".bias");
+      }
+    } else {
+      order.push_back("top.weight");
+      order.push_back("top.bias");
     }
     for (auto& pi : net->params)
       for (size_t i = 0; i < order.size(); ++i)
@@ -522,6 +541,26 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
   L.l1 = take((int64_t)n_samples * 256 * e);
   L.q = take((int64_t)n_samples * 64 * e);
   L.qf = take((int64_t)n_samples * 64 * 4);
+  L.avg = L.r_c1 = L.bnw_begin = -1;
+  L.bnw_bytes = 0;
+  for (int b = 0; b < 8; ++b) L.r_h[b] = L.r_o[b] = L.r_ds[b] = -1;
+  for (int i = 0; i < kMaxLayers; ++i) L.bnw[i] = -1;
+  if (net->basic()) {
+    L.avg = take(n * 512 * e);
+    L.r_c1 = take(n * 112 * 112 * 64 * e);
+    for (int b = 0; b < 8; ++b) {
+      const int li = b / 2;
+      const int64_t planes = 64 << li, sp = 56 >> li;
+      const int64_t sz = n * sp * sp * planes * e;
+      L.r_h[b] = take(sz);
+      L.r_o[b] = take(sz);
+      L.r_ds[b] = (b % 2 == 0 && li > 0) ? take(sz) : -1;
+    }
+    L.bnw_begin = off;
+    for (size_t i = 0; i < net->layers.size(); ++i)
+      if (net->layers[i].has_bn) L.bnw[i] = take((int64_t)2 * F * 6 * net->layers[i].co * 4);
+    L.bnw_bytes = off - L.bnw_begin;
+  }
   L.total = off;
   return L;
 }
@@ -562,6 +601,16 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
     const int64_t planes = 64 << (b / 2), sp = 56 >> (b / 2);
     L.p_o[b] = take((tiles(n * sp * sp) + 4) * planes * 4);  // +4: stride-2 dgrad rounds tiles per parity class
     L.p_h[b] = take(tiles(n * sp * sp) * planes * 4);
+  }
+  L.g_avg = -1;
+  for (int b = 0; b < 8; ++b) L.g_or[b] = L.g_dsr[b] = -1;
+  if (net->basic()) {
+    L.g_avg = take(n * 512 * e);
+    for (int b = 0; b < 8; ++b) {
+      const int64_t planes = 64 << (b / 2), sp = 56 >> (b / 2);
+      L.g_or[b] = take(n * sp * sp * planes * e);
+      if (b % 2 == 0 && b > 0) L.g_dsr[b] = take(n * sp * sp * planes * e);
+    }
   }
   L.total = off;
   return L;
@@ -655,10 +704,54 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
     RC(run_conv(net, c2, packed, acts + A.h[b], acts + A.o[b], n, identity, 1, nullptr, st));
     x = acts + A.o[b];
   }
+  if (net->basic()) {
+    RC(vdqn_avgpool_fwd(x, acts + A.avg, n, 49, 512, dt, st));
+    RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.avg, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
+    return VDQN_OK;
+  }
   RC(run_conv(net, net->layers[net->l_f8], packed, x, acts + A.f8, n, nullptr, 1, nullptr, st));
   RC(run_conv(net, net->layers[net->l_top0], packed, acts + A.f8, acts + A.l0, n_samples, nullptr, 1, nullptr, st));
   RC(run_conv(net, net->layers[net->l_top2], packed, acts + A.l0, acts + A.l1, n_samples, nullptr, 1, nullptr, st));
   RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.l1, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
+  return VDQN_OK;
+}
+
+// train-mode BatchNorm of layer L over the raw conv output y: z = relu?(bn(y) (+ resid)); updates the running statistics
+int run_bn(const vdqn_net* net, int li, const float* params, float* bnstats, unsigned char* acts, const ActLayout& A, const void* y,
+           const void* resid, void* z, int n_img, int iph, int relu, hipStream_t st) {
+  const Layer& L = net->layers[li];
+  return vdqn_bn_train_fwd(y, resid, z, params + L.g_off, params + L.b_off, bnstats + L.mean_off, bnstats + L.var_off,
+                           reinterpret_cast<float*>(acts + A.bnw[li]), n_img, L.ho * L.wo, L.co, net->cfg.num_frames, iph, relu, kBnMomentum,
+                           kBnEps, net->cfg.dtype, st);
+}
+
+// ARCHITECTURE='basic' in train mode (archs/HabitatDQNMultiAction.py:37-40 leaves the ResNet in train mode): forward over
+// n_samples samples = n_samples/halves per model call, batch statistics per (call, frame slot), raw conv outputs kept for
+// the backward.  `packed` must hold the un-folded weights (vdqn_net_pack_weights flag 2).
+int forward_train_impl(const vdqn_net* net, const unsigned char* packed, const float* params, float* bnstats, const void* t_in, int n_samples,
+                       int halves, unsigned char* acts, const ActLayout& A, hipStream_t st) {
+  const int F = net->cfg.num_frames, n = n_samples * F, iph = n / halves;
+  const int dt = net->cfg.dtype;
+  RC(run_conv(net, net->layers[net->l_conv1], packed, t_in, acts + A.r_c1, n, nullptr, 0, nullptr, st));
+  RC(run_bn(net, net->l_conv1, params, bnstats, acts, A, acts + A.r_c1, nullptr, acts + A.c1, n, iph, 1, st));
+  RC(vdqn_maxpool_fwd(acts + A.c1, acts + A.pool, acts + A.idx, n, 112, 112, 64, dt, st));
+  const unsigned char* x = acts + A.pool;
+  for (int b = 0; b < 8; ++b) {
+    const int i1 = net->l_b_conv1[b], i2 = net->l_b_conv2[b], ids = net->l_b_ds[b];
+    RC(run_conv(net, net->layers[i1], packed, x, acts + A.r_h[b], n, nullptr, 0, nullptr, st));
+    RC(run_bn(net, i1, params, bnstats, acts, A, acts + A.r_h[b], nullptr, acts + A.h[b], n, iph, 1, st));
+    RC(run_conv(net, net->layers[i2], packed, acts + A.h[b], acts + A.r_o[b], n, nullptr, 0, nullptr, st));
+    const void* identity = x;
+    if (ids >= 0) {
+      RC(run_conv(net, net->layers[ids], packed, x, acts + A.r_ds[b], n, nullptr, 0, nullptr, st));
+      RC(run_bn(net, ids, params, bnstats, acts, A, acts + A.r_ds[b], nullptr, acts + A.ds[b], n, iph, 0, st));
+      identity = acts + A.ds[b];
+    }
+    RC(run_bn(net, i2, params, bnstats, acts, A, acts + A.r_o[b], identity, acts + A.o[b], n, iph, 1, st));
+    x = acts + A.o[b];
+  }
+  RC(vdqn_avgpool_fwd(x, acts + A.avg, n, 49, 512, dt, st));
+  RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.avg, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
   return VDQN_OK;
 }
 
@@ -669,7 +762,7 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out) {
   VDQN_CHECK(cfg && out, "vdqn_net_create: null arg");
-  VDQN_CHECK(cfg->extra_capacity == 1, "vdqn_net_create: only ARCHITECTURE='extra_capacity' is implemented (basic arch: BatchNorm train mode, next round)");
+  VDQN_CHECK(cfg->extra_capacity == 0 || cfg->extra_capacity == 1, "vdqn_net_create: extra_capacity must be 0 or 1");
   VDQN_CHECK(cfg->dtype == VDQN_F32 || cfg->dtype == VDQN_BF16, "vdqn_net_create: bad dtype %d", cfg->dtype);
   VDQN_CHECK(cfg->action_dim >= 1 && cfg->num_classes >= 1 && cfg->action_dim * cfg->num_classes <= 64, "vdqn_net_create: action_dim*num_classes must be in 1..64");
   VDQN_CHECK(cfg->num_frames >= 1 && cfg->num_frames <= 64, "vdqn_net_create: num_frames out of range");
@@ -744,6 +837,11 @@ extern "C" int64_t vdqn_net_act_offset(const vdqn_net* net, int32_t n_samples, c
   if ((v = indexed(name, "h", A.h)) != -2) return v;
   if ((v = indexed(name, "o", A.o)) != -2) return v;
   if ((v = indexed(name, "ds", A.ds)) != -2) return v;
+  if (strcmp(name, "avg") == 0) return A.avg;
+  if (strcmp(name, "r_c1") == 0) return A.r_c1;
+  if ((v = indexed(name, "r_h", A.r_h)) != -2) return v;
+  if ((v = indexed(name, "r_o", A.r_o)) != -2) return v;
+  if ((v = indexed(name, "r_ds", A.r_ds)) != -2) return v;
   return -1;
 }
 extern "C" int64_t vdqn_net_bwd_offset(const vdqn_net* net, int32_t n_samples, const char* name) {
@@ -757,6 +855,9 @@ extern "C" int64_t vdqn_net_bwd_offset(const vdqn_net* net, int32_t n_samples, c
   if ((v = indexed(name, "g_o", W.g_o)) != -2) return v;
   if ((v = indexed(name, "g_h", W.g_h)) != -2) return v;
   if ((v = indexed(name, "dsg", W.dsg)) != -2) return v;
+  if (strcmp(name, "g_avg") == 0) return W.g_avg;
+  if ((v = indexed(name, "g_or", W.g_or)) != -2) return v;
+  if ((v = indexed(name, "g_dsr", W.g_dsr)) != -2) return v;
   if (strncmp(name, "dw:", 3) == 0 || strncmp(name, "db:", 3) == 0)
     for (auto& L : net->layers)
       if (L.name == name + 3) return name[1] == 'w' ? L.dw_off : L.db_off;
@@ -766,11 +867,12 @@ extern "C" int64_t vdqn_net_bwd_offset(const vdqn_net* net, int32_t n_samples, c
 extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad, void* stream) {
   VDQN_CHECK(net && params && bnstats && packed, "vdqn_net_pack_weights: null arg");
   dim3 grid(256, (unsigned)net->layers.size(), 2);
-  ProfScope ps_("fold_weights", 0.0, (double)net->trainable_numel * 4.0 + (double)net->packed_bytes * (with_dgrad ? 1.0 : 0.5), (hipStream_t)stream);
+  const int dgrad = with_dgrad & 1, raw = (with_dgrad >> 1) & 1;
+  ProfScope ps_("fold_weights", 0.0, (double)net->trainable_numel * 4.0 + (double)net->packed_bytes * (dgrad ? 1.0 : 0.5), (hipStream_t)stream);
   if (net->cfg.dtype == VDQN_BF16)
-    hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, with_dgrad);
+    hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw);
   else
-    hipLaunchKernelGGL((fold_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, with_dgrad);
+    hipLaunchKernelGGL((fold_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }
@@ -790,6 +892,23 @@ extern "C" int vdqn_net_forward(vdqn_net* net, const void* packed, const void* f
   return VDQN_OK;
 }
 
+extern "C" int vdqn_net_forward_train(vdqn_net* net, const float* params, float* bnstats, void* packed, const void* frames, int32_t src_kind,
+                                      int32_t n_samples, void* acts, float* q_out, void* stream) {
+  VDQN_CHECK(net && params && bnstats && packed && frames && acts && q_out, "vdqn_net_forward_train: null arg");
+  VDQN_CHECK(net->basic(), "vdqn_net_forward_train: only ARCHITECTURE='basic' has train-mode BatchNorm (extra_capacity: use vdqn_net_forward)");
+  VDQN_CHECK(n_samples >= 1 && n_samples <= net->cfg.max_batch, "vdqn_net_forward_train: n_samples %d exceeds max_batch %d", n_samples, net->cfg.max_batch);
+  hipStream_t st = (hipStream_t)stream;
+  const ActLayout A = act_layout(net, n_samples);
+  unsigned char* ab = (unsigned char*)acts;
+  RC(vdqn_net_pack_weights(net, params, bnstats, packed, 2, st));
+  RC(vdqn_pack_input(frames, src_kind, ab + A.t_in, n_samples * net->cfg.num_frames, net->cfg.dtype, st));
+  RC(forward_train_impl(net, (const unsigned char*)packed, params, bnstats, ab + A.t_in, n_samples, 1, ab, A, st));
+  const int nq = net->cfg.action_dim * net->cfg.num_classes;
+  hipError_t e = hipMemcpy2DAsync(q_out, (size_t)nq * 4, ab + A.qf, 64 * 4, (size_t)nq * 4, (size_t)n_samples, hipMemcpyDeviceToDevice, st);
+  VDQN_CHECK(e == hipSuccess, "vdqn_net_forward_train: q copy failed: %s", hipGetErrorString(e));
+  return VDQN_OK;
+}
+
 extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream) {
   VDQN_CHECK(net && a, "vdqn_net_td_forward: null arg");
   VDQN_CHECK(a->params && a->bnstats && a->packed_online && a->before && a->act && a->acts_online && a->bwd && a->loss, "vdqn_net_td_forward: null buffer");
@@ -805,7 +924,7 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
 
-  RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, 1, st));
+  RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
   const int64_t frame_bytes = (int64_t)115 * 115 * 16 * net->esz;
   RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, st));
   if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, st));
@@ -815,7 +934,10 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     const ActLayout T = act_layout(net, B);
     RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst));
   }
-  RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st));
+  if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
+    RC(forward_train_impl(net, (const unsigned char*)a->packed_online, a->params, a->bnstats, ao + A.t_in, ns_online, gtb ? 1 : 2, ao, A, st));
+  else
+    RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st));
   if (tst != st) join_side(net, st);
 
   hipError_t e = hipMemsetAsync(bw + W.zero_begin, 0, (size_t)W.zero_bytes, st);
@@ -880,6 +1002,46 @@ int block_backward(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayou
   return VDQN_OK;
 }
 
+// train-mode BatchNorm backward of layer li on the `before` half: dy = d/dy of bn(y), parameter gradients straight into `grads`
+int run_bn_bwd(const vdqn_net* net, const vdqn_step_args* a, int li, const ActLayout& A, const void* g, const void* y, void* dy, int n,
+               hipStream_t st) {
+  const Layer& L = net->layers[li];
+  return vdqn_bn_train_bwd(g, y, dy, reinterpret_cast<float*>((unsigned char*)a->acts_online + A.bnw[li]), a->grads + L.g_off, a->grads + L.b_off,
+                           n, L.ho * L.wo, L.co, net->cfg.num_frames, n, net->cfg.dtype, st);
+}
+
+// 'basic': BasicBlock b with train-mode BatchNorm; g_o[b] holds the (ReLU-masked) gradient of the block output
+int block_backward_train(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayout& A, const BwdLayout& W, int n, hipStream_t st) {
+  const unsigned char* pk = (const unsigned char*)a->packed_online;
+  unsigned char* ao = (unsigned char*)a->acts_online;
+  unsigned char* bw = (unsigned char*)a->bwd;
+  const int i1 = net->l_b_conv1[b], i2 = net->l_b_conv2[b], ids = net->l_b_ds[b];
+  const Layer& c1 = net->layers[i1];
+  const Layer& c2 = net->layers[i2];
+  const unsigned char* x = b == 0 ? ao + A.pool : ao + A.o[b - 1];
+  unsigned char* gx = b == 0 ? bw + W.g_pool : bw + W.g_o[b - 1];
+  const void* g_out = bw + W.g_o[b];
+  RC(run_bn_bwd(net, a, i2, A, g_out, ao + A.r_o[b], bw + W.g_or[b], n, st));
+  hipStream_t ws = fork_side(net, st);
+  RC(run_wgrad(net, c2, bw, bw + W.g_or[b], ao + A.h[b], n, ws));
+  if (ids >= 0) {
+    RC(run_bn_bwd(net, a, ids, A, g_out, ao + A.r_ds[b], bw + W.g_dsr[b], n, st));
+    ws = fork_side(net, st);
+    RC(run_wgrad(net, net->layers[ids], bw, bw + W.g_dsr[b], x, n, ws));
+  }
+  RC(run_dgrad(net, c2, pk, bw + W.g_or[b], bw + W.g_h[b], n, nullptr, ao + A.h[b], st));
+  RC(run_bn_bwd(net, a, i1, A, bw + W.g_h[b], ao + A.r_h[b], bw + W.g_h[b], n, st));
+  ws = fork_side(net, st);
+  RC(run_wgrad(net, c1, bw, bw + W.g_h[b], x, n, ws));
+  const void* resid = g_out;
+  if (ids >= 0) {
+    RC(run_dgrad(net, net->layers[ids], pk, bw + W.g_dsr[b], bw + W.dsg[b], n, nullptr, nullptr, st));
+    resid = bw + W.dsg[b];
+  }
+  RC(run_dgrad(net, c1, pk, bw + W.g_h[b], gx, n, resid, x, st));
+  return VDQN_OK;
+}
+
 }  // namespace
 
 extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream) {
@@ -894,7 +1056,24 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
 
-  if (stage == 0) {
+  if (net->basic()) {
+    if (stage == 0) {
+      const Layer& top = net->layers[net->l_top4];
+      RC(run_wgrad(net, top, bw, bw + W.dq, ao + A.avg, B, fork_side(net, st), true));
+      RC(run_dgrad(net, top, pk, bw + W.dq, bw + W.g_avg, B, nullptr, nullptr, st));
+      RC(vdqn_avgpool_bwd(bw + W.g_avg, ao + A.o[7], bw + W.g_o[7], n, 49, 512, dt, st));
+      RC(block_backward_train(net, a, 7, A, W, n, st));
+      RC(block_backward_train(net, a, 6, A, W, n, st));
+    } else if (stage == 1) {
+      RC(block_backward_train(net, a, 5, A, W, n, st));
+      RC(block_backward_train(net, a, 4, A, W, n, st));
+    } else {
+      for (int b = 3; b >= 0; --b) RC(block_backward_train(net, a, b, A, W, n, st));
+      RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
+      RC(run_bn_bwd(net, a, net->l_conv1, A, bw + W.g_c1, ao + A.r_c1, bw + W.g_c1, n, st));
+      RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
+    }
+  } else if (stage == 0) {
     const Layer& t4 = net->layers[net->l_top4];
     const Layer& t2 = net->layers[net->l_top2];
     const Layer& t0 = net->layers[net->l_top0];
@@ -927,7 +1106,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   ProfScope ps_("unfold_grads", 0.0, (double)(net->stage_end[stage] - net->stage_begin[stage]) * 12.0, st);
   PartTable pt;
   memset(&pt, 0, sizeof(pt));
-  {
+  if (!net->basic()) {
     auto tiles = [](int64_t rows) { return (int)((rows + 127) / 128); };
     auto set = [&](int li, int64_t off, int64_t rows, int ld, int groups, int gstride) {
       if (li < 0) return;
@@ -950,7 +1129,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     }
   }
   hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, st, net->fold, pt, net->layer_stage_first[stage],
-                     a->params, a->bnstats, (const unsigned char*)bw, a->grads);
+                     a->params, a->bnstats, (const unsigned char*)bw, a->grads, net->basic() ? 1 : 0);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }

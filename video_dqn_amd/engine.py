@@ -56,12 +56,10 @@ class NetEngine:
         # point still requires the GPU and raises otherwise — there is no CPU arithmetic in this package.
         self.storage_only = device is not None and torch.device(device).type == "cpu"
         self.device = torch.device("cpu") if self.storage_only else require_gpu(device)
-        if not extra_capacity:
-            raise NotImplementedError("ARCHITECTURE='basic' (BatchNorm in train mode) is not implemented yet; "
-                                      "use ARCHITECTURE: 'extra_capacity' (configs/experiments/real_data)")
+        self.extra_capacity = bool(extra_capacity)
         self.action_dim, self.num_classes, self.num_frames = action_dim, num_classes, num_frames
         self.dtype_name = "bf16" if DTYPES[dtype] == _lib.VDQN_BF16 else "f32"
-        self.cfg = _lib.NetConfig(action_dim, num_classes, num_frames, 1, DTYPES[dtype], max_batch)
+        self.cfg = _lib.NetConfig(action_dim, num_classes, num_frames, int(self.extra_capacity), DTYPES[dtype], max_batch)
         h = C.c_void_p()
         _lib.check(self.lib.vdqn_net_create(C.byref(self.cfg), C.byref(h)), "vdqn_net_create")
         self.handle = h
@@ -79,6 +77,9 @@ class NetEngine:
         self.packed_bytes = self.lib.vdqn_net_packed_bytes(h)
         self.params = torch.zeros(self.params_numel, dtype=torch.float32, device=self.device)
         self.bnstats = torch.zeros(self.bnstats_numel, dtype=torch.float32, device=self.device)
+        # BatchNorm.num_batches_tracked of the 20 BatchNorm layers (only ever advanced by ARCHITECTURE='basic',
+        # whose BatchNorm layers run in train mode)
+        self.num_batches_tracked = torch.zeros(20, dtype=torch.long, device=self.device)
         self.packed = None if self.storage_only else torch.zeros(self.packed_bytes, dtype=torch.uint8, device=self.device)
         self._packed_version = -1
         self._version = 0
@@ -155,6 +156,24 @@ class NetEngine:
                                                  _ptr(acts), _ptr(q), _stream()), "vdqn_net_forward")
         return q
 
+    def forward_train(self, frames: torch.Tensor, src_kind: int, n_samples: int) -> torch.Tensor:
+        """ARCHITECTURE='basic' with the module in train mode: batch statistics per frame slot, running statistics and
+        num_batches_tracked updated (one model call, archs/HabitatDQNMultiAction.py:44-54 under model.train())."""
+        self._need_gpu()
+        if self.extra_capacity:
+            raise _lib.VdqnError("forward_train: extra_capacity keeps BatchNorm in eval mode; use forward()")
+        if n_samples > self.max_batch:
+            raise _lib.VdqnError(f"batch {n_samples} exceeds max_batch {self.max_batch}")
+        with torch.cuda.device(self.device):
+            q = torch.empty((n_samples, self.num_classes * self.action_dim), dtype=torch.float32, device=self.device)
+            acts = self._acts_for(n_samples)
+            self._packed_version = -1  # self.packed now holds the un-folded weights
+            _lib.check(self.lib.vdqn_net_forward_train(self.handle, _ptr(self.params), _ptr(self.bnstats), _ptr(self.packed),
+                                                       _ptr(frames), src_kind, n_samples, _ptr(acts), _ptr(q), _stream()),
+                       "vdqn_net_forward_train")
+            self.num_batches_tracked += self.num_frames
+        return q
+
 
 class TDStepper:
     """Device state of the training loop: target-network weights, Adam moments, workspaces, and one TD update.
@@ -225,6 +244,9 @@ class TDStepper:
             a = self._args(before, after, src_kind, act, rew, term, valid if valid is not None else self._ones, gt)
             st = _stream()
             _lib.check(self.lib.vdqn_net_td_forward(n.handle, C.byref(a), st), "vdqn_net_td_forward")
+            if not n.extra_capacity:  # train-mode BatchNorm: model(before) [+ model(after)], F feature calls each
+                n.num_batches_tracked += (1 if self.gtb else 2) * n.num_frames
+                n.mark_dirty()  # the running statistics changed: eval-mode packed weights are stale
             for stage in range(3):
                 _lib.check(self.lib.vdqn_net_backward_stage(n.handle, C.byref(a), stage, st), "vdqn_net_backward_stage")
                 if self.allreduce is not None:

@@ -9,8 +9,9 @@ Mirrors ``archs/HabitatDQNMultiAction.py:8-54`` and the factory/loader of ``trai
     loader produces) and returns ``float32[B,5,A]``; raises ``Exception("bad shape")`` on a frame-count
     mismatch (:47-48).  Extension: a uint8 ``[B,(F,)224,224,3]`` tensor is normalised on the GPU inside the
     input-packing kernel (``util/torch.py:26-36`` semantics);
-  * ``set_train()`` / ``eval()`` / ``train()`` only set flags: in ``extra_capacity`` every BatchNorm layer runs on
-    its running statistics in both modes (:37-40), which is what the engine implements.
+  * ``set_train()`` / ``eval()`` / ``train()`` set flags: in ``extra_capacity`` every BatchNorm layer runs on its
+    running statistics in both modes (:37-40); in ``basic`` a forward in train mode normalises with batch statistics
+    per frame slot and updates ``running_mean/var`` and ``num_batches_tracked`` like torch's BatchNorm2d.
 
 The module's parameters and BatchNorm buffers are *views* into the engine's flat device arrays, so
 ``load_state_dict`` writes straight into what the kernels read; there is no autograd graph — gradients come
@@ -103,6 +104,7 @@ class HabitatDQNMultiAction(nn.Module):
     def _build_tree(self):
         eng = self.engine
         cache = {}
+        bn_count = [0]
 
         def P(name):
             if name not in cache:
@@ -114,7 +116,8 @@ class HabitatDQNMultiAction(nn.Module):
             m.weight, m.bias = P(name + ".weight"), P(name + ".bias")
             m.register_buffer("running_mean", eng.view(name + ".running_mean"))
             m.register_buffer("running_var", eng.view(name + ".running_var"))
-            m.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long, device=eng.device))
+            m.register_buffer("num_batches_tracked", eng.num_batches_tracked[bn_count[0]])  # 0-dim view
+            bn_count[0] += 1
             return m
 
         resnet = _Holder()
@@ -143,11 +146,14 @@ class HabitatDQNMultiAction(nn.Module):
         resnet.avgpool = _Stateless()
         resnet.fc = _conv(P, "resnet.fc", has_bias=True)
         self.resnet = resnet
-        # archs/HabitatDQNMultiAction.py:30-31
-        self.features = nn.Sequential(*list(self.resnet.children())[:-2], _conv(P, "features.8", has_bias=True),
-                                      _Stateless(), _Stateless())
-        self.top = nn.Sequential(_conv(P, "top.0", True), _Stateless(), _conv(P, "top.2", True), _Stateless(),
-                                 _conv(P, "top.4", True))
+        if self.extra_capacity:  # archs/HabitatDQNMultiAction.py:30-31
+            self.features = nn.Sequential(*list(self.resnet.children())[:-2], _conv(P, "features.8", has_bias=True),
+                                          _Stateless(), _Stateless())
+            self.top = nn.Sequential(_conv(P, "top.0", True), _Stateless(), _conv(P, "top.2", True), _Stateless(),
+                                     _conv(P, "top.4", True))
+        else:  # :33-34
+            self.features = nn.Sequential(*list(self.resnet.children())[:-1])
+            self.top = _conv(P, "top", True)
 
     # ---- reference surface ----------------------------------------------------------------------------
     def set_train(self):  # :37-40
@@ -191,7 +197,10 @@ class HabitatDQNMultiAction(nn.Module):
         if b > eng.max_batch:
             outs = [self.forward(inp[i:i + eng.max_batch]) for i in range(0, b, eng.max_batch)]
             return torch.cat(outs, 0)
-        q = eng.forward(inp, src_kind, b)
+        if self.training and not self.extra_capacity:  # the ResNet's BatchNorm layers are in train mode (:37-40)
+            q = eng.forward_train(inp, src_kind, b)
+        else:
+            q = eng.forward(inp, src_kind, b)
         return q.view((-1, self.num_classes, self.action_dim))
 
 

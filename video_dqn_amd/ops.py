@@ -135,3 +135,49 @@ def gt_loss(q_before, act, gt, *, n_cat=5, n_act=3, inv_count=None, value_learni
 def adam(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     lib = _lib.load()
     _lib.check(lib.vdqn_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, lr, beta1, beta2, eps, _stream()), "vdqn_adam")
+
+
+def bn_train_fwd(y: torch.Tensor, gamma, beta, running_mean=None, running_var=None, *, resid=None, relu=False,
+                 num_frames=1, imgs_per_half=None, momentum=0.1, eps=1e-5):
+    """Train-mode BatchNorm2d over NHWC y [n, h, w, c] (statistic groups: see include/vdqn.h).
+    Returns (z, work) — `work` f32 [groups, 6, c] is what bn_train_bwd needs."""
+    lib = _lib.load()
+    n, h, w, c = y.shape
+    iph = n if imgs_per_half is None else imgs_per_half
+    groups = n // iph * num_frames
+    z = torch.empty_like(y)
+    work = torch.zeros((groups, 6, c), dtype=torch.float32, device=y.device)
+    _lib.check(lib.vdqn_bn_train_fwd(_ptr(y), _ptr(resid), _ptr(z), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                     _ptr(work), n, h * w, c, num_frames, iph, int(relu), momentum, eps, dtype_code(y), _stream()),
+               "vdqn_bn_train_fwd")
+    return z, work
+
+
+def bn_train_bwd(g: torch.Tensor, y: torch.Tensor, work: torch.Tensor, *, num_frames=1, imgs_per_half=None):
+    """Returns (dy, dgamma, dbeta) for the BatchNorm whose forward filled `work`."""
+    lib = _lib.load()
+    n, h, w, c = y.shape
+    iph = n if imgs_per_half is None else imgs_per_half
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    _lib.check(lib.vdqn_bn_train_bwd(_ptr(g), _ptr(y), _ptr(dy), _ptr(work), _ptr(dgamma), _ptr(dbeta), n, h * w, c, num_frames, iph,
+                                     dtype_code(y), _stream()), "vdqn_bn_train_bwd")
+    return dy, dgamma, dbeta
+
+
+def avgpool_fwd(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    n, h, w, c = x.shape
+    out = torch.empty((n, c), dtype=x.dtype, device=x.device)
+    _lib.check(lib.vdqn_avgpool_fwd(_ptr(x), _ptr(out), n, h * w, c, dtype_code(x), _stream()), "vdqn_avgpool_fwd")
+    return out
+
+
+def avgpool_bwd(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """g [n, c]; x [n, h, w, c] (post-ReLU input of the pool): gx = (x > 0) * g / (h*w)."""
+    lib = _lib.load()
+    n, h, w, c = x.shape
+    gx = torch.empty_like(x)
+    _lib.check(lib.vdqn_avgpool_bwd(_ptr(g), _ptr(x), _ptr(gx), n, h * w, c, dtype_code(x), _stream()), "vdqn_avgpool_bwd")
+    return gx
