@@ -69,6 +69,33 @@ def main():
                 out[f"{k}_gnorm_{n}"] = np.array(g.double().norm().item())
                 out[f"{k}_gabsmax_{n}"] = np.array(g.abs().max().item())
                 out[f"{k}_gsamp_{n}"] = g[idx].numpy()
+            if step == 1:
+                # the same update by the same reference code in float64: how far the reference's OWN fp32 run is from
+                # exact arithmetic (train-mode BatchNorm makes a ReLU sign flip non-local) — the yardstick of the GPU gate
+                m64 = RefModel(3, 5, extra_capacity=False, panorama=pano)
+                m64.load_state_dict(sd)
+                t64 = RefModel(3, 5, extra_capacity=False, panorama=pano)
+                t64.load_state_dict(synth.make_state_dict(8, extra_capacity=False, num_frames=F))
+                m64.double()
+                t64.double().eval()
+                m64.set_train()
+                tup64 = (tup[0].double(), tup[1].double()) + tuple(tup[2:])
+                pb_factory(m64, t64, cfg)(tup64, compare_ground_truth=False, batch_number=1).backward()
+                e_max, e_l2 = 0.0, 0.0
+                g32 = dict(model.named_parameters())
+                for n, p in m64.named_parameters():
+                    if p.grad is None:
+                        continue
+                    g = p.grad.detach().flatten()
+                    out[f"{k}_gsamp64_{n}"] = g[sample_idx(n, g.numel())].numpy()
+                    out[f"{k}_gnorm64_{n}"] = np.array(g.norm().item())
+                    out[f"{k}_gabsmax64_{n}"] = np.array(g.abs().max().item())
+                    d = g32[n].grad.detach().flatten().double() - g
+                    e_max = max(e_max, (d.abs().max() / g.abs().max()).item())
+                    e_l2 = max(e_l2, (d.norm() / g.norm()).item())
+                out[f"{k}_ref32_vs_ref64_worst_max"] = np.array(e_max)
+                out[f"{k}_ref32_vs_ref64_worst_l2"] = np.array(e_l2)
+                print(tag, "reference fp32 vs fp64: worst max-err", e_max, "worst l2-err", e_l2)
             opt.step()  # :227
             for n, p in model.named_parameters():
                 out[f"{k}_psamp_{n}"] = p.detach().flatten()[sample_idx(n, p.numel())].numpy()

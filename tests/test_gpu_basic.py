@@ -163,17 +163,24 @@ def _basic_steps(dtype, F, B, steps, pano):
 @pytest.mark.parametrize("tag,pano,F,B,steps", [("F1", False, 1, 6, 2), ("F4", True, 4, 3, 1)])
 def test_basic_td_steps_match_reference_golden_f32(golden_basic, tag, pano, F, B, steps):
     """Full updates of ARCHITECTURE='basic' against G5 (reference class + reference process_batch + torch Adam): loss, Q(s),
-    every parameter's gradient (norm 1e-3 strict on step 1, sampled elements), post-Adam parameters, running statistics,
-    num_batches_tracked.  Batch-statistics BatchNorm couples all activations of a group, so a ReLU flip is not local;
-    the sampled-element gate is the same 3e-3-of-max as in the extra_capacity test."""
+    running statistics, num_batches_tracked at 1e-3; gradients and post-Adam parameters as follows.
+
+    With batch-statistics BatchNorm a ReLU whose pre-activation rounds to the other side of zero changes the statistics of
+    its whole group, so two fp32 implementations differ by more than 1e-3 in some gradient tensors — the reference's own
+    fp32 run is 1.8e-2 .. 3.9e-2 (max-error) away from the same code run in float64 (stored in the golden file by
+    make_golden_basic.py as ref32_vs_ref64_worst_*).  The gate therefore measures the engine against the reference's
+    float64 gradients and requires it to be as close as 1e-3/5e-3 or as close as 1.5x the reference's own fp32 run."""
     g = golden_basic
     net, out = _basic_steps("f32", F, B, steps, pano)
     lr = 1e-4
+    e_max, e_l2 = float(g[f"g5_{tag}_s1_ref32_vs_ref64_worst_max"]), float(g[f"g5_{tag}_s1_ref32_vs_ref64_worst_l2"])
+    tol_elem, tol_norm = max(5e-3, 1.5 * e_max), max(1e-3, 1.5 * e_l2)
     for step, o in enumerate(out, start=1):
         k = f"g5_{tag}_s{step}"
         np.testing.assert_allclose(o["loss"], float(g[f"{k}_loss"]), rtol=1e-3)
         assert relerr(o["q_before"], torch.from_numpy(g[f"{k}_qbefore"]).reshape(B, 15)) < 1e-3
         assert int(o["nbt"][0]) == int(o["nbt"][-1]) == 2 * F * step
+        tight = []
         for name, s in net.slots.items():
             if s.kind in (2, 3):
                 got = o["bnstats"][s.offset:s.offset + s.numel]
@@ -182,15 +189,51 @@ def test_basic_td_steps_match_reference_golden_f32(golden_basic, tag, pano, F, B
                 continue
             gr = o["grads"][s.offset:s.offset + s.numel]
             idx = synth.randint(1234, "idx." + name, (min(16, s.numel),), s.numel)
-            amax = float(g[f"{k}_gabsmax_{name}"])
             pdiff = np.abs(o["params"][s.offset:s.offset + s.numel][idx].numpy() - g[f"{k}_psamp_{name}"])
             if step == 1:
-                assert np.abs(gr[idx].numpy() - g[f"{k}_gsamp_{name}"]).max() <= 3e-3 * amax + 1e-12, (step, name)
-                np.testing.assert_allclose(gr.double().norm().item(), float(g[f"{k}_gnorm_{name}"]), rtol=1e-3, err_msg=name)
-                assert pdiff.max() <= 0.02 * lr + 1e-9, (step, name)
+                amax = float(g[f"{k}_gabsmax64_{name}"])
+                assert np.abs(gr[idx].double().numpy() - g[f"{k}_gsamp64_{name}"]).max() <= tol_elem * amax + 1e-12, (step, name)
+                np.testing.assert_allclose(gr.double().norm().item(), float(g[f"{k}_gnorm64_{name}"]), rtol=tol_norm, err_msg=name)
+                assert pdiff.max() <= 2.5 * lr, (step, name)  # first Adam step = lr * sign(g): at most one sign flip
+                tight.append(pdiff <= 0.02 * lr + 1e-9)
             else:  # trajectory check (see test_gpu_engine.py::test_td_steps_match_reference_golden_f32)
                 np.testing.assert_allclose(gr.double().norm().item(), float(g[f"{k}_gnorm_{name}"]), rtol=5e-2, err_msg=name)
                 assert pdiff.max() <= 2.5 * lr * step, (step, name)
+        if step == 1:
+            assert np.concatenate(tight).mean() >= 0.99
+
+
+@pytest.mark.parametrize("F,B", [(1, 6), (4, 3)])
+def test_basic_td_step_all_elements_vs_oracle_f32(F, B):
+    """Every gradient element of one update against the oracle run live in float64 and float32 on the host: the engine's
+    distance to the float64 gradients must be within 1e-3 (L2) / 5e-3 (max) or within 1.5x the fp32 oracle's own distance."""
+    from oracle import ref_cpu
+    net, out = _basic_steps("f32", F, B, 1, F > 1)
+    cfg = ref_cpu.default_config(ARCHITECTURE="basic", PANORAMA=F > 1)
+    (tup, _) = synth.make_batch(400 + 10 * F + 1, B, F, structured=True, reward_p=0.3)
+    grads = {}
+    for prec in (torch.float32, torch.float64):
+        tr = ref_cpu.Trainer(cfg, synth.make_state_dict(7, extra_capacity=False, num_frames=F), num_frames=F)
+        tr.target_net.load_state_dict(synth.make_state_dict(8, extra_capacity=False, num_frames=F))
+        tr.model.to(prec)
+        tr.target_net.to(prec)
+        tr.model.set_train()
+        loss = ref_cpu.process_batch(tr.model, tr.target_net, cfg, (tup[0].to(prec), tup[1].to(prec)) + tuple(tup[2:]))
+        loss.backward()
+        grads[prec] = {n: p.grad.double() for n, p in tr.model.named_parameters() if p.grad is not None}
+        assert abs(out[0]["loss"] - loss.item()) <= 1e-4 * abs(loss.item())
+    worst = dict(eng_max=0.0, eng_l2=0.0, ref_max=0.0, ref_l2=0.0)
+    for name, r in grads[torch.float64].items():
+        s = net.slots[name]
+        ge = out[0]["grads"][s.offset:s.offset + s.numel].view(s.shape).double()
+        g32 = grads[torch.float32][name]
+        worst["eng_max"] = max(worst["eng_max"], ((ge - r).abs().max() / r.abs().max()).item())
+        worst["eng_l2"] = max(worst["eng_l2"], ((ge - r).norm() / r.norm()).item())
+        worst["ref_max"] = max(worst["ref_max"], ((g32 - r).abs().max() / r.abs().max()).item())
+        worst["ref_l2"] = max(worst["ref_l2"], ((g32 - r).norm() / r.norm()).item())
+    print("worst gradient error vs float64:", worst)
+    assert worst["eng_max"] <= max(5e-3, 1.5 * worst["ref_max"]), worst
+    assert worst["eng_l2"] <= max(1e-3, 1.5 * worst["ref_l2"]), worst
 
 
 def test_basic_td_step_bf16_direction_and_scale():
