@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
     ap.add_argument("--frames", type=int, default=1, help="views per sample (12 = BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--arch", default="extra_capacity", choices=["extra_capacity", "basic"],
+                    help="ARCHITECTURE key (north_star / real_data config: extra_capacity; defaults.py: basic)")
     ap.add_argument("--target-update-interval", type=int, default=1000)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,12 +84,12 @@ def cpu_baseline(batch: int, budget_s: float = 25.0):
             "multi_threads": threads, "host_cores_visible": avail}
 
 
-def pmc_traffic(kernel: str, batch: int, frames: int, dtype: str):
+def pmc_traffic(kernel: str, batch: int, frames: int, dtype: str, arch: str = "extra_capacity"):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_latest.json: rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes).
     PMC collection cannot run inside this process; the figure is only quoted for the configuration it was
     collected on (batch 256, 1 frame, bf16), otherwise null."""
-    if (batch, frames, dtype) != (256, 1, "bf16"):
+    if (batch, frames, dtype, arch) != (256, 1, "bf16", "extra_capacity"):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
@@ -120,8 +122,9 @@ def main():
     from video_dqn_amd.dist import BucketAllReduce
 
     B, F = args.batch, args.frames
-    net = NetEngine(3, 5, F, True, args.dtype, 2 * B, device=dev)
-    net.load_tensors(synth.make_state_dict(4, num_frames=F))  # same seed on every rank: replicas start identical
+    ec = args.arch == "extra_capacity"
+    net = NetEngine(3, 5, F, ec, args.dtype, 2 * B, device=dev)
+    net.load_tensors(synth.make_state_dict(4, extra_capacity=ec, num_frames=F))  # same seed on every rank: replicas start identical
     comm = BucketAllReduce(world) if world > 1 else None
     stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=args.target_update_interval,
                     world_size=world, allreduce=(comm.launch if comm else None))
@@ -190,7 +193,7 @@ def main():
         if v["flops"] > 0:
             ach = v["flops"] / v["ms"] / 1e9
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B, F, args.dtype),
+                        "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B, F, args.dtype, args.arch),
                         "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
                         "alg_flops_per_launch": round(v["flops"] / v["launches"]),
                         "alg_bytes_per_launch": round(v["bytes"] / v["launches"]),
@@ -210,7 +213,7 @@ def main():
             "value": round(value, 2), "unit": "tuples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "HabitatDQNMultiAction ResNet-18 extra_capacity, 5 categories x 3 actions, full TD update "
+            "config": {"workload": f"HabitatDQNMultiAction ResNet-18 {args.arch}, 5 categories x 3 actions, full TD update "
                                    "(online fwd on [s;s'], target fwd on s', Double-DQN target + L2 TD loss, backward, Adam)",
                        "batch_per_gpu": B, "global_batch": B * world, "frames_per_sample": F, "frame": "224x224x3 uint8 (normalise fused)",
                        "parallelism": f"dp{world}", "target_update_interval": args.target_update_interval,

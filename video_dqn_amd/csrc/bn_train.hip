@@ -46,36 +46,43 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ a, c
     mu[e] = MODE == 1 ? wk[cg * E16 + e] : 0.f;
     rs[e] = MODE == 1 ? wk[C + cg * E16 + e] : 0.f;
   }
-  if (stripe < nstripe && r0 + stripe < r1) {
-    int j = r0 + stripe;
-    int smp = j / gm.hw, p = j - smp * gm.hw;
+  if (stripe < nstripe) {
     const int smp_half = gm.iph / gm.frames;
-    for (; j < r1; j += nstripe) {
-      const size_t row = ((size_t)(half * smp_half + smp) * gm.frames + f) * gm.hw + p;
-      const uint4 va = *reinterpret_cast<const uint4*>(a + row * C + cg * E16);
+    // row of the j-th pixel of this group (contiguous when there is one frame slot)
+    auto row_of = [&](int j) -> size_t {
+      if (gm.frames == 1) return (size_t)half * gm.grp_rows + j;
+      const int smp = j / gm.hw, p = j - smp * gm.hw;
+      return ((size_t)(half * smp_half + smp) * gm.frames + f) * gm.hw + p;
+    };
+    auto accum = [&](const uint4& va, const uint4& vy) {
       const T* pa = reinterpret_cast<const T*>(&va);
-      if (MODE == 0) {
+      const T* py = reinterpret_cast<const T*>(&vy);
 #pragma unroll
-        for (int e = 0; e < E16; ++e) {
-          const float v = to_f32<T>(pa[e]);
-          s1[e] += v;
-          s2[e] += v * v;
-        }
-      } else {
-        const uint4 vy = *reinterpret_cast<const uint4*>(y + row * C + cg * E16);
-        const T* py = reinterpret_cast<const T*>(&vy);
+      for (int e = 0; e < E16; ++e) {
+        const float v = to_f32<T>(pa[e]);
+        s1[e] += v;
+        s2[e] += MODE == 0 ? v * v : v * (to_f32<T>(py[e]) - mu[e]) * rs[e];
+      }
+    };
+    constexpr int U = 4;  // independent 16-byte loads in flight per thread
+    int j = r0 + stripe;
+    for (; j + (U - 1) * nstripe < r1; j += U * nstripe) {
+      uint4 va[U], vy[U];
 #pragma unroll
-        for (int e = 0; e < E16; ++e) {
-          const float g = to_f32<T>(pa[e]);
-          s1[e] += g;
-          s2[e] += g * (to_f32<T>(py[e]) - mu[e]) * rs[e];
-        }
+      for (int u = 0; u < U; ++u) {
+        const size_t row = row_of(j + u * nstripe);
+        va[u] = *reinterpret_cast<const uint4*>(a + row * C + cg * E16);
+        if (MODE == 1) vy[u] = *reinterpret_cast<const uint4*>(y + row * C + cg * E16);
+        else vy[u] = va[u];
       }
-      p += nstripe;
-      while (p >= gm.hw) {
-        p -= gm.hw;
-        ++smp;
-      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accum(va[u], vy[u]);
+    }
+    for (; j < r1; j += nstripe) {
+      const size_t row = row_of(j);
+      const uint4 va = *reinterpret_cast<const uint4*>(a + row * C + cg * E16);
+      const uint4 vy = MODE == 1 ? *reinterpret_cast<const uint4*>(y + row * C + cg * E16) : va;
+      accum(va, vy);
     }
   }
 #pragma unroll
@@ -245,8 +252,8 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
 }
 
 inline int grid_rows(int M, int* rpb) {
-  int blocks = (M + 511) / 512;
-  if (blocks > 512) blocks = 512;
+  int blocks = (M + 511) / 512;  // measured: more, smaller blocks lose to the per-block reduction + atomics
+  if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   *rpb = (M + blocks - 1) / blocks;
   return blocks;
