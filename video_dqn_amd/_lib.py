@@ -145,7 +145,7 @@ def profile_enable(on: bool) -> None:
 
 def profile_collect():
     """-> {kernel: dict(launches, ms, flops, bytes)}; synchronises the recorded events and resets."""
-    buf = (ProfEntry * 64)()
-    n = load().vdqn_profile_collect(buf, 64)
+    buf = (ProfEntry * 256)()
+    n = load().vdqn_profile_collect(buf, 256)
     return {buf[i].name.decode(): dict(launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops, bytes=buf[i].bytes)
             for i in range(n)}

@@ -63,6 +63,7 @@ void vdqn_set_error(const char* fmt, ...);
 void vdqn_prof_begin(const char* tag, double flops, double bytes, hipStream_t st);
 void vdqn_prof_end(hipStream_t st);
 extern thread_local double g_prof_alg_flops;  // engine sets the algorithmic FLOPs of the next launch (padding excluded)
+extern thread_local const char* g_prof_suffix;  // engine: per-layer profile rows when VDQN_PROFILE_LAYERS=1
 struct ProfScope {
   hipStream_t st;
   ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : st(s) { vdqn_prof_begin(tag, flops, bytes, s); }

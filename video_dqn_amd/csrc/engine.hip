@@ -619,6 +619,17 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
 // ---------------------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------
+// per-layer rows in the launch profiler (VDQN_PROFILE_LAYERS=1): "<kernel>|<layer> n<images>"
+void prof_layer(const Layer& L, int n_units) {
+  static const bool on = [] { const char* e = getenv("VDQN_PROFILE_LAYERS"); return e && e[0] == '1'; }();
+  if (!on) return;
+  static thread_local char buf[64];
+  const char* nm = L.name.c_str();
+  if (strncmp(nm, "resnet.", 7) == 0) nm += 7;
+  snprintf(buf, sizeof(buf), "%s n%d", nm, n_units);
+  g_prof_suffix = buf;
+}
+
 int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* in, void* out, int n_units, const void* resid,
              int relu, float* out_f32, hipStream_t st) {
   vdqn_conv_args a;
@@ -637,6 +648,7 @@ int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, c
   a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
   a.mode = 0; a.relu = relu; a.dtype = net->cfg.dtype;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
+  prof_layer(L, n_units);
   return vdqn_conv2d(&a, st);
 }
 
@@ -657,6 +669,7 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
   a.r = L.k_r; a.s = L.k_s; a.stride = L.stride; a.pad = L.pad;
   a.mode = 1; a.relu = 0; a.dtype = net->cfg.dtype;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
+  prof_layer(L, n_units);
   return vdqn_conv2d(&a, st);
 }
 
@@ -675,6 +688,7 @@ int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const voi
   a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
   a.splitk = 0; a.dtype = net->cfg.dtype;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
+  prof_layer(L, n_units);
   return vdqn_conv2d_wgrad(&a, st);
 }
 

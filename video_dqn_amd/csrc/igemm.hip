@@ -7,14 +7,18 @@
 //   `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB = 8 tile rows per wave-instruction): no staging VGPRs, no
 //   ds_write.  Padding taps and rows past M need no branch: their lane offset is set out of the buffer
 //   descriptor's range and the hardware writes zeros into LDS (probed: tools/probes/lds_dma_oob.hip).
-// * Tiles: 128 (M) x BN (N, 64 or 128) x 128 bytes (K); 256 threads = 4 waves in a 2x2 grid, each wave owns
-//   64 x BN/2 as 16x16 MFMA fragments (v_mfma_f32_16x16x32_bf16, or v_mfma_f32_16x16x4_f32 in the exact
-//   f32 parity mode — same staging code, only the MFMA differs).
+// * Tiles: BM (128 | 256) x BN (64 | 128) x 128 bytes of K; a (BM/64) x WN grid of waves, each owning 64 x BN/WN as
+//   16x16 MFMA fragments (v_mfma_f32_16x16x32_bf16, or v_mfma_f32_16x16x4_f32 in the exact f32 parity mode — same
+//   staging code, only the MFMA differs).
 // * LDS: rows of 128 B; the DMA image is lane-linear, so the bank-conflict swizzle is applied on the SOURCE:
-//   lane (row, p) fetches logical chunk p ^ (row & 7) and fragment reads XOR the same term.  Two buffers;
-//   the DMA of step k+1 is in flight while step k's MFMAs run; one barrier per K-step.
-// * Epilogue: accumulators -> LDS (f32) -> 16-byte vector loads of bias/residual/mask and 16-byte stores
-//   (whole 128/256-byte output rows per 8/16 lanes).
+//   lane (row, p) fetches logical chunk p ^ key(row) and fragment reads XOR the same term.  Two LDS buffers and two
+//   register sets of fragments: the DMA of tile k+2 and the ds_reads of tile k+1 are both in flight underneath the
+//   MFMAs of tile k; one barrier per K-step, no LDS wait in front of any MFMA.
+// * The weights are the MFMA's FIRST operand, so the accumulator lane (i16, g) holds 4 consecutive output channels of
+//   pixel i16; the weight fragment rows are read in a permuted order (channel g*4NF + j*4 + r from fragment j) so that a
+//   lane's NF fragments are 4*NF CONSECUTIVE channels.  The epilogue therefore needs no LDS transpose: every lane adds
+//   bias / residual, applies ReLU / mask and stores 16..64 contiguous bytes; 4 lanes cover a whole output row of the
+//   wave's tile (full 128-byte lines), and all residual/mask loads of a lane are issued before the first is used.
 // * blockIdx is remapped so the N-tiles of one M-tile run on the same XCD (A rows stay in that XCD's L2).
 //
 // Reference call sites this serves: the torch conv2d/linear (+BatchNorm eval, ReLU, residual) launched
@@ -23,13 +27,10 @@
 
 #include "common.h"
 
-#ifndef VDQN_IGEMM_STAGES
-#define VDQN_IGEMM_STAGES 2
-#endif
-
 namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmParams {
   const void* in;
@@ -52,20 +53,24 @@ constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (
 
 // MODE 0: forward gather (h = oh*stride - pad + kr); 1: dgrad, stride 1 (h = oh + pad - kr);
 //      2: dgrad, stride 2 (h = (oh + pad - kr) / 2 when even)
-template <typename T, int BM, int BN, int MODE, int NSTAGE>
-__global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igemm_kernel(const IgemmParams p) {
-  constexpr int NT = 2 * BM;    // threads: BM/64 x 2 waves, each owning 64 x BN/2 (BM = 256 is used for the 64-column
-                                // layers: 16 waves per CU and half the weight traffic per MFMA)
+// WN = waves along N.  256 x 64 tiles with WN = 1 give the 64-output-channel layers the same 64x64 wave tile (16 MFMAs
+// per 8 fragment reads) as the 128x128 kernel.
+template <typename T, int BM, int BN, int MODE, int WN>
+__global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) {
+  constexpr int NT = BM * WN;   // threads: BM/64 x WN waves, each owning 64 x BN/WN
   constexpr int RPS = NT / 8;   // tile rows staged per pass (8 lanes x 16 B per 128-byte row)
   constexpr int ESZ = (int)sizeof(T);
   constexpr int KC = 128 / ESZ;
-  constexpr int NF = BN / 32;
+  constexpr int NF = BN / (16 * WN);  // weight fragments per wave
+  constexpr int CPL = 4 * NF;         // consecutive output channels a lane ends up with
   constexpr int BROWS = BN / RPS;
+  constexpr int AROWS = BM / RPS;  // A rows staged per thread (4 or 8)
+  static_assert(AROWS == 4 || AROWS == 8, "A staging is issued in groups of four pieces");
+  static_assert(NF == 2 || NF == 4, "wave tile is 64 x 32 or 64 x 64");
   constexpr int PSTR = RPS * 128;  // LDS byte distance between a thread's consecutive DMA pieces
-  constexpr int LDC = BN + 4;  // f32 row stride of the epilogue tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
-  unsigned char* sB = smem + NSTAGE * BM * 128;
+  unsigned char* sB = smem + 2 * BM * 128;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -90,8 +95,12 @@ __global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igem
   const int row_w = MODE == 2 ? p.cls_w[cls_pw] : p.wo;
   const int pix_per_img = MODE == 2 ? p.cls_h[cls_ph] * row_w : p.howo;
   const int rows_total = MODE == 2 ? p.n_img * pix_per_img : p.M;
-  const int lrow = tid >> 3;                        // tile row this thread stages (+32 i)
-  const int lchunk = (tid & 7) ^ (lrow & 7);        // logical 16-byte chunk it fetches (source-side swizzle)
+  const int lrow = tid >> 3;  // tile row this thread stages (+RPS i)
+  // logical 16-byte chunk it fetches (source-side swizzle).  A rows are read by lanes i16 = row & 15: key = row & 7.
+  // Weight rows are read in the permuted order row(j, i16) = (i16 >> 2) * CPL + j * 4 + (i16 & 3); the key that is
+  // again i16 & 7 for the reading lane is ((row / CPL) & 1) * 4 + (row & 3).
+  const int lchunk_a = (tid & 7) ^ (lrow & 7);
+  const int lchunk_b = (tid & 7) ^ ((((lrow / CPL) & 1) << 2) | (lrow & 3));
 
   // ---- buffer descriptors (4 SGPRs each): A relative to the first image of this tile, B = whole weight tensor.
   // The DMA is issued from inline asm: hipcc would otherwise wait vmcnt(0) before the first ds_read that follows
@@ -108,12 +117,12 @@ __global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igem
   const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
                       __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
 
-  // ---- per-row gather state (4 A rows per thread) ----
-  uint32_t a_off[4];
-  int a_hb[4], a_wb[4];
+  // ---- per-row gather state (AROWS A rows per thread) ----
+  uint32_t a_off[AROWS];
+  int a_hb[AROWS], a_wb[AROWS];
   const int pixB = p.pix_stride * ESZ;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < AROWS; ++i) {
     const int m = m0 + lrow + RPS * i;
     const bool ok = m < rows_total;
     const int mm = ok ? m : m0;
@@ -137,26 +146,35 @@ __global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igem
       hq = MODE == 2 ? (hb >> 1) : hb;
       wq = MODE == 2 ? (wb >> 1) : wb;
     }
-    a_off[i] = (uint32_t)(((img - img0) * p.hi + hq) * p.wi + wq) * (uint32_t)pixB + (uint32_t)(lchunk * 16);
+    a_off[i] = (uint32_t)(((img - img0) * p.hi + hq) * p.wi + wq) * (uint32_t)pixB + (uint32_t)(lchunk_a * 16);
     a_hb[i] = ok ? hb : -(1 << 20);
     a_wb[i] = wb;
   }
   uint32_t b_off[BROWS];
 #pragma unroll
-  for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + RPS * i) * (uint32_t)(p.ktot * ESZ) + (uint32_t)(lchunk * 16);
+  for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + RPS * i) * (uint32_t)(p.ktot * ESZ) + (uint32_t)(lchunk_b * 16);
 
-  // LDS byte addresses (wave-uniform) of this wave's DMA pieces: piece i of an operand covers tile rows 32 i + 8 wave .. +7
+  // LDS byte addresses (wave-uniform) of this wave's DMA pieces: piece i of an operand covers tile rows RPS i + 8 wave .. +7
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const uint32_t lds_wave = lds_base + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (8 * 128);
 
+#define VDQN_DMA4(V0, V1, V2, V3, LDS, RSRC, SOFF)                                                                  \
+  asm volatile(                                                                                                     \
+      "s_nop 4\n\t"                                                                                                 \
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, %6 offen lds\n\t"                                \
+      "s_add_u32 m0, %4, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"                            \
+      "s_add_u32 m0, %4, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"                            \
+      "s_add_u32 m0, %4, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                                 \
+      ::"v"(V0), "v"(V1), "v"(V2), "v"(V3), "s"(LDS), "s"(RSRC), "s"(SOFF), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
+      : "memory", "scc")
 #define VDQN_ISSUE(BUF, KR, KS, C0, KSTEP)                                                                          \
   {                                                                                                                 \
     const int delta_ = (MODE == 0   ? (((KR)*p.wi + (KS)) * p.pix_stride + (C0))                                    \
                         : MODE == 1 ? ((C0) - ((KR)*p.wi + (KS)) * p.pix_stride)                                    \
                                     : ((C0) - (((KR) >> 1) * p.wi + ((KS) >> 1)) * p.pix_stride)) *                 \
                        ESZ;                                                                                         \
-    uint32_t vo_[4];                                                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
+    uint32_t vo_[AROWS];                                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < AROWS; ++i_) {                                                          \
       bool ok_;                                                                                                     \
       if (MODE == 0) {                                                                                              \
         ok_ = ((unsigned)(a_hb[i_] + (KR)) < (unsigned)p.hi) && ((unsigned)(a_wb[i_] + (KS)) < (unsigned)p.wi);     \
@@ -169,26 +187,16 @@ __global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igem
       vo_[i_] = ok_ ? a_off[i_] + (uint32_t)delta_ : kOob;                                                          \
     }                                                                                                               \
     const uint32_t la_ = lds_wave + (uint32_t)(BUF) * (BM * 128);                                                   \
-    asm volatile(                                                                                                   \
-        "s_nop 4\n\t"                                                                                               \
-        "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, 0 offen lds\n\t"                               \
-        "s_add_u32 m0, %4, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"                           \
-        "s_add_u32 m0, %4, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"                           \
-        "s_add_u32 m0, %4, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds"                                \
-        ::"v"(vo_[0]), "v"(vo_[1]), "v"(vo_[2]), "v"(vo_[3]), "s"(la_), "s"(rs_a), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
-        : "memory", "scc");                                                                                         \
-    const uint32_t lb_ = lds_wave + (uint32_t)(NSTAGE * BM * 128) + (uint32_t)(BUF) * (BN * 128);                   \
+    const int zero_ = 0;                                                                                            \
+    VDQN_DMA4(vo_[0], vo_[1], vo_[2], vo_[3], la_, rs_a, zero_);                                                    \
+    if constexpr (AROWS == 8) {                                                                                     \
+      const uint32_t la2_ = la_ + 4 * PSTR;                                                                         \
+      VDQN_DMA4(vo_[AROWS - 4], vo_[AROWS - 3], vo_[AROWS - 2], vo_[AROWS - 1], la2_, rs_a, zero_);                 \
+    }                                                                                                               \
+    const uint32_t lb_ = lds_wave + (uint32_t)(2 * BM * 128) + (uint32_t)(BUF) * (BN * 128);                        \
     const int so_ = (KSTEP)*128;                                                                                    \
     if constexpr (BROWS == 4) {                                                                                     \
-      asm volatile(                                                                                                 \
-          "s_nop 4\n\t"                                                                                             \
-          "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, %6 offen lds\n\t"                            \
-          "s_add_u32 m0, %4, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"                        \
-          "s_add_u32 m0, %4, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"                        \
-          "s_add_u32 m0, %4, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                             \
-          ::"v"(b_off[0]), "v"(b_off[BROWS > 1 ? 1 : 0]), "v"(b_off[BROWS > 2 ? 2 : 0]), "v"(b_off[BROWS > 2 ? 3 : 0]), "s"(lb_),    \
-          "s"(rs_b), "s"(so_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR)                                              \
-          : "memory", "scc");                                                                                       \
+      VDQN_DMA4(b_off[0], b_off[BROWS > 1 ? 1 : 0], b_off[BROWS > 2 ? 2 : 0], b_off[BROWS > 2 ? 3 : 0], lb_, rs_b, so_); \
     } else if constexpr (BROWS == 2) {                                                                              \
       asm volatile(                                                                                                 \
           "s_nop 4\n\t"                                                                                             \
@@ -217,174 +225,226 @@ __global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igem
   // index of a K-step inside a weight row ([r][s][ci], 128-byte steps)
 #define VDQN_WSTEP() (MODE == 2 ? ((ikr * p.s + iks) * (p.ci / KC) + ic0 / KC) : issued)
 
+  // acc[f][j]: pixels f*16 + i16 (lane & 15), channels g*CPL + j*4 + reg (g = lane >> 4)
   f32x4 acc[4][NF];
 #pragma unroll
   for (int f = 0; f < 4; ++f)
 #pragma unroll
     for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int i16 = lane & 15, g = lane >> 4;
-  const int sw = i16 & 7;
 
-  // ---- main loop: K-steps enumerate (r, s, c0) with c0 fastest; NSTAGE LDS buffers, NSTAGE-1 tiles in flight ----
+  // ---- main loop: K-steps enumerate (r, s, c0) with c0 fastest ----
   int ikr = kr0, iks = ks0, ic0 = 0;  // coordinates of the next K-step to issue
   int issued = 0;
-#pragma unroll
-  for (int s_ = 0; s_ < NSTAGE - 1; ++s_) {
-    if (issued < nk) {
-      VDQN_ISSUE(s_, ikr, iks, ic0, VDQN_WSTEP())
-      VDQN_ADVANCE()
-      ++issued;
-    }
+  u32x4 fa[2][2][4], fb[2][2][NF];  // [register set][K half][fragment]
+  const unsigned char* a_rd = sA + (wr * 64 + i16) * 128;
+  const unsigned char* b_rd = sB + (wc * (BN / WN) + (i16 >> 2) * CPL + (i16 & 3)) * 128;
+  const int coff0 = ((g ^ (i16 & 7)) << 4), coff1 = (((g + 4) ^ (i16 & 7)) << 4);
+#define VDQN_LOAD_FRAGS(SET, BUF)                                                                                        \
+  {                                                                                                                      \
+    const unsigned char* a_ = a_rd + (BUF) * (BM * 128);                                                                 \
+    const unsigned char* b_ = b_rd + (BUF) * (BN * 128);                                                                 \
+    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                                                   \
+      fa[SET][0][f_] = *reinterpret_cast<const u32x4*>(a_ + f_ * 16 * 128 + coff0);                                      \
+      fa[SET][1][f_] = *reinterpret_cast<const u32x4*>(a_ + f_ * 16 * 128 + coff1);                                      \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) {                                                                  \
+      fb[SET][0][j_] = *reinterpret_cast<const u32x4*>(b_ + j_ * 4 * 128 + coff0);                                       \
+      fb[SET][1][j_] = *reinterpret_cast<const u32x4*>(b_ + j_ * 4 * 128 + coff1);                                       \
+    }                                                                                                                    \
   }
-  int buf = 0, ibuf = NSTAGE - 1;
-  for (int k = 0; k < nk; ++k) {
-    // tile k has landed once at most (issued - k - 1) younger tiles are still outstanding
-    if (NSTAGE == 3 && issued - k - 1 >= 1) {
-      if constexpr (BROWS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if constexpr (BROWS == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile k are visible; every wave is done with tile k-1
-    if (issued < nk) {
-      VDQN_ISSUE(ibuf, ikr, iks, ic0, VDQN_WSTEP())
-      VDQN_ADVANCE()
-      ++issued;
-    }
-    const unsigned char* a = sA + buf * (BM * 128) + (wr * 64 + i16) * 128;
-    const unsigned char* b = sB + buf * (BN * 128) + (wc * (BN / 2) + i16) * 128;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int coff = (((g + 4 * h) ^ sw) << 4);
-      uint4 af[4], bfr[NF];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) af[f] = *reinterpret_cast<const uint4*>(a + f * 16 * 128 + coff);
-#pragma unroll
-      for (int j = 0; j < NF; ++j) bfr[j] = *reinterpret_cast<const uint4*>(b + j * 16 * 128 + coff);
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-          if constexpr (sizeof(T) == 2) {
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bfr[j]),
-                                                                acc[f][j], 0, 0, 0);
-          } else {
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].x), __uint_as_float(bfr[j].x), acc[f][j], 0, 0, 0);
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].y), __uint_as_float(bfr[j].y), acc[f][j], 0, 0, 0);
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].z), __uint_as_float(bfr[j].z), acc[f][j], 0, 0, 0);
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].w), __uint_as_float(bfr[j].w), acc[f][j], 0, 0, 0);
-          }
-        }
-    }
-    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
-    ibuf = (ibuf + 1 == NSTAGE) ? 0 : ibuf + 1;
+#define VDQN_MFMA_ALL(SET)                                                                                               \
+  _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_)                     \
+      _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) {                                                                \
+    if constexpr (sizeof(T) == 2) {                                                                                      \
+      acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[SET][h_][j_]),                 \
+                                                            __builtin_bit_cast(bf16x8, fa[SET][h_][f_]), acc[f_][j_], 0, 0, 0); \
+    } else {                                                                                                             \
+      acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fb[SET][h_][j_].x), __uint_as_float(fa[SET][h_][f_].x), acc[f_][j_], 0, 0, 0); \
+      acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fb[SET][h_][j_].y), __uint_as_float(fa[SET][h_][f_].y), acc[f_][j_], 0, 0, 0); \
+      acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fb[SET][h_][j_].z), __uint_as_float(fa[SET][h_][f_].z), acc[f_][j_], 0, 0, 0); \
+      acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fb[SET][h_][j_].w), __uint_as_float(fa[SET][h_][f_].w), acc[f_][j_], 0, 0, 0); \
+    }                                                                                                                    \
   }
-  __syncthreads();  // all waves done reading LDS before the epilogue reuses it
+  // one K-step: tile K's fragments are in register set CUR (their reads were issued one step ago)
+#define VDQN_STEP(K, CUR, NXT)                                                                                           \
+  {                                                                                                                      \
+    /* own DMA pieces of tile K+1 landed; own fragment reads of tile K complete (its buffer is about to be refilled) */  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
+    /* tell the compiler set CUR is complete HERE, so it does not wait for it (and for the younger reads) later */      \
+    asm volatile("" : "+v"(fa[CUR][0][0]), "+v"(fa[CUR][0][1]), "+v"(fa[CUR][0][2]), "+v"(fa[CUR][0][3]),                \
+                      "+v"(fa[CUR][1][0]), "+v"(fa[CUR][1][1]), "+v"(fa[CUR][1][2]), "+v"(fa[CUR][1][3]));               \
+    _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) asm volatile("" : "+v"(fb[CUR][0][j_]), "+v"(fb[CUR][1][j_]));     \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    if (issued < nk) {                                                                                                   \
+      VDQN_ISSUE((K) & 1, ikr, iks, ic0, VDQN_WSTEP())                                                                   \
+      VDQN_ADVANCE()                                                                                                     \
+      ++issued;                                                                                                          \
+    }                                                                                                                    \
+    if ((K) + 1 < nk) VDQN_LOAD_FRAGS(NXT, ((K) + 1) & 1)                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    VDQN_MFMA_ALL(CUR)                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+  // prologue: tiles 0 and 1 in flight, wait for tile 0 only
+  VDQN_ISSUE(0, ikr, iks, ic0, VDQN_WSTEP())
+  VDQN_ADVANCE()
+  ++issued;
+  if (issued < nk) {
+    VDQN_ISSUE(1, ikr, iks, ic0, VDQN_WSTEP())
+    VDQN_ADVANCE()
+    ++issued;
+    if constexpr (AROWS + BROWS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (AROWS + BROWS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (AROWS + BROWS == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (AROWS + BROWS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();  // tile 0 visible
+  VDQN_LOAD_FRAGS(0, 0)
+  for (int k = 0; k < nk; k += 2) {
+    VDQN_STEP(k, 0, 1)
+    if (k + 1 < nk) VDQN_STEP(k + 1, 1, 0)
+  }
+#undef VDQN_LOAD_FRAGS
+#undef VDQN_MFMA_ALL
+#undef VDQN_STEP
 #undef VDQN_ISSUE
+#undef VDQN_DMA4
 #undef VDQN_ADVANCE
 #undef VDQN_WSTEP
 
-  // ---- epilogue: accumulators -> LDS f32 tile (C layout: col = lane & 15, row = (lane >> 4) * 4 + reg) ----
-  float* sC = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        sC[(wr * 64 + f * 16 + g * 4 + reg) * LDC + wc * (BN / 2) + j * 16 + i16] = acc[f][j][reg];
-  __syncthreads();
-
+  // ---- epilogue, straight from the accumulators: lane (i16, g) owns channels [ncol, ncol + CPL) of pixels f*16 + i16 ----
   T* __restrict__ out = (T*)p.out;
   const T* __restrict__ resid = (const T*)p.resid;
   const T* __restrict__ mask = (const T*)p.mask;
-  constexpr int TPR = BN / 8;         // threads per tile row (8 columns each)
-  constexpr int RPP = NT / TPR;       // rows per pass
-  const int col8 = (tid % TPR) * 8;
-  const int n = n0 + col8;
-  float cs[8];  // per-thread column sums of the values this tile stores (for the BN-shift / bias gradient)
+  constexpr int V16 = CPL * ESZ / 16;  // 16-byte vectors per lane and pixel
+  const int ncol = n0 + wc * (BN / WN) + g * CPL;
+  float cs[CPL];  // per-lane column sums of the values this tile stores (for the BN-shift / bias gradient)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
-  if (n < p.co) {
-    const bool vec = p.vec_ok && (n + 8 <= p.co);
-    float bv[8];
+  for (int e = 0; e < CPL; ++e) cs[e] = 0.f;
+  if (ncol < p.co) {
+    const bool vec = p.vec_ok && (ncol + CPL <= p.co);
+    float bv[CPL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.co) ? p.bias[n + e] : 0.f;
-#pragma unroll 2
-    for (int r0 = tid / TPR; r0 < BM; r0 += RPP) {
-      int m = m0 + r0;
-      if (m >= rows_total) break;
+    for (int e = 0; e < CPL; ++e) bv[e] = (p.bias && ncol + e < p.co) ? p.bias[ncol + e] : 0.f;
+    size_t o[4];
+    bool okr[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      int m = m0 + wr * 64 + f * 16 + i16;
+      okr[f] = m < rows_total;
       if constexpr (MODE == 2) {  // class-local row -> output pixel
-        const int img = m / pix_per_img;
-        const int rem = m - img * pix_per_img;
+        const int mm = okr[f] ? m : m0;
+        const int img = mm / pix_per_img;
+        const int rem = mm - img * pix_per_img;
         const int ohc = rem / row_w;
         m = (img * p.ho + 2 * ohc + cls_ph) * p.wo + 2 * (rem - ohc * row_w) + cls_pw;
       }
-      const size_t o = (size_t)m * p.ldo + n;
-      float v[8];
-      const float4 c0v = *reinterpret_cast<const float4*>(sC + r0 * LDC + col8);
-      const float4 c1v = *reinterpret_cast<const float4*>(sC + r0 * LDC + col8 + 4);
-      v[0] = c0v.x + bv[0]; v[1] = c0v.y + bv[1]; v[2] = c0v.z + bv[2]; v[3] = c0v.w + bv[3];
-      v[4] = c1v.x + bv[4]; v[5] = c1v.y + bv[5]; v[6] = c1v.z + bv[6]; v[7] = c1v.w + bv[7];
-      if (vec) {
-        T rv[8], mv[8], ov[8];
-        if (resid) {
-          if constexpr (ESZ == 2) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(resid + o);
-          else { reinterpret_cast<uint4*>(rv)[0] = reinterpret_cast<const uint4*>(resid + o)[0]; reinterpret_cast<uint4*>(rv)[1] = reinterpret_cast<const uint4*>(resid + o)[1]; }
+      o[f] = (size_t)m * p.ldo + ncol;
+    }
+    if (vec) {
+      uint4 rv[4][V16], mv[4][V16];
+      if (resid) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(rv[e]);
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int q = 0; q < V16; ++q) rv[f][q] = okr[f] ? reinterpret_cast<const uint4*>(resid + o[f])[q] : make_uint4(0, 0, 0, 0);
+      }
+      if (mask) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int q = 0; q < V16; ++q) mv[f][q] = okr[f] ? reinterpret_cast<const uint4*>(mask + o[f])[q] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        float v[CPL];
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + bv[j * 4 + r];
+        if (resid) {
+          const T* pr = reinterpret_cast<const T*>(rv[f]);
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] += to_f32<T>(pr[e]);
         }
         if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (mask) {
-          if constexpr (ESZ == 2) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + o);
-          else { reinterpret_cast<uint4*>(mv)[0] = reinterpret_cast<const uint4*>(mask + o)[0]; reinterpret_cast<uint4*>(mv)[1] = reinterpret_cast<const uint4*>(mask + o)[1]; }
+          const T* pm = reinterpret_cast<const T*>(mv[f]);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (to_f32<T>(mv[e]) > 0.f) ? v[e] : 0.f;
+          for (int e = 0; e < CPL; ++e) v[e] = (to_f32<T>(pm[e]) > 0.f) ? v[e] : 0.f;
         }
-        if (out) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            ov[e] = from_f32<T>(v[e]);
-            cs[e] += to_f32<T>(ov[e]);
-          }
-          if constexpr (ESZ == 2) *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ov);
-          else { reinterpret_cast<uint4*>(out + o)[0] = reinterpret_cast<const uint4*>(ov)[0]; reinterpret_cast<uint4*>(out + o)[1] = reinterpret_cast<const uint4*>(ov)[1]; }
-        }
-        if (p.out_f32) {
-          *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(p.out_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-      } else {
-        for (int e = 0; e < 8 && n + e < p.co; ++e) {
-          float x = v[e];
-          if (resid) x += to_f32<T>(resid[o + e]);
-          if (p.relu) x = fmaxf(x, 0.f);
-          if (mask) x = (to_f32<T>(mask[o + e]) > 0.f) ? x : 0.f;
+        if (okr[f]) {
           if (out) {
-            out[o + e] = from_f32<T>(x);
-            cs[e] += to_f32<T>(from_f32<T>(x));
+            T ov[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+              ov[e] = from_f32<T>(v[e]);
+              cs[e] += to_f32<T>(ov[e]);
+            }
+#pragma unroll
+            for (int q = 0; q < V16; ++q) reinterpret_cast<uint4*>(out + o[f])[q] = reinterpret_cast<const uint4*>(ov)[q];
           }
-          if (p.out_f32) p.out_f32[o + e] = x;
+          if (p.out_f32) {
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q)
+              *reinterpret_cast<float4*>(p.out_f32 + o[f] + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          }
         }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        if (!okr[f]) continue;
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = j * 4 + r;
+            if (ncol + e >= p.co) continue;
+            float x = acc[f][j][r] + bv[e];
+            if (resid) x += to_f32<T>(resid[o[f] + e]);
+            if (p.relu) x = fmaxf(x, 0.f);
+            if (mask) x = (to_f32<T>(mask[o[f] + e]) > 0.f) ? x : 0.f;
+            if (out) {
+              out[o[f] + e] = from_f32<T>(x);
+              cs[e] += to_f32<T>(from_f32<T>(x));
+            }
+            if (p.out_f32) p.out_f32[o[f] + e] = x;
+          }
       }
     }
   }
   if (p.colsum_part) {  // uniform branch: partial column sums of this tile -> colsum_part[tile_m][ldo]
-    __syncthreads();    // everyone has read the staging tile: reuse its head for the reduction
-    float* sR = sC;
+    // sum the 16 pixel-lanes of every channel group, then the BM/64 wave rows through LDS
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sR[(tid / TPR) * BN + col8 + e] = cs[e];
+    for (int e = 0; e < CPL; ++e) {
+      float t = cs[e];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      t += __shfl_xor(t, 8, 64);
+      cs[e] = t;
+    }
+    __syncthreads();  // every wave is past its last fragment read: LDS can be reused
+    float* sR = reinterpret_cast<float*>(smem);
+    if (i16 == 0) {
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) sR[wr * BN + wc * (BN / WN) + g * CPL + e] = cs[e];
+    }
     __syncthreads();
     if (tid < BN && n0 + tid < p.co) {
       float t = 0.f;
 #pragma unroll
-      for (int r = 0; r < RPP; ++r) t += sR[r * BN + tid];
+      for (int r = 0; r < BM / 64; ++r) t += sR[r * BN + tid];
       if constexpr (BM == 256) {  // consumers sum ceil(M/128) entries: this tile covers two of them
         p.colsum_part[(size_t)(2 * tile_m) * p.ldo + n0 + tid] = t;
         if ((2 * tile_m + 1) * 128 < p.M) p.colsum_part[(size_t)(2 * tile_m + 1) * p.ldo + n0 + tid] = 0.f;
@@ -395,39 +455,42 @@ __global__ __launch_bounds__(2 * BM, NSTAGE == 3 && BN == 128 ? 1 : 2) void igem
   }
 }
 
-template <typename T, int BM, int BN, int MODE, int NSTAGE = VDQN_IGEMM_STAGES>
+template <typename T, int BM, int BN, int MODE>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
-  const size_t main_bytes = NSTAGE * (BM + BN) * 128, epi_bytes = BM * (BN + 4) * 4;
-  const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  // 256x64 tiles: 4 waves of 64x64 (WN = 1); everything else a (BM/64) x 2 wave grid
+  constexpr int WN = (BM == 256 && BN == 64) ? 1 : 2;
+  const size_t smem = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, MODE, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, MODE, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
   const double esz = sizeof(T);
   // one tag per kernel symbol (T, BM, BN, MODE), so bench.py rows line up with rocprofv3's kernel names
-  static const char* const kTag[2][3][3] = {{{"igemm<bf16,64,fwd>", "igemm<bf16,64,dgrad>", "igemm<bf16,64,dgrad_s2>"},
+  static const char* const kTag[2][4][3] = {{{"igemm<bf16,64,fwd>", "igemm<bf16,64,dgrad>", "igemm<bf16,64,dgrad_s2>"},
                                              {"igemm<bf16,128,fwd>", "igemm<bf16,128,dgrad>", "igemm<bf16,128,dgrad_s2>"},
-                                             {"igemm<bf16,256x64,fwd>", "igemm<bf16,256x64,dgrad>", "igemm<bf16,256x64,dgrad_s2>"}},
+                                             {"igemm<bf16,256x64,fwd>", "igemm<bf16,256x64,dgrad>", "igemm<bf16,256x64,dgrad_s2>"},
+                                             {"igemm<bf16,256x128,fwd>", "igemm<bf16,256x128,dgrad>", "igemm<bf16,256x128,dgrad_s2>"}},
                                             {{"igemm<f32,64,fwd>", "igemm<f32,64,dgrad>", "igemm<f32,64,dgrad_s2>"},
                                              {"igemm<f32,128,fwd>", "igemm<f32,128,dgrad>", "igemm<f32,128,dgrad_s2>"},
-                                             {"igemm<f32,256x64,fwd>", "igemm<f32,256x64,dgrad>", "igemm<f32,256x64,dgrad_s2>"}}};
-  vdqn_prof_begin(kTag[sizeof(T) == 2 ? 0 : 1][BM == 256 ? 2 : (BN == 128 ? 1 : 0)][MODE],
+                                             {"igemm<f32,256x64,fwd>", "igemm<f32,256x64,dgrad>", "igemm<f32,256x64,dgrad_s2>"},
+                                             {"igemm<f32,256x128,fwd>", "igemm<f32,256x128,dgrad>", "igemm<f32,256x128,dgrad_s2>"}}};
+  vdqn_prof_begin(kTag[sizeof(T) == 2 ? 0 : 1][BM == 256 ? (BN == 128 ? 3 : 2) : (BN == 128 ? 1 : 0)][MODE],
                   2.0 * p.M * p.co * p.ktot,
                   esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
                   stream);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, MODE, NSTAGE>), dim3(grid), dim3(2 * BM), smem, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, MODE, WN>), dim3(grid), dim3(BM * WN), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }
 
-template <typename T, int BM, int BN, int NSTAGE = VDQN_IGEMM_STAGES>
+template <typename T, int BM, int BN>
 int launch_mode(const IgemmParams& p, int mode, hipStream_t st) {
-  if (mode == 0) return launch_igemm<T, BM, BN, 0, NSTAGE>(p, st);
-  if (mode == 1) return launch_igemm<T, BM, BN, 1, NSTAGE>(p, st);
-  if constexpr (BM == 128) return launch_igemm<T, BM, BN, 2, NSTAGE>(p, st);
+  if (mode == 0) return launch_igemm<T, BM, BN, 0>(p, st);
+  if (mode == 1) return launch_igemm<T, BM, BN, 1>(p, st);
+  if constexpr (BM == 128) return launch_igemm<T, BM, BN, 2>(p, st);
   return VDQN_ERR_INVALID;
 }
 

@@ -2,6 +2,7 @@
 // events recorded on the launch stream; vdqn_profile_collect() returns per-kernel totals (launch count, device
 // milliseconds, algorithmic FLOPs and bytes).  bench.py uses it for the live roofline numbers; the numbers are
 // cross-checked against `rocprofv3 --kernel-trace --stats` (profiles/).
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -24,6 +25,7 @@ Rec* g_open = nullptr;
 }  // namespace
 
 thread_local double g_prof_alg_flops = -1.0;
+thread_local const char* g_prof_suffix = nullptr;  // engine: layer name of the next launch (VDQN_PROFILE_LAYERS=1)
 
 void vdqn_prof_begin(const char* tag, double flops, double bytes, hipStream_t st) {
   if (!g_on) {
@@ -37,6 +39,15 @@ void vdqn_prof_begin(const char* tag, double flops, double bytes, hipStream_t st
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     g_pool.emplace_back(a, b);
   }
+  std::string full(tag);
+  if (g_prof_suffix) {
+    // keep the layer name when the 47-character entry name cannot hold both
+    std::string sfx(g_prof_suffix);
+    if (full.size() + 1 + sfx.size() > 47) full = full.substr(0, 47 - 1 - std::min<size_t>(sfx.size(), 46));
+    full += "|" + sfx;
+    g_prof_suffix = nullptr;
+  }
+  tag = full.c_str();
   auto it = g_tag_ids.find(tag);
   int id;
   if (it == g_tag_ids.end()) {
