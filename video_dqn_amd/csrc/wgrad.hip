@@ -199,13 +199,82 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
    }
   };
 
-  issue_tile(kbeg, 0);
-  for (int k = 0; k < nk; ++k) {
-    const int buf = k & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile k landed for every wave; every wave is done with tile k-1
-    if (k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
-    compute(buf);
+  if constexpr (sizeof(T) == 2) {
+    // bf16: the fragments of a whole staged K-step live in registers, double-buffered — the transposing reads of
+    // tile k+1 run underneath the MFMAs of tile k and the DMA of tile k+2 (same scheme as igemm.hip)
+    constexpr int NSUB = WSPLIT ? 1 : KSUB;  // 32-pixel sub-steps this wave computes per staged K-step
+    typedef short s16x4v __attribute__((ext_vector_type(4)));
+    s16x4v fa[2][NSUB][NFR][2], fb[2][NSUB][NFR][2];  // [set][sub-step][fragment][pixel half]
+    const int q = i16 >> 2, pp = i16 & 3;
+    const int row = 4 * grp + q;
+    const int sz = wg_swz<T, BT>(row);
+    const int sub8 = (pp & 1) << 3;
+    int offa[NFR], offb[NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) {
+      offa[f] = row * RB + (((((wr * (BT / 2) + f * 16) >> 3) + (pp >> 1)) ^ sz) << 4) + sub8;
+      offb[f] = row * RB + (((((wc * (BT / 2) + f * 16) >> 3) + (pp >> 1)) ^ sz) << 4) + sub8;
+    }
+#define WG_LOAD(SET, BUF)                                                                                            \
+  _Pragma("unroll") for (int u_ = 0; u_ < NSUB; ++u_) {                                                              \
+    const int sb_ = WSPLIT ? wave : u_;                                                                              \
+    const unsigned char* a_ = sA + (BUF) * (KP * RB) + sb_ * (32 * RB);                                              \
+    const unsigned char* b_ = sB + (BUF) * (KP * RB) + sb_ * (32 * RB);                                              \
+    _Pragma("unroll") for (int f_ = 0; f_ < NFR; ++f_) {                                                             \
+      fa[SET][u_][f_][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a_ + offa[f_]));           \
+      fa[SET][u_][f_][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a_ + offa[f_] + 16 * RB)); \
+      fb[SET][u_][f_][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b_ + offb[f_]));           \
+      fb[SET][u_][f_][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b_ + offb[f_] + 16 * RB)); \
+    }                                                                                                                \
+  }
+#define WG_MFMA(SET)                                                                                                 \
+  _Pragma("unroll") for (int u_ = 0; u_ < NSUB; ++u_) _Pragma("unroll") for (int f_ = 0; f_ < NFR; ++f_)            \
+      _Pragma("unroll") for (int j_ = 0; j_ < NFR; ++j_) {                                                           \
+    const s16x8 av_ = (s16x8){fa[SET][u_][f_][0][0], fa[SET][u_][f_][0][1], fa[SET][u_][f_][0][2], fa[SET][u_][f_][0][3],   \
+                              fa[SET][u_][f_][1][0], fa[SET][u_][f_][1][1], fa[SET][u_][f_][1][2], fa[SET][u_][f_][1][3]};  \
+    const s16x8 bv_ = (s16x8){fb[SET][u_][j_][0][0], fb[SET][u_][j_][0][1], fb[SET][u_][j_][0][2], fb[SET][u_][j_][0][3],   \
+                              fb[SET][u_][j_][1][0], fb[SET][u_][j_][1][1], fb[SET][u_][j_][1][2], fb[SET][u_][j_][1][3]};  \
+    acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av_), __builtin_bit_cast(bf16x8, bv_), acc[f_][j_], 0, 0, 0); \
+  }
+#define WG_STEP(K, CUR, NXT)                                                                                         \
+  {                                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                      \
+    _Pragma("unroll") for (int u_ = 0; u_ < NSUB; ++u_) _Pragma("unroll") for (int f_ = 0; f_ < NFR; ++f_)          \
+        asm volatile("" : "+v"(fa[CUR][u_][f_][0]), "+v"(fa[CUR][u_][f_][1]), "+v"(fb[CUR][u_][f_][0]), "+v"(fb[CUR][u_][f_][1])); \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    if ((K) + 2 < nk) issue_tile(kbeg + ((K) + 2) * KP, (K) & 1);                                                    \
+    if ((K) + 1 < nk) WG_LOAD(NXT, ((K) + 1) & 1)                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    WG_MFMA(CUR)                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+    issue_tile(kbeg, 0);
+    if (nk > 1) {
+      issue_tile(kbeg + KP, 1);
+      if constexpr (2 * NL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (2 * NL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    WG_LOAD(0, 0)
+    for (int k = 0; k < nk; k += 2) {
+      WG_STEP(k, 0, 1)
+      if (k + 1 < nk) WG_STEP(k + 1, 1, 0)
+    }
+#undef WG_LOAD
+#undef WG_MFMA
+#undef WG_STEP
+  } else {
+    issue_tile(kbeg, 0);
+    for (int k = 0; k < nk; ++k) {
+      const int buf = k & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // tile k landed for every wave; every wave is done with tile k-1
+      if (k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
+      compute(buf);
+    }
   }
 
   // C layout: col (lane & 15) -> ci, row ((lane >> 4) * 4 + reg) -> co
@@ -227,6 +296,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       const float v = red[o] + red[4096 + o] + red[8192 + o] + red[12288 + o];
       const int co = co0 + (o >> 6), ci = ci0 + (o & 63);
       if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, v);
+    }
+  } else if constexpr (sizeof(T) == 2) {
+    // stage the 128x128 f32 tile through LDS so that every wave-instruction adds 256 contiguous bytes of one dw row
+    // (the accumulator layout would give 4 rows x 64 B per instruction)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [BT][BT] f32 = the 64 KiB of staging buffers
+#pragma unroll
+    for (int f = 0; f < NFR; ++f)
+#pragma unroll
+      for (int j = 0; j < NFR; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          red[(wr * (BT / 2) + f * 16 + grp * 4 + reg) * BT + wc * (BT / 2) + j * 16 + i16] = acc[f][j][reg];
+    __syncthreads();
+#pragma unroll 8
+    for (int e = 0; e < BT * BT / 256; ++e) {
+      const int o = tid + 256 * e;
+      const int co = co0 + o / BT, ci = ci0 + o % BT;
+      if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, red[o]);
     }
   } else {
 #pragma unroll
@@ -329,7 +417,10 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   const int tiles = (co_pad / bt) * p.taps * p.ci_tiles;
   int splitk = a->splitk;
   if (splitk <= 0) {
-    splitk = 1024 / tiles;  // <= 1024 blocks: two full rounds at 2 blocks per CU, no third (tail) round
+    // 512 blocks = ONE round at 2 blocks per CU: measured 650 vs 555 TFLOP/s against two rounds of half-length blocks
+    // (half the f32 atomics, twice the K-steps per prologue/epilogue); fewer than 512 leaves CUs idle (384: 540)
+    static const int target = [] { const char* e = getenv("VDQN_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    splitk = target / tiles;
     const int max_split = (p.M + 255) / 256;  // at least 8 K-steps per block
     if (splitk > max_split) splitk = max_split;
     if (splitk < 1) splitk = 1;
