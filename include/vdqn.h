@@ -148,6 +148,14 @@ int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, flo
                  int32_t batch, int32_t n_cat, int32_t n_act, int32_t ldq, float inv_count, int32_t value_learning,
                  int32_t dtype, void* stream);
 
+/* The ResNet stem in one kernel: conv1 7x7/2 (as the 4x4/1 convolution over the packed operand of vdqn_pack_input,
+ * weights [64][4][1][64] with BatchNorm folded, f32 bias[64]) + ReLU + MaxPool2d(3, 2, 1)
+ * (torchvision resnet.py conv1/bn1/relu/maxpool; archs/HabitatDQNMultiAction.py:30).  Writes pool [n][56][56][64] and
+ * the argmax codes idx (as vdqn_maxpool_fwd); the 112x112x64 convolution output is never stored.  Results are
+ * bit-identical to vdqn_conv2d followed by vdqn_maxpool_fwd. */
+int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img,
+                        int32_t dtype, void* stream);
+
 /* torch.optim.Adam step (train_q_network.py:124,227) over one flat f32 range:
  *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * Hyper-parameters are doubles like torch's python scalars (1-b2 is formed in double before rounding to f32). */

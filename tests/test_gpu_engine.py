@@ -233,7 +233,7 @@ def test_forward_activations_layer_by_layer_f32():
     net.forward(tup[0].contiguous().to(DEV), 1, B)
     torch.cuda.synchronize()
     buf = net._acts[B]
-    dims = {"c1": (112, 64), "pool": (56, 64)}
+    dims = {"pool": (56, 64)}  # c1 is never materialised: conv1 + max-pool are one kernel
     for b in range(8):
         dims[f"o{b}"] = (56 >> (b // 2), 64 << (b // 2))
         dims[f"h{b}"] = dims[f"o{b}"]
@@ -258,7 +258,7 @@ def _oracle_relu_outputs(model, x_frames):
 
     def hook(name):
         return lambda mod, inp, out: feats.__setitem__(name, out.detach())
-    hs = [model.resnet.relu.register_forward_hook(hook("c1"))]
+    hs = [model.resnet.maxpool.register_forward_hook(hook("pool"))]  # c1 is fused away; pool > 0 <=> some c1 in the window > 0
     for b in range(8):
         blk = getattr(model.resnet, f"layer{b // 2 + 1}")[b % 2]
         hs.append(blk.register_forward_hook(hook(f"o{b}")))

@@ -187,6 +187,10 @@ def test_stem_pack_conv1_maxpool(dtype, src_kind):
     pool, idx = ops.maxpool_fwd(c1)
     torch.cuda.synchronize()
     assert torch.equal(pool.float().cpu().permute(0, 3, 1, 2), pref.detach())
+    # the fused stem kernel (conv1 + ReLU + max-pool, no c1 in HBM) is bit-identical to the two separate kernels
+    pool_f, idx_f = ops.stem_conv_pool(packed, s2d_weights(w7, dtype), b.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(pool_f, pool) and torch.equal(idx_f, idx)
     # backward: gx = relu'(c1) * unpool(gy)
     gy = q(rnd(9, "gy", tuple(pref.shape)), dtype)
     pref.backward(gy)

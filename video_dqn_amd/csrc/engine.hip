@@ -525,7 +525,7 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
     return o;
   };
   L.t_in = take(n * 115 * 115 * 16 * e);
-  L.c1 = take(n * 112 * 112 * 64 * e);
+  L.c1 = net->basic() ? take(n * 112 * 112 * 64 * e) : -1;  // extra_capacity: conv1 + max-pool are one kernel, c1 never exists
   L.pool = take(n * 56 * 56 * 64 * e);
   L.idx = take(n * 56 * 56 * 64);
   for (int b = 0; b < 8; ++b) {
@@ -703,8 +703,14 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
                  hipStream_t st) {
   const int n = n_samples * net->cfg.num_frames;
   const int dt = net->cfg.dtype;
-  RC(run_conv(net, net->layers[net->l_conv1], packed, t_in, acts + A.c1, n, nullptr, 1, nullptr, st));
-  RC(vdqn_maxpool_fwd(acts + A.c1, acts + A.pool, acts + A.idx, n, 112, 112, 64, dt, st));
+  if (A.c1 >= 0) {  // 'basic' eval path keeps the separate kernels (its train path needs the raw conv output anyway)
+    RC(run_conv(net, net->layers[net->l_conv1], packed, t_in, acts + A.c1, n, nullptr, 1, nullptr, st));
+    RC(vdqn_maxpool_fwd(acts + A.c1, acts + A.pool, acts + A.idx, n, 112, 112, 64, dt, st));
+  } else {
+    const Layer& L1 = net->layers[net->l_conv1];
+    prof_layer(L1, n);
+    RC(vdqn_stem_conv_pool(t_in, packed + L1.wf_off, reinterpret_cast<const float*>(packed + L1.bias_off), acts + A.pool, acts + A.idx, n, dt, st));
+  }
   const unsigned char* x = acts + A.pool;
   for (int b = 0; b < 8; ++b) {
     const Layer& c1 = net->layers[net->l_b_conv1[b]];

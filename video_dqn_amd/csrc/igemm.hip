@@ -41,6 +41,8 @@ struct IgemmParams {
   void* out;
   float* out_f32;
   float* colsum_part;
+  void* pool_out;      // MODE 3 (stem): max-pooled output [n][56][56][64] and its argmax codes
+  uint8_t* pool_idx;
   int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldo, r, s, stride, pad, relu;
   int M, howo, ktot, nk, tiles_m, tiles_n;
   int cls_tile0[5], cls_h[2], cls_w[2];  // MODE 2: first tile of each output-parity class; class heights / widths
@@ -53,6 +55,10 @@ constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (
 
 // MODE 0: forward gather (h = oh*stride - pad + kr); 1: dgrad, stride 1 (h = oh + pad - kr);
 //      2: dgrad, stride 2 (h = (oh + pad - kr) / 2 when even)
+//      3: the ResNet stem — conv1 (as a 4x4/1 conv on the space-to-depth operand) + folded BatchNorm + ReLU + the 3x3/2
+//         max-pool in one kernel: a tile is a 16x16 patch of conv pixels (rows 14 ty - 1 .., cols 14 tx - 1 ..) that holds
+//         every window of a 7x7 patch of pooled pixels, so the 112x112x64 conv output never goes to HBM (the patches
+//         overlap by two rows/columns: 30 % more MFMA work on a kernel whose cost is its output traffic)
 // WN = waves along N.  256 x 64 tiles with WN = 1 give the 64-output-channel layers the same 64x64 wave tile (16 MFMAs
 // per 8 fragment reads) as the 128x128 kernel.
 template <typename T, int BM, int BN, int MODE, int WN>
@@ -92,6 +98,8 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     const int nkr = p.r > kr0 ? (p.r - kr0 + 1) / 2 : 0, nks = p.s > ks0 ? (p.s - ks0 + 1) / 2 : 0;
     nk = nkr * nks * (p.ci / KC);
   }
+  constexpr bool FWD = (MODE == 0 || MODE == 3);
+  const int st_img = MODE == 3 ? tile_m >> 6 : 0, st_ty = (tile_m >> 3) & 7, st_tx = tile_m & 7;  // MODE 3 tile coordinates
   const int row_w = MODE == 2 ? p.cls_w[cls_pw] : p.wo;
   const int pix_per_img = MODE == 2 ? p.cls_h[cls_ph] * row_w : p.howo;
   const int rows_total = MODE == 2 ? p.n_img * pix_per_img : p.M;
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
   // ---- buffer descriptors (4 SGPRs each): A relative to the first image of this tile, B = whole weight tensor.
   // The DMA is issued from inline asm: hipcc would otherwise wait vmcnt(0) before the first ds_read that follows
   // a pending LDS-DMA (it cannot prove the buffers distinct), which serialises the copy behind the MFMAs.
-  const int img0 = m0 / pix_per_img;
+  const int img0 = MODE == 3 ? st_img : m0 / pix_per_img;
   const long long img_bytes = (long long)p.hi * p.wi * p.pix_stride * ESZ;
   const long long a_base_off = (long long)img0 * img_bytes;
   long long a_rem = p.in_bytes - a_base_off;
@@ -124,9 +132,9 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     const int m = m0 + lrow + RPS * i;
-    const bool ok = m < rows_total;
+    const bool ok = MODE == 3 || m < rows_total;
     const int mm = ok ? m : m0;
-    const int img = mm / pix_per_img;
+    int img = mm / pix_per_img;
     const int rem = mm - img * pix_per_img;
     int oh = rem / row_w;
     int ow = rem - oh * row_w;
@@ -134,8 +142,14 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
       oh = 2 * oh + cls_ph;
       ow = 2 * ow + cls_pw;
     }
+    if constexpr (MODE == 3) {  // patch pixel -> conv pixel, clamped into the image (clamped rows are never pooled)
+      const int r_ = lrow + RPS * i;
+      img = st_img;
+      oh = min(max(14 * st_ty - 1 + (r_ >> 4), 0), p.ho - 1);
+      ow = min(max(14 * st_tx - 1 + (r_ & 15), 0), p.wo - 1);
+    }
     int hb, wb, hq, wq;
-    if (MODE == 0) {
+    if (FWD) {
       hb = oh * p.stride - p.pad;
       wb = ow * p.stride - p.pad;
       hq = hb;
@@ -169,14 +183,14 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
       : "memory", "scc")
 #define VDQN_ISSUE(BUF, KR, KS, C0, KSTEP)                                                                          \
   {                                                                                                                 \
-    const int delta_ = (MODE == 0   ? (((KR)*p.wi + (KS)) * p.pix_stride + (C0))                                    \
+    const int delta_ = (FWD         ? (((KR)*p.wi + (KS)) * p.pix_stride + (C0))                                    \
                         : MODE == 1 ? ((C0) - ((KR)*p.wi + (KS)) * p.pix_stride)                                    \
                                     : ((C0) - (((KR) >> 1) * p.wi + ((KS) >> 1)) * p.pix_stride)) *                 \
                        ESZ;                                                                                         \
     uint32_t vo_[AROWS];                                                                                            \
     _Pragma("unroll") for (int i_ = 0; i_ < AROWS; ++i_) {                                                          \
       bool ok_;                                                                                                     \
-      if (MODE == 0) {                                                                                              \
+      if (FWD) {                                                                                                    \
         ok_ = ((unsigned)(a_hb[i_] + (KR)) < (unsigned)p.hi) && ((unsigned)(a_wb[i_] + (KS)) < (unsigned)p.wi);     \
       } else if (MODE == 1) {                                                                                       \
         ok_ = ((unsigned)(a_hb[i_] - (KR)) < (unsigned)p.hi) && ((unsigned)(a_wb[i_] - (KS)) < (unsigned)p.wi);     \
@@ -318,6 +332,77 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
 #undef VDQN_ADVANCE
 #undef VDQN_WSTEP
 
+  if constexpr (MODE == 3) {
+    // ---- stem epilogue: bias + ReLU, the 16x16x64 patch goes to LDS (16-byte chunks XOR-swizzled by the pixel), then
+    // 49 pooled pixels x 64 channels are reduced from it with the first-maximum-wins rule of maxpool_fwd_kernel ----
+    static_assert(MODE != 3 || (BM == 256 && BN == 64 && WN == 1), "stem tile is 16x16 pixels x 64 channels");
+    constexpr int E16 = 16 / ESZ, CPP = 64 / E16;  // elements per 16 bytes; chunks per pixel
+    __syncthreads();  // every wave is past its last fragment read
+    T* sT = reinterpret_cast<T*>(smem);
+    {
+      float bv[CPL];
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) bv[e] = p.bias[g * CPL + e];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int r = wr * 64 + f * 16 + i16;
+        T ov[CPL];
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ov[j * 4 + q] = from_f32<T>(fmaxf(acc[f][j][q] + bv[j * 4 + q], 0.f));
+#pragma unroll
+        for (int c = 0; c < CPL / E16; ++c) {
+          const int chunk = (g * (CPL / E16) + c) ^ (r & 7);
+          *reinterpret_cast<uint4*>(sT + (size_t)r * 64 + chunk * E16) = reinterpret_cast<const uint4*>(ov)[c];
+        }
+      }
+    }
+    __syncthreads();
+    T* __restrict__ pool = (T*)p.pool_out;
+    for (int item = tid; item < 49 * CPP; item += NT) {
+      const int pp = item / CPP, cg = item - pp * CPP;
+      const int pi = pp / 7, pj = pp - pi * 7;
+      float best[E16];
+      uint8_t bi[E16];
+#pragma unroll
+      for (int e = 0; e < E16; ++e) {
+        best[e] = -INFINITY;
+        bi[e] = 0;
+      }
+      bool first = true;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int py = 2 * pi + kh, y = 14 * st_ty - 1 + py;
+        if ((unsigned)y >= (unsigned)p.ho) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int px = 2 * pj + kw, x = 14 * st_tx - 1 + px;
+          if ((unsigned)x >= (unsigned)p.wo) continue;
+          const int r = py * 16 + px;
+          const uint4 v = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * E16));
+          const T* pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+          for (int e = 0; e < E16; ++e) {
+            const float fv = to_f32<T>(pv[e]);
+            if (first || fv > best[e] || fv != fv) {
+              best[e] = fv;
+              bi[e] = (uint8_t)(kh * 3 + kw);
+            }
+          }
+          first = false;
+        }
+      }
+      const size_t o = (((size_t)st_img * 56 + 7 * st_ty + pi) * 56 + 7 * st_tx + pj) * 64 + cg * E16;
+      T ov[E16];
+#pragma unroll
+      for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(best[e]);
+      *reinterpret_cast<uint4*>(pool + o) = *reinterpret_cast<const uint4*>(ov);
+      if constexpr (E16 == 8) *reinterpret_cast<uint2*>(p.pool_idx + o) = *reinterpret_cast<const uint2*>(bi);
+      else *reinterpret_cast<uint32_t*>(p.pool_idx + o) = *reinterpret_cast<const uint32_t*>(bi);
+    }
+    return;
+  }
   // ---- epilogue, straight from the accumulators: lane (i16, g) owns channels [ncol, ncol + CPL) of pixels f*16 + i16 ----
   T* __restrict__ out = (T*)p.out;
   const T* __restrict__ resid = (const T*)p.resid;
@@ -476,10 +561,14 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
                                              {"igemm<f32,128,fwd>", "igemm<f32,128,dgrad>", "igemm<f32,128,dgrad_s2>"},
                                              {"igemm<f32,256x64,fwd>", "igemm<f32,256x64,dgrad>", "igemm<f32,256x64,dgrad_s2>"},
                                              {"igemm<f32,256x128,fwd>", "igemm<f32,256x128,dgrad>", "igemm<f32,256x128,dgrad_s2>"}}};
-  vdqn_prof_begin(kTag[sizeof(T) == 2 ? 0 : 1][BM == 256 ? (BN == 128 ? 3 : 2) : (BN == 128 ? 1 : 0)][MODE],
-                  2.0 * p.M * p.co * p.ktot,
-                  esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
-                  stream);
+  if constexpr (MODE == 3)
+    vdqn_prof_begin(sizeof(T) == 2 ? "stem_conv_pool<bf16>" : "stem_conv_pool<f32>", 2.0 * p.n_img * 112 * 112 * 64 * 147,
+                    esz * ((double)p.n_img * 115 * 115 * 16 + 64.0 * 256 + (double)p.n_img * 56 * 56 * 64) + (double)p.n_img * 56 * 56 * 64, stream);
+  else
+    vdqn_prof_begin(kTag[sizeof(T) == 2 ? 0 : 1][BM == 256 ? (BN == 128 ? 3 : 2) : (BN == 128 ? 1 : 0)][MODE],
+                    2.0 * p.M * p.co * p.ktot,
+                    esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
+                    stream);
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, MODE, WN>), dim3(grid), dim3(BM * WN), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
@@ -510,6 +599,7 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   VDQN_CHECK((a->pix_stride * esz) % 16 == 0 && (((uintptr_t)a->in | (uintptr_t)a->wt) & 15) == 0, "vdqn_conv2d: in/wt must be 16-byte aligned");
   IgemmParams p;
   p.in = a->in; p.wt = a->wt; p.bias = a->bias; p.resid = a->resid; p.mask = a->mask; p.out = a->out; p.out_f32 = a->out_f32; p.colsum_part = a->colsum_part;
+  p.pool_out = nullptr; p.pool_idx = nullptr;
   p.n_img = a->n_img; p.hi = a->hi; p.wi = a->wi; p.ci = a->ci; p.pix_stride = a->pix_stride;
   p.ho = a->ho; p.wo = a->wo; p.co = a->co; p.ldo = a->ldo; p.r = a->r; p.s = a->s; p.stride = a->stride; p.pad = a->pad;
   p.relu = a->relu;
@@ -549,4 +639,29 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   }
   if (a->dtype == VDQN_BF16) return bn == 128 ? launch_mode<bf16raw, 128, 128>(p, mode, st) : launch_mode<bf16raw, 128, 64>(p, mode, st);
   return bn == 128 ? launch_mode<float, 128, 128>(p, mode, st) : launch_mode<float, 128, 64>(p, mode, st);
+}
+
+extern "C" int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img, int32_t dtype,
+                                   void* stream) {
+  VDQN_CHECK(t_in && wt && bias && pool && idx && n_img > 0, "vdqn_stem_conv_pool: bad args");
+  VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_stem_conv_pool: bad dtype %d", dtype);
+  VDQN_CHECK((((uintptr_t)t_in | (uintptr_t)wt | (uintptr_t)pool | (uintptr_t)idx) & 15) == 0, "vdqn_stem_conv_pool: tensors must be 16-byte aligned");
+  const int esz = dtype == VDQN_BF16 ? 2 : 4;
+  VDQN_CHECK((long long)n_img * 64 < (1ll << 31) / 256, "vdqn_stem_conv_pool: too many images");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = t_in; p.wt = wt; p.bias = bias; p.pool_out = pool; p.pool_idx = (uint8_t*)idx;
+  p.n_img = n_img; p.hi = 115; p.wi = 115; p.ci = 64; p.pix_stride = 16;  // one K-step = 4 packed pixels x 16 = one kernel row
+  p.ho = 112; p.wo = 112; p.co = 64; p.ldo = 64; p.r = 4; p.s = 1; p.stride = 1; p.pad = 0; p.relu = 1;
+  p.howo = 112 * 112;
+  p.ktot = 256;
+  p.nk = p.ktot / (128 / esz);
+  p.tiles_m = n_img * 64;  // 8 x 8 patches of 7 x 7 pooled pixels per image
+  p.tiles_n = 1;
+  p.M = p.tiles_m * 256;
+  p.in_bytes = (long long)n_img * 115 * 115 * 16 * esz;
+  p.wt_bytes = 64 * p.ktot * esz;
+  p.vec_ok = 1;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == VDQN_BF16 ? launch_igemm<bf16raw, 256, 64, 3>(p, st) : launch_igemm<float, 256, 64, 3>(p, st);
 }

@@ -181,3 +181,14 @@ def avgpool_bwd(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     gx = torch.empty_like(x)
     _lib.check(lib.vdqn_avgpool_bwd(_ptr(g), _ptr(x), _ptr(gx), n, h * w, c, dtype_code(x), _stream()), "vdqn_avgpool_bwd")
     return gx
+
+
+def stem_conv_pool(t_in: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor):
+    """t_in [n,115,115,16] (pack_input), wt [64,4,1,64], bias f32 [64] -> (pool [n,56,56,64], idx uint8)."""
+    lib = _lib.load()
+    n = t_in.shape[0]
+    pool = torch.empty((n, 56, 56, 64), dtype=t_in.dtype, device=t_in.device)
+    idx = torch.empty((n, 56, 56, 64), dtype=torch.uint8, device=t_in.device)
+    _lib.check(lib.vdqn_stem_conv_pool(_ptr(t_in), _ptr(wt), _ptr(bias), _ptr(pool), _ptr(idx), n, dtype_code(t_in), _stream()),
+               "vdqn_stem_conv_pool")
+    return pool, idx
