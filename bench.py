@@ -32,8 +32,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
     ap.add_argument("--frames", type=int, default=1, help="views per sample (12 = BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])

@@ -59,9 +59,11 @@ struct FoldDesc {
   int64_t w_off, g_off, b_off, mean_off, var_off;
   int64_t wf_off, wd_off, bias_off, scale_off, dw_off, db_off;
   int co, ci, r, s, kind, co_pad, kf, k_ci, k_s, cd_rows, kd, has_bn, has_bias;
+  int tiled;       // packed by fold_tile_kernel (plain convs with ci % 64 == 0): 64 x 64-channel tiles through LDS
+  int tile_begin;  // first tile of this layer in fold_tile_kernel's grid
 };
 struct FoldTable {
-  int n;
+  int n, n_tiles;
   FoldDesc d[kMaxLayers];
 };
 // where unfold finds dL/dbias of layer i: tiles > 0 -> sum of dgrad-epilogue partials
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const fl
                                                    unsigned char* __restrict__ packed, int with_dgrad, int raw) {
   const FoldDesc& d = tab.d[blockIdx.y];
   const int which = blockIdx.z;
+  if (d.tiled) return;  // fold_tile_kernel's layers
   if (which == 1 && (!with_dgrad || d.wd_off < 0)) return;
   const long stride = (long)gridDim.x * blockDim.x;
   if (which == 0) {
@@ -231,6 +234,91 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const fl
   }
 }
 
+// Plain convolutions (3x3 / 1x1, ci % 64 == 0): one block packs a tile of 32 output channels x 64 input channels x all
+// taps.  The OIHW source of such a tile is 32 contiguous runs of 64*taps floats (coalesced 16-byte reads, each master
+// weight fetched once); the tile is transposed through LDS and written as contiguous runs into BOTH packed operands
+// (Wf rows [co][tap][c], Wd rows [c][tap][co]).  The element-wise kernel above read the master weights with a stride of `taps`
+// floats for Wf and of ci*taps floats for Wd: 706 MB of HBM traffic per launch for ~150 MB of algorithmic bytes (PMC).
+// grid: (64x64-channel tiles over all tiled layers, 2 halves of 32 output channels)
+template <typename T, int TAPS>
+__device__ __forceinline__ void fold_tile_body(const FoldDesc& d, const float* __restrict__ params, const float* __restrict__ bnstats,
+                                               unsigned char* __restrict__ packed, int with_dgrad, int raw, float* sW, float* s_scale, int t, int cot_sub) {
+  constexpr int COT = 32;              // output channels per block
+  constexpr int RUN = 64 * TAPS;       // floats per output channel in this tile (contiguous in OIHW)
+  constexpr int PITCH = RUN + 1;       // LDS row pitch: odd, so the column walk of the Wd pass spreads over the banks
+  const int ci_tiles = d.ci / 64;
+  const int cot = t / ci_tiles, cit = t - cot * ci_tiles;
+  const int co0 = cot * 64 + cot_sub * COT, c0 = cit * 64;
+  if (threadIdx.x < COT) {
+    const int co = co0 + threadIdx.x;
+    const float sc = co < d.co ? fold_scale(d, params, bnstats, co, raw) : 0.f;
+    s_scale[threadIdx.x] = sc;
+    if (cit == 0) {
+      float b = 0.f;
+      if (co < d.co) {
+        if (d.has_bn) b = raw ? 0.f : params[d.b_off + co] - bnstats[d.mean_off + co] * sc;
+        else if (d.has_bias) b = params[d.b_off + co];
+      }
+      reinterpret_cast<float*>(packed + d.bias_off)[co] = b;
+      reinterpret_cast<float*>(packed + d.scale_off)[co] = sc;
+    }
+  }
+  __syncthreads();
+  // master weights -> LDS in source order, scaled: 16-byte loads of the contiguous [c][tap] run of every output channel
+#pragma unroll 6
+  for (int i = threadIdx.x; i < COT * RUN / 4; i += 256) {
+    const int co_l = i / (RUN / 4), q = i - co_l * (RUN / 4);
+    const int co = co0 + co_l;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (co < d.co) v = *reinterpret_cast<const float4*>(params + d.w_off + ((long)co * d.ci + c0) * TAPS + 4 * q);
+    const float sc = s_scale[co_l];
+    float* dst = sW + co_l * PITCH + 4 * q;
+    dst[0] = v.x * sc; dst[1] = v.y * sc; dst[2] = v.z * sc; dst[3] = v.w * sc;
+  }
+  __syncthreads();
+  // Wf rows [co][tap][c]: a thread writes two consecutive channels (a wave: 128 contiguous channels' worth of one or two runs)
+  T* wf = reinterpret_cast<T*>(packed + d.wf_off);
+#pragma unroll 6
+  for (int i = threadIdx.x; i < COT * RUN / 2; i += 256) {
+    const int co_l = i / (RUN / 2), rem = i - co_l * (RUN / 2);
+    const int tap = rem >> 5, c_l = (rem & 31) * 2;
+    const float* src = sW + co_l * PITCH + c_l * TAPS + tap;
+    T o2[2] = {from_f32<T>(src[0]), from_f32<T>(src[TAPS])};
+    T* dst = wf + (long)(co0 + co_l) * d.kf + tap * d.ci + c0 + c_l;
+    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(o2);
+    else *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(o2);
+  }
+  if (with_dgrad && d.wd_off >= 0) {
+    // Wd rows [c][tap][co]: a thread writes two consecutive output channels
+    T* wd = reinterpret_cast<T*>(packed + d.wd_off);
+#pragma unroll 6
+    for (int i = threadIdx.x; i < COT * RUN / 2; i += 256) {
+      const int co_l = (i % (COT / 2)) * 2, rem = i / (COT / 2);
+      const int tap = rem % TAPS, c_l = rem / TAPS;
+      const float* src = sW + co_l * PITCH + c_l * TAPS + tap;
+      T o2[2] = {from_f32<T>(src[0]), from_f32<T>(src[PITCH])};
+      T* dst = wd + (long)(c0 + c_l) * d.kd + tap * d.co_pad + co0 + co_l;
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(o2);
+      else *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(o2);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fold_tile_kernel(const FoldTable tab, const float* __restrict__ params, const float* __restrict__ bnstats,
+                                                        unsigned char* __restrict__ packed, int with_dgrad, int raw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fold_smem[];
+  float* sW = reinterpret_cast<float*>(fold_smem);  // [32][64 * taps + 1] f32, source order
+  __shared__ float s_scale[32];
+  int li = 0;
+  for (int i = 0; i < tab.n; ++i)
+    if (tab.d[i].tiled && (int)blockIdx.x >= tab.d[i].tile_begin) li = i;
+  const FoldDesc& d = tab.d[li];
+  const int t = (int)blockIdx.x - d.tile_begin;
+  if (d.r * d.s == 9) fold_tile_body<T, 9>(d, params, bnstats, packed, with_dgrad, raw, sW, s_scale, t, (int)blockIdx.y);
+  else fold_tile_body<T, 1>(d, params, bnstats, packed, with_dgrad, raw, sW, s_scale, t, (int)blockIdx.y);
+}
+
 // grid: (max co, layers of the stage): one block per output channel
 // raw = 1: the weights were packed without BatchNorm folding; the BatchNorm parameter gradients were already written
 // by the train-mode BatchNorm backward
@@ -259,12 +347,28 @@ __global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, const 
     sc = params[d.g_off + co] * rstd;
   }
   float dot = 0.f;
-  for (int k = threadIdx.x; k < d.kf; k += 256) {
-    const long src = fold_src_index(d, co, k);
-    if (src >= 0) {
-      const float g = dw[k];
-      grads[d.w_off + src] = g * sc;
-      dot += g * params[d.w_off + src];
+  __shared__ float s_row[4608];  // one packed-layout dW' row of a plain convolution (<= 9 taps x 512 channels)
+  if (d.tiled && d.kf <= 4608) {
+    // packed row -> LDS (coalesced), then the OIHW row of the gradient and of the master weights is walked in ITS order
+    // (coalesced global accesses; the [tap][c] -> [c][tap] permutation happens on the LDS read)
+    for (int k = threadIdx.x; k < d.kf; k += 256) s_row[k] = dw[k];
+    __syncthreads();
+    const int taps = d.r * d.s;
+    const long base = d.w_off + (long)co * d.kf;
+    for (int i = threadIdx.x; i < d.kf; i += 256) {
+      const int c = i / taps, tap = i - c * taps;
+      const float g = s_row[tap * d.ci + c];
+      grads[base + i] = g * sc;
+      dot += g * params[base + i];
+    }
+  } else {
+    for (int k = threadIdx.x; k < d.kf; k += 256) {
+      const long src = fold_src_index(d, co, k);
+      if (src >= 0) {
+        const float g = dw[k];
+        grads[d.w_off + src] = g * sc;
+        dot += g * params[d.w_off + src];
+      }
     }
   }
   __shared__ float red[8];
@@ -512,6 +616,15 @@ void build_layers(vdqn_net* net) {
     d.dw_off = L.dw_off; d.db_off = L.db_off;
     d.co = L.co; d.ci = L.ci; d.r = L.r; d.s = L.s; d.kind = L.kind; d.co_pad = L.co_pad; d.kf = L.kf();
     d.k_ci = L.k_ci; d.k_s = L.k_s; d.cd_rows = L.k_ci; d.kd = L.kd(); d.has_bn = L.has_bn; d.has_bias = L.has_bias;
+    d.tiled = (L.kind == K_CONV && L.ci % 64 == 0 && (L.r * L.s == 9 || L.r * L.s == 1)) ? 1 : 0;
+    d.tile_begin = 0;
+  }
+  net->fold.n_tiles = 0;
+  for (int i = 0; i < net->fold.n; ++i) {
+    FoldDesc& d = net->fold.d[i];
+    if (!d.tiled) continue;
+    d.tile_begin = net->fold.n_tiles;
+    net->fold.n_tiles += (d.co_pad / 64) * (d.ci / 64);
   }
 }
 
@@ -889,10 +1002,22 @@ extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const f
   dim3 grid(256, (unsigned)net->layers.size(), 2);
   const int dgrad = with_dgrad & 1, raw = (with_dgrad >> 1) & 1;
   ProfScope ps_("fold_weights", 0.0, (double)net->trainable_numel * 4.0 + (double)net->packed_bytes * (dgrad ? 1.0 : 0.5), (hipStream_t)stream);
-  if (net->cfg.dtype == VDQN_BF16)
+  const size_t tile_smem = 32 * (64 * 9 + 1) * 4;  // [32 output channels][64 * taps + 1] f32
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_tile_kernel<bf16raw>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_tile_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_smem);
+    attr_set = true;
+  }
+  if (net->cfg.dtype == VDQN_BF16) {
     hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw);
-  else
+    hipLaunchKernelGGL((fold_tile_kernel<bf16raw>), dim3(net->fold.n_tiles, 2), dim3(256), tile_smem, (hipStream_t)stream, net->fold, params, bnstats,
+                       (unsigned char*)packed, dgrad, raw);
+  } else {
     hipLaunchKernelGGL((fold_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw);
+    hipLaunchKernelGGL((fold_tile_kernel<float>), dim3(net->fold.n_tiles, 2), dim3(256), tile_smem, (hipStream_t)stream, net->fold, params, bnstats,
+                       (unsigned char*)packed, dgrad, raw);
+  }
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }
