@@ -302,27 +302,89 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     VDQN_MFMA_ALL(CUR)                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
-  // prologue: tiles 0 and 1 in flight, wait for tile 0 only
-  VDQN_ISSUE(0, ikr, iks, ic0, VDQN_WSTEP())
-  VDQN_ADVANCE()
-  ++issued;
-  if (issued < nk) {
-    VDQN_ISSUE(1, ikr, iks, ic0, VDQN_WSTEP())
+  if constexpr (MODE == 3 && ESZ == 2) {
+    // Stem, bf16: K-step kr of conv row py reads the packed rows of conv row py + 1 at K-step kr - 1, so ONE staged window of
+    // 19 x 16 rows (window row wy*16 + px = 128 bytes at packed pixel (y0 + wy, x0 + px)) serves all four K-steps: the
+    // fragments of step kr are read 16 rows further down (the swizzle key px & 7 does not move).  The window (38 KiB) and
+    // the whole weight matrix (4 x 8 KiB) are staged once per tile — 70 KiB instead of 160 KiB through the L1 — and the
+    // K loop runs without barriers or DMA.  (A persistent one-workgroup-per-CU variant with the weights resident and the
+    // window double-buffered was slower: experiments/stem_persistent.hip.)
+    static_assert(MODE != 3 || ESZ != 2 || (AROWS == 8 && BROWS == 2), "stem staging assumes 256 threads");
+    constexpr int WROWS = 320;  // 19 * 16 = 304 window rows, rounded up to the 32-row staging pass
+    unsigned char* sBw = smem + WROWS * 128;
+    const int y0 = 14 * st_ty - 1, x0 = 14 * st_tx - 1;
+    uint32_t vw[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int R = lrow + RPS * i;
+      const int sy = y0 + (R >> 4);
+      const bool ok = (R < 304) && ((unsigned)sy < (unsigned)p.hi);
+      // a packed column of -1 / 115 (only read for conv columns that are never pooled) wraps inside the image or falls out
+      // of the descriptor's range (zeros): harmless either way
+      vw[i] = ok ? (uint32_t)((sy * p.wi + x0 + (R & 15)) * pixB + lchunk_a * 16) : kOob;
+    }
+    const int zero_ = 0;
+    VDQN_DMA4(vw[0], vw[1], vw[2], vw[3], lds_wave, rs_a, zero_);
+    const uint32_t lw1_ = lds_wave + 4 * PSTR, lw2_ = lds_wave + 8 * PSTR;
+    VDQN_DMA4(vw[4], vw[5], vw[6], vw[7], lw1_, rs_a, zero_);
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, 0 offen lds\n\t"
+        "s_add_u32 m0, %2, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds"
+        ::"v"(vw[8]), "v"(vw[9]), "s"(lw2_), "s"(rs_a), "n"(PSTR)
+        : "memory", "scc");
+#pragma unroll
+    for (int ks_ = 0; ks_ < 4; ++ks_) {  // weight rows lrow, lrow + 32 of K-step ks_
+      const uint32_t lbw_ = lds_wave + (uint32_t)(WROWS * 128 + ks_ * (BN * 128));
+      const int so_ = ks_ * 128;
+      asm volatile(
+          "s_nop 4\n\t"
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %4 offen lds\n\t"
+          "s_add_u32 m0, %2, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds"
+          ::"v"(b_off[0]), "v"(b_off[BROWS > 1 ? 1 : 0]), "s"(lbw_), "s"(rs_b), "s"(so_), "n"(PSTR)
+          : "memory", "scc");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* aw_ = smem + (wr * 64 + i16) * 128;
+    const unsigned char* bw_ = sBw + ((i16 >> 2) * CPL + (i16 & 3)) * 128;
+#pragma unroll
+    for (int kr_ = 0; kr_ < 4; ++kr_) {
+#pragma unroll
+      for (int f_ = 0; f_ < 4; ++f_) {
+        fa[0][0][f_] = *reinterpret_cast<const u32x4*>(aw_ + (kr_ * 16 + f_ * 16) * 128 + coff0);
+        fa[0][1][f_] = *reinterpret_cast<const u32x4*>(aw_ + (kr_ * 16 + f_ * 16) * 128 + coff1);
+      }
+#pragma unroll
+      for (int j_ = 0; j_ < NF; ++j_) {
+        fb[0][0][j_] = *reinterpret_cast<const u32x4*>(bw_ + kr_ * (BN * 128) + j_ * 4 * 128 + coff0);
+        fb[0][1][j_] = *reinterpret_cast<const u32x4*>(bw_ + kr_ * (BN * 128) + j_ * 4 * 128 + coff1);
+      }
+      VDQN_MFMA_ALL(0)
+    }
+  } else {
+    // prologue: tiles 0 and 1 in flight, wait for tile 0 only
+    VDQN_ISSUE(0, ikr, iks, ic0, VDQN_WSTEP())
     VDQN_ADVANCE()
     ++issued;
-    if constexpr (AROWS + BROWS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (AROWS + BROWS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (AROWS + BROWS == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (AROWS + BROWS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();  // tile 0 visible
-  VDQN_LOAD_FRAGS(0, 0)
-  for (int k = 0; k < nk; k += 2) {
-    VDQN_STEP(k, 0, 1)
-    if (k + 1 < nk) VDQN_STEP(k + 1, 1, 0)
+    if (issued < nk) {
+      VDQN_ISSUE(1, ikr, iks, ic0, VDQN_WSTEP())
+      VDQN_ADVANCE()
+      ++issued;
+      if constexpr (AROWS + BROWS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (AROWS + BROWS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (AROWS + BROWS == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if constexpr (AROWS + BROWS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // tile 0 visible
+    VDQN_LOAD_FRAGS(0, 0)
+    for (int k = 0; k < nk; k += 2) {
+      VDQN_STEP(k, 0, 1)
+      if (k + 1 < nk) VDQN_STEP(k + 1, 1, 0)
+    }
   }
 #undef VDQN_LOAD_FRAGS
 #undef VDQN_MFMA_ALL
@@ -365,32 +427,66 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
       const int pi = pp / 7, pj = pp - pi * 7;
       float best[E16];
       uint8_t bi[E16];
+      if constexpr (ESZ == 2) {
+        // post-ReLU bf16 values are >= +0 (or NaN), so their bit patterns order like unsigned integers with NaN on top;
+        // key = bits << 4 | (8 - tap) makes ONE v_max_u32 per element and tap do "larger value, else earlier tap"
+        uint32_t key[E16];
 #pragma unroll
-      for (int e = 0; e < E16; ++e) {
-        best[e] = -INFINITY;
-        bi[e] = 0;
-      }
-      bool first = true;
+        for (int e = 0; e < E16; ++e) key[e] = 0u;
+        bool any = false;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int py = 2 * pi + kh, y = 14 * st_ty - 1 + py;
-        if ((unsigned)y >= (unsigned)p.ho) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+          const int py = 2 * pi + kh, y = 14 * st_ty - 1 + py;
+          if ((unsigned)y >= (unsigned)p.ho) continue;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int px = 2 * pj + kw, x = 14 * st_tx - 1 + px;
-          if ((unsigned)x >= (unsigned)p.wo) continue;
-          const int r = py * 16 + px;
-          const uint4 v = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * E16));
-          const T* pv = reinterpret_cast<const T*>(&v);
+          for (int kw = 0; kw < 3; ++kw) {
+            const int px = 2 * pj + kw, x = 14 * st_tx - 1 + px;
+            if ((unsigned)x >= (unsigned)p.wo) continue;
+            const int r = py * 16 + px;
+            const uint4 v = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * E16));
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t tag = (uint32_t)(8 - (kh * 3 + kw));
 #pragma unroll
-          for (int e = 0; e < E16; ++e) {
-            const float fv = to_f32<T>(pv[e]);
-            if (first || fv > best[e] || fv != fv) {
-              best[e] = fv;
-              bi[e] = (uint8_t)(kh * 3 + kw);
+            for (int q = 0; q < 4; ++q) {
+              key[2 * q] = max(key[2 * q], ((w4[q] << 4) & 0x7fff0u) | tag);  // sign bit dropped: ReLU may leave -0.0
+              key[2 * q + 1] = max(key[2 * q + 1], ((w4[q] >> 12) & 0x7fff0u) | tag);
             }
+            any = true;
           }
-          first = false;
+        }
+#pragma unroll
+        for (int e = 0; e < E16; ++e) {
+          best[e] = any ? bf16_to_f32((bf16raw)(key[e] >> 4)) : -INFINITY;
+          bi[e] = any ? (uint8_t)(8u - (key[e] & 15u)) : (uint8_t)0;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < E16; ++e) {
+          best[e] = -INFINITY;
+          bi[e] = 0;
+        }
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int py = 2 * pi + kh, y = 14 * st_ty - 1 + py;
+          if ((unsigned)y >= (unsigned)p.ho) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int px = 2 * pj + kw, x = 14 * st_tx - 1 + px;
+            if ((unsigned)x >= (unsigned)p.wo) continue;
+            const int r = py * 16 + px;
+            const uint4 v = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * E16));
+            const T* pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int e = 0; e < E16; ++e) {
+              const float fv = to_f32<T>(pv[e]);
+              if (first || fv > best[e] || fv != fv) {
+                best[e] = fv;
+                bi[e] = (uint8_t)(kh * 3 + kw);
+              }
+            }
+            first = false;
+          }
         }
       }
       const size_t o = (((size_t)st_img * 56 + 7 * st_ty + pi) * 56 + 7 * st_tx + pj) * 64 + cg * E16;
