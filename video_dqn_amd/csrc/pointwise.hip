@@ -160,6 +160,67 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// Row-pair tiled variant (even input heights, c * sizeof(T) a multiple of 16): one block produces input rows 2k and 2k+1
+// of one image.  Row 2k only receives from pooled row k (kh = 1), row 2k+1 from pooled rows k (kh = 2) and k+1 (kh = 0),
+// so the block stages those two pooled rows of gy and idx in LDS once (each pooled element is then fetched from HBM/L2
+// by two blocks instead of by 2.25 scattered gathers) and writes full 16-byte vectors of gx.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_rows_kernel(const T* __restrict__ gy, const uint8_t* __restrict__ idx, const T* __restrict__ x,
+                                                               T* __restrict__ gx, int hi, int wi, int c) {
+  constexpr int E16 = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char mp_smem[];
+  const int ho = hi / 2, wo = wi / 2;
+  const int cg_n = c / E16;
+  const int n = blockIdx.y, k = blockIdx.x;
+  const int rows = (k + 1 < ho) ? 2 : 1;          // pooled rows k (and k + 1)
+  const int vec_row = wo * cg_n;                    // 16-byte gy vectors per pooled row
+  uint4* sG = reinterpret_cast<uint4*>(mp_smem);    // [2][wo][cg_n] gy vectors
+  uint8_t* sI = mp_smem + 2 * vec_row * 16;         // [2][wo][c] arg-max codes
+  const size_t prow = ((size_t)n * ho + k) * wo;    // first pooled pixel of row k
+  for (int i = threadIdx.x; i < rows * vec_row; i += 256) {
+    sG[i] = reinterpret_cast<const uint4*>(gy + prow * c)[i];
+    if constexpr (E16 == 8) reinterpret_cast<uint2*>(sI)[i] = reinterpret_cast<const uint2*>(idx + prow * c)[i];
+    else reinterpret_cast<uint32_t*>(sI)[i] = reinterpret_cast<const uint32_t*>(idx + prow * c)[i];
+  }
+  __syncthreads();
+  const int items = 2 * wi * cg_n;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int cg = it % cg_n;
+    const int t = it / cg_n;
+    const int w = t % wi, hr = t / wi;              // hr = 0: row 2k, 1: row 2k + 1
+    const int h = 2 * k + hr;
+    float s[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) s[e] = 0.f;
+    const int ow_lo = w / 2, ow_hi = min(wo - 1, (w + 1) / 2);
+    const int pr_hi = hr == 0 ? 0 : rows - 1;       // pooled rows (relative to k) whose window holds h
+    for (int pr = 0; pr <= pr_hi; ++pr) {
+      const int kh = h - (2 * (k + pr) - 1);
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const int tap = kh * 3 + (w - (2 * ow - 1));
+        const uint4 gv = sG[(pr * wo + ow) * cg_n + cg];
+        const T* pg = reinterpret_cast<const T*>(&gv);
+        const uint8_t* iv = sI + ((size_t)(pr * wo + ow) * cg_n + cg) * E16;
+#pragma unroll
+        for (int e = 0; e < E16; ++e)
+          if (iv[e] == tap) s[e] += to_f32<T>(pg[e]);
+      }
+    }
+    const size_t xo = (((size_t)n * hi + h) * wi + w) * c + cg * E16;
+    T ov[E16];
+    if (x) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(x + xo);
+      const T* px = reinterpret_cast<const T*>(&xv);
+#pragma unroll
+      for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(to_f32<T>(px[e]) > 0.f ? s[e] : 0.f);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(s[e]);
+    }
+    *reinterpret_cast<uint4*>(gx + xo) = *reinterpret_cast<const uint4*>(ov);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // fused Double-DQN target + TD loss + dQ   (train_q_network.py:134-169,180)
 // one thread per (sample, padded column); loss reduced per block, one atomic per block
@@ -332,6 +393,15 @@ extern "C" int vdqn_maxpool_bwd(const void* gy, const uint8_t* idx, const void* 
   const int e16 = dtype == VDQN_BF16 ? 8 : 4;
   const int g = grid_for((long)n_img * hi * wi * (c / e16), 65536);
   ProfScope ps_("maxpool_bwd", 0.0, (double)n_img * c * ((x ? 2.0 : 1.0) * hi * wi * (16 / e16) + (double)(hi / 2) * (wi / 2) * (16 / e16 + 1)), (hipStream_t)stream);
+  const size_t rows_smem = (size_t)2 * (wi / 2) * c * ((dtype == VDQN_BF16 ? 2 : 4) + 1);
+  if (hi % 2 == 0 && wi % 2 == 0 && n_img <= 65535 && rows_smem <= 64 * 1024) {  // row-pair tiles (the 112 x 112 x 64 stem gradient)
+    if (dtype == VDQN_BF16)
+      hipLaunchKernelGGL((maxpool_bwd_rows_kernel<bf16raw>), dim3(hi / 2, n_img), dim3(256), rows_smem, (hipStream_t)stream, (const bf16raw*)gy, idx, (const bf16raw*)x, (bf16raw*)gx, hi, wi, c);
+    else
+      hipLaunchKernelGGL((maxpool_bwd_rows_kernel<float>), dim3(hi / 2, n_img), dim3(256), rows_smem, (hipStream_t)stream, (const float*)gy, idx, (const float*)x, (float*)gx, hi, wi, c);
+    VDQN_LAUNCH_CHECK();
+    return VDQN_OK;
+  }
   if (dtype == VDQN_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)gy, idx, (const bf16raw*)x, (bf16raw*)gx, n_img, hi, wi, c);
   else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)gy, idx, (const float*)x, (float*)gx, n_img, hi, wi, c);
   VDQN_LAUNCH_CHECK();
