@@ -126,6 +126,8 @@ def main():
     net = NetEngine(3, 5, F, ec, args.dtype, 2 * B, device=dev)
     net.load_tensors(synth.make_state_dict(4, extra_capacity=ec, num_frames=F))  # same seed on every rank: replicas start identical
     comm = BucketAllReduce(world) if world > 1 else None
+    if world > 1 and not ec:
+        net.set_bn_sync(world)  # 'basic': global BatchNorm statistics (N ranks == one big batch)
     stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=args.target_update_interval,
                     world_size=world, allreduce=(comm.launch if comm else None))
 

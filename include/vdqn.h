@@ -255,6 +255,13 @@ int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnsta
 int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples,
                      void* acts, float* q_out, void* stream);
 
+/* SyncBN for ARCHITECTURE='basic' under data parallelism (without it N ranks are not one big batch).
+ * `fn` must SUM-all-reduce `count` f32 at `buf` (device memory inside the `acts` workspace passed to the forward/step
+ * call) across the ranks, in place, ordered on `stream`; it is called twice per BatchNorm layer and update (forward
+ * statistics, backward sums).  world_size <= 1 or fn == NULL switches it off (per-rank statistics, torch DDP's default). */
+typedef void (*vdqn_allreduce_fn)(void* user, float* buf, int64_t count, void* stream);
+int vdqn_net_set_bn_sync(vdqn_net* net, vdqn_allreduce_fn fn, void* user, int32_t world_size);
+
 /* ARCHITECTURE='basic' with the module in train mode (model.train(); archs/HabitatDQNMultiAction.py:37-40 leaves the
  * ResNet's BatchNorm layers in train mode): one model call over n_samples samples with batch statistics per frame
  * slot (features is applied slot by slot, :49-51); updates `bnstats` (momentum 0.1, unbiased variance) F times per

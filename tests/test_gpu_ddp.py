@@ -85,3 +85,66 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
     assert delta <= 2.5e-4 and (big[:nt] - r0["params"][:nt]).abs().mean().item() < 2e-6
     # the per-rank partial losses sum to the big-batch loss
     assert abs((r0["loss"] + r1["loss"]).item() - ns[1].loss.item()) < 1e-5 * abs(ns[1].loss.item()) + 1e-7
+
+
+# ---- ARCHITECTURE='basic': train-mode BatchNorm needs global statistics (SyncBN) for N ranks == one big batch ----
+def _make_basic(B, world, hook=None, sync=None):
+    from video_dqn_amd import synth
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    net = NetEngine(3, 5, 1, False, "f32", 2 * B)
+    net.load_tensors(synth.make_state_dict(7, extra_capacity=False))
+    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, world_size=world, allreduce=hook)
+    if sync is not None:
+        net.set_bn_sync(world, sync)
+    return net, stp
+
+
+def _worker_basic(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+
+    def through_host(t, stage=None):
+        torch.cuda.synchronize()
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+
+    ns = _make_basic(4, world, through_host, through_host)
+    tup = _batch(231, 8)
+    net, stp = ns
+    dev = "cuda"
+    lo, hi = rank * 4, rank * 4 + 4
+    stp.forward_backward(tup[0][lo:hi].contiguous().to(dev), tup[1][lo:hi].contiguous().to(dev), 1, tup[2][lo:hi].to(dev),
+                         tup[3][lo:hi].float().to(dev), tup[4][lo:hi].float().to(dev))
+    torch.cuda.synchronize()
+    torch.save({"grads": stp.grads.cpu(), "bnstats": net.bnstats.cpu(), "loss": stp.loss.cpu(), "q": stp.q_before.cpu()},
+               os.path.join(out_dir, f"basic{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_basic_arch_syncbn_two_ranks_equal_one_big_batch(tmp_path):
+    """With the SyncBN hook the BatchNorm statistics are global: the all-reduced gradient, the running statistics and
+    Q(s) of two ranks x 4 samples equal one process with 8 samples (f32, up to summation order)."""
+    world = 2
+    mp.spawn(_worker_basic, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "basic0.pt")
+    r1 = torch.load(tmp_path / "basic1.pt")
+    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["bnstats"], r1["bnstats"])
+    net, stp = _make_basic(8, 1)
+    tup = _batch(231, 8)
+    dev = "cuda"
+    stp.forward_backward(tup[0].contiguous().to(dev), tup[1].contiguous().to(dev), 1, tup[2].to(dev), tup[3].float().to(dev), tup[4].float().to(dev))
+    torch.cuda.synchronize()
+    big_g, big_s = stp.grads.cpu(), net.bnstats.cpu()
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    assert rel(r0["bnstats"], big_s) < 1e-5
+    assert rel(torch.cat([r0["q"], r1["q"]]), stp.q_before.cpu()) < 1e-4
+    assert abs((r0["loss"] + r1["loss"]).item() - stp.loss.item()) < 1e-4 * abs(stp.loss.item())
+    # gradients: same network, same global statistics -> agreement to rounding (a ReLU flip would show as ~1e-2)
+    assert rel(r0["grads"], big_g) < 2e-3

@@ -67,6 +67,8 @@ class StepArgs(C.Structure):
                 ("q_before", c_vp)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(None, c_vp, c_vp, c_i64, c_vp)  # vdqn_allreduce_fn(user, buf, count, stream)
+
 _SIGS = {
     "vdqn_last_error": (C.c_char_p, []),
     "vdqn_abi_version": (C.c_int, []),
@@ -89,6 +91,7 @@ _SIGS = {
     "vdqn_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(c_vp)]),
     "vdqn_net_destroy": (None, [c_vp]),
     "vdqn_net_set_overlap": (C.c_int, [c_vp, C.c_int]),
+    "vdqn_net_set_bn_sync": (C.c_int, [c_vp, c_vp, c_vp, c_i32]),
     "vdqn_net_num_params": (C.c_int, [c_vp]),
     "vdqn_net_param_info": (C.c_int, [c_vp, C.c_int, C.POINTER(ParamInfo)]),
     "vdqn_net_params_numel": (c_i64, [c_vp]),

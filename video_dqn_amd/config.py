@@ -10,7 +10,8 @@
 
 Keys added by this build (all optional, defaults reproduce the reference): BATCH_SIZE (the reference
 hard-codes 16, train_q_network.py:98), NUM_WORKERS (8), COMPUTE_DTYPE ('bf16' | 'f32'), NUM_FRAMES (0 = the
-reference's rule: 4 if PANORAMA or PREVIOUS_IMAGES else 1), SYNTHETIC_DATA (train on generated frames).
+reference's rule: 4 if PANORAMA or PREVIOUS_IMAGES else 1), SYNTHETIC_DATA (train on generated frames), SYNC_BN (ARCHITECTURE='basic' on several GPUs: global BatchNorm
+statistics, so N ranks equal the reference's single big batch; default True).
 """
 from __future__ import annotations
 
@@ -123,6 +124,7 @@ def get_cfg_defaults() -> CfgNode:
     c.COMPUTE_DTYPE = "bf16"
     c.NUM_FRAMES = 0
     c.SYNTHETIC_DATA = False
+    c.SYNC_BN = True
     return c
 
 

@@ -251,6 +251,17 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// cross-rank statistics (SyncBN): the two sums of every group are packed into one contiguous buffer, all-reduced by
+// the host's callback, and unpacked again.  dir = 0: work -> buf, 1: buf -> work
+__global__ void bn_sync_pack_kernel(float* __restrict__ work, float* __restrict__ buf, int groups, int C, int dir) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= groups * 2 * C) return;
+  const int g = i / (2 * C), r = i - g * 2 * C;
+  float* w = work + (size_t)g * 6 * C + 4 * C + r;
+  if (dir == 0) buf[i] = *w;
+  else *w = buf[i];
+}
+
 inline int grid_rows(int M, int* rpb) {
   int blocks = (M + 511) / 512;  // measured: more, smaller blocks lose to the per-block reduction + atomics
   if (blocks > 1024) blocks = 1024;
@@ -287,9 +298,10 @@ int make_geom(const char* who, int n_img, int hw, int c, int frames, int iph, in
 
 }  // namespace
 
-extern "C" int vdqn_bn_train_fwd(const void* y, const void* resid, void* z, const float* gamma, const float* beta, float* running_mean,
-                                 float* running_var, float* work, int32_t n_img, int32_t hw, int32_t c, int32_t num_frames,
-                                 int32_t imgs_per_half, int32_t relu, float momentum, float eps, int32_t dtype, void* stream) {
+// sync (may be null): all-reduce hook + scratch for SyncBN; the statistics then cover grp_rows * sync->world rows
+int vdqn_bn_train_fwd_impl(const void* y, const void* resid, void* z, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* work, int32_t n_img, int32_t hw, int32_t c, int32_t num_frames,
+                           int32_t imgs_per_half, int32_t relu, float momentum, float eps, int32_t dtype, void* stream, const BnSync* sync) {
   VDQN_CHECK(y && z && gamma && beta && work, "vdqn_bn_train_fwd: null arg");
   BnGeom gm;
   if (int rc = make_geom("vdqn_bn_train_fwd", n_img, hw, c, num_frames, imgs_per_half, dtype, &gm)) return rc;
@@ -304,7 +316,15 @@ extern "C" int vdqn_bn_train_fwd(const void* y, const void* resid, void* z, cons
     if (dtype == VDQN_BF16) hipLaunchKernelGGL((bn_sums_kernel<bf16raw, 0>), dim3(blocks, gm.groups), dim3(256), 0, st, (const bf16raw*)y, (const bf16raw*)nullptr, work, gm, c, rpb);
     else hipLaunchKernelGGL((bn_sums_kernel<float, 0>), dim3(blocks, gm.groups), dim3(256), 0, st, (const float*)y, (const float*)nullptr, work, gm, c, rpb);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, st, work, gamma, beta, running_mean, running_var, gm.groups, gm.grp_rows, c, momentum, eps);
+  int total_rows = gm.grp_rows;
+  if (sync && sync->fn && sync->world > 1) {
+    const int cnt = gm.groups * 2 * c;
+    hipLaunchKernelGGL(bn_sync_pack_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, work, sync->scratch, gm.groups, c, 0);
+    sync->fn(sync->user, sync->scratch, (int64_t)cnt, stream);
+    hipLaunchKernelGGL(bn_sync_pack_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, work, sync->scratch, gm.groups, c, 1);
+    total_rows = gm.grp_rows * sync->world;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, st, work, gamma, beta, running_mean, running_var, gm.groups, total_rows, c, momentum, eps);
   {
     const int per_img = hw * (c / (dtype == VDQN_BF16 ? 8 : 4));
     ProfScope ps("bn_apply", 0.0, elems * esz * (resid ? 3 : 2), st);
@@ -315,8 +335,16 @@ extern "C" int vdqn_bn_train_fwd(const void* y, const void* resid, void* z, cons
   return VDQN_OK;
 }
 
-extern "C" int vdqn_bn_train_bwd(const void* g, const void* y, void* dy, float* work, float* dgamma, float* dbeta, int32_t n_img, int32_t hw,
-                                 int32_t c, int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* stream) {
+extern "C" int vdqn_bn_train_fwd(const void* y, const void* resid, void* z, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float* work, int32_t n_img, int32_t hw, int32_t c, int32_t num_frames,
+                                 int32_t imgs_per_half, int32_t relu, float momentum, float eps, int32_t dtype, void* stream) {
+  return vdqn_bn_train_fwd_impl(y, resid, z, gamma, beta, running_mean, running_var, work, n_img, hw, c, num_frames, imgs_per_half, relu, momentum,
+                                eps, dtype, stream, nullptr);
+}
+
+// dgamma / dbeta receive the LOCAL sums (the flat gradient is summed over the ranks later); dy uses the global ones
+int vdqn_bn_train_bwd_impl(const void* g, const void* y, void* dy, float* work, float* dgamma, float* dbeta, int32_t n_img, int32_t hw,
+                           int32_t c, int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* stream, const BnSync* sync) {
   VDQN_CHECK(g && y && dy && work, "vdqn_bn_train_bwd: null arg");
   BnGeom gm;
   if (int rc = make_geom("vdqn_bn_train_bwd", n_img, hw, c, num_frames, imgs_per_half, dtype, &gm)) return rc;
@@ -330,14 +358,27 @@ extern "C" int vdqn_bn_train_bwd(const void* g, const void* y, void* dy, float* 
     else hipLaunchKernelGGL((bn_sums_kernel<float, 1>), dim3(blocks, gm.groups), dim3(256), 0, st, (const float*)g, (const float*)y, work, gm, c, rpb);
   }
   if (dgamma || dbeta) hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, st, work, dgamma, dbeta, gm.groups, c);
+  int total_rows = gm.grp_rows;
+  if (sync && sync->fn && sync->world > 1) {
+    const int cnt = gm.groups * 2 * c;
+    hipLaunchKernelGGL(bn_sync_pack_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, work, sync->scratch, gm.groups, c, 0);
+    sync->fn(sync->user, sync->scratch, (int64_t)cnt, stream);
+    hipLaunchKernelGGL(bn_sync_pack_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, work, sync->scratch, gm.groups, c, 1);
+    total_rows = gm.grp_rows * sync->world;
+  }
   {
     const int per_img = hw * (c / (dtype == VDQN_BF16 ? 8 : 4));
     ProfScope ps("bn_bwd_apply", 0.0, 3.0 * elems * esz, st);
-    if (dtype == VDQN_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16raw>), dim3(apply_chunks(per_img), n_img), dim3(256), 0, st, (const bf16raw*)g, (const bf16raw*)y, (bf16raw*)dy, work, gm, c, 1.0f / (float)gm.grp_rows);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(apply_chunks(per_img), n_img), dim3(256), 0, st, (const float*)g, (const float*)y, (float*)dy, work, gm, c, 1.0f / (float)gm.grp_rows);
+    if (dtype == VDQN_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16raw>), dim3(apply_chunks(per_img), n_img), dim3(256), 0, st, (const bf16raw*)g, (const bf16raw*)y, (bf16raw*)dy, work, gm, c, 1.0f / (float)total_rows);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(apply_chunks(per_img), n_img), dim3(256), 0, st, (const float*)g, (const float*)y, (float*)dy, work, gm, c, 1.0f / (float)total_rows);
   }
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
+}
+
+extern "C" int vdqn_bn_train_bwd(const void* g, const void* y, void* dy, float* work, float* dgamma, float* dbeta, int32_t n_img, int32_t hw,
+                                 int32_t c, int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* stream) {
+  return vdqn_bn_train_bwd_impl(g, y, dy, work, dgamma, dbeta, n_img, hw, c, num_frames, imgs_per_half, dtype, stream, nullptr);
 }
 
 extern "C" int vdqn_avgpool_fwd(const void* x, void* out, int32_t n_img, int32_t hw, int32_t c, int32_t dtype, void* stream) {

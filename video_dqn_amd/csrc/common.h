@@ -69,6 +69,19 @@ struct ProfScope {
   ProfScope(const char* tag, double flops, double bytes, hipStream_t s) : st(s) { vdqn_prof_begin(tag, flops, bytes, s); }
   ~ProfScope() { vdqn_prof_end(st); }
 };
+// SyncBN hook of the train-mode BatchNorm kernels (bn_train.hip; set through vdqn_net_set_bn_sync)
+struct BnSync {
+  vdqn_allreduce_fn fn;  // SUM all-reduce of `count` floats in place, ordered on `stream`
+  void* user;
+  float* scratch;        // device buffer for the packed sums (>= groups * 2 * channels floats)
+  int world;
+};
+int vdqn_bn_train_fwd_impl(const void* y, const void* resid, void* z, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* work, int32_t n_img, int32_t hw, int32_t c, int32_t num_frames, int32_t imgs_per_half,
+                           int32_t relu, float momentum, float eps, int32_t dtype, void* stream, const BnSync* sync);
+int vdqn_bn_train_bwd_impl(const void* g, const void* y, void* dy, float* work, float* dgamma, float* dbeta, int32_t n_img, int32_t hw, int32_t c,
+                           int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* stream, const BnSync* sync);
+
 #define VDQN_CHECK(cond, ...)        \
   do {                               \
     if (!(cond)) {                   \

@@ -78,7 +78,7 @@ struct ActLayout {
   int64_t h[8], o[8], ds[8];
   int64_t f8, l0, l1, q, qf;
   // ARCHITECTURE='basic' only: pooled features, raw (pre-BatchNorm) conv outputs, per-layer BatchNorm work areas
-  int64_t avg, r_c1, r_h[8], r_o[8], r_ds[8], bnw[kMaxLayers], bnw_begin, bnw_bytes;
+  int64_t avg, r_c1, r_h[8], r_o[8], r_ds[8], bnw[kMaxLayers], bnw_begin, bnw_bytes, bn_sync;
   int64_t total;
 };
 struct BwdLayout {
@@ -110,6 +110,7 @@ struct vdqn_net {
   // A second HIP stream for work that is independent of the main dependency chain: the weight gradients (they only
   // need gy, the data-gradient chain does not wait for them) and the target-network forward.  Blocks of the side
   // kernels fill the tail rounds of the main kernels (784..3136-block grids on 512 resident blocks).
+  BnSync bn_sync = {nullptr, nullptr, nullptr, 1};  // SyncBN hook ('basic' under data parallelism)
   int overlap = 1;
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> events;
@@ -654,7 +655,7 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
   L.l1 = take((int64_t)n_samples * 256 * e);
   L.q = take((int64_t)n_samples * 64 * e);
   L.qf = take((int64_t)n_samples * 64 * 4);
-  L.avg = L.r_c1 = L.bnw_begin = -1;
+  L.avg = L.r_c1 = L.bnw_begin = L.bn_sync = -1;
   L.bnw_bytes = 0;
   for (int b = 0; b < 8; ++b) L.r_h[b] = L.r_o[b] = L.r_ds[b] = -1;
   for (int i = 0; i < kMaxLayers; ++i) L.bnw[i] = -1;
@@ -673,6 +674,7 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
     for (size_t i = 0; i < net->layers.size(); ++i)
       if (net->layers[i].has_bn) L.bnw[i] = take((int64_t)2 * F * 6 * net->layers[i].co * 4);
     L.bnw_bytes = off - L.bnw_begin;
+    L.bn_sync = take((int64_t)2 * F * 2 * 512 * 4);  // packed sums of one layer (SyncBN scratch)
   }
   L.total = off;
   return L;
@@ -853,9 +855,11 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
 int run_bn(const vdqn_net* net, int li, const float* params, float* bnstats, unsigned char* acts, const ActLayout& A, const void* y,
            const void* resid, void* z, int n_img, int iph, int relu, hipStream_t st) {
   const Layer& L = net->layers[li];
-  return vdqn_bn_train_fwd(y, resid, z, params + L.g_off, params + L.b_off, bnstats + L.mean_off, bnstats + L.var_off,
-                           reinterpret_cast<float*>(acts + A.bnw[li]), n_img, L.ho * L.wo, L.co, net->cfg.num_frames, iph, relu, kBnMomentum,
-                           kBnEps, net->cfg.dtype, st);
+  BnSync sy = net->bn_sync;
+  sy.scratch = reinterpret_cast<float*>(acts + A.bn_sync);
+  return vdqn_bn_train_fwd_impl(y, resid, z, params + L.g_off, params + L.b_off, bnstats + L.mean_off, bnstats + L.var_off,
+                                reinterpret_cast<float*>(acts + A.bnw[li]), n_img, L.ho * L.wo, L.co, net->cfg.num_frames, iph, relu, kBnMomentum,
+                                kBnEps, net->cfg.dtype, st, &sy);
 }
 
 // ARCHITECTURE='basic' in train mode (archs/HabitatDQNMultiAction.py:37-40 leaves the ResNet in train mode): forward over
@@ -921,6 +925,15 @@ extern "C" int vdqn_net_set_overlap(vdqn_net* net, int on) {
   VDQN_CHECK(net, "vdqn_net_set_overlap: null net");
   if (net->side) (void)hipStreamSynchronize(net->side);
   net->overlap = on ? 1 : 0;
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_net_set_bn_sync(vdqn_net* net, vdqn_allreduce_fn fn, void* user, int32_t world_size) {
+  VDQN_CHECK(net, "vdqn_net_set_bn_sync: null net");
+  VDQN_CHECK(net->basic() || fn == nullptr, "vdqn_net_set_bn_sync: only ARCHITECTURE='basic' has train-mode BatchNorm");
+  net->bn_sync.fn = (fn && world_size > 1) ? fn : nullptr;
+  net->bn_sync.user = user;
+  net->bn_sync.world = world_size > 1 ? world_size : 1;
   return VDQN_OK;
 }
 
@@ -1151,8 +1164,10 @@ int block_backward(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayou
 int run_bn_bwd(const vdqn_net* net, const vdqn_step_args* a, int li, const ActLayout& A, const void* g, const void* y, void* dy, int n,
                hipStream_t st) {
   const Layer& L = net->layers[li];
-  return vdqn_bn_train_bwd(g, y, dy, reinterpret_cast<float*>((unsigned char*)a->acts_online + A.bnw[li]), a->grads + L.g_off, a->grads + L.b_off,
-                           n, L.ho * L.wo, L.co, net->cfg.num_frames, n, net->cfg.dtype, st);
+  BnSync sy = net->bn_sync;
+  sy.scratch = reinterpret_cast<float*>((unsigned char*)a->acts_online + A.bn_sync);
+  return vdqn_bn_train_bwd_impl(g, y, dy, reinterpret_cast<float*>((unsigned char*)a->acts_online + A.bnw[li]), a->grads + L.g_off, a->grads + L.b_off,
+                                n, L.ho * L.wo, L.co, net->cfg.num_frames, n, net->cfg.dtype, st, &sy);
 }
 
 // 'basic': BasicBlock b with train-mode BatchNorm; g_o[b] holds the (ReLU-masked) gradient of the block output

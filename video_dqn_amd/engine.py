@@ -156,6 +156,45 @@ class NetEngine:
                                                  _ptr(acts), _ptr(q), _stream()), "vdqn_net_forward")
         return q
 
+    # ---- SyncBN (ARCHITECTURE='basic' under data parallelism) ----------------------------------------
+    def set_bn_sync(self, world_size: int, allreduce=None) -> None:
+        """Make the train-mode BatchNorm statistics global over ``world_size`` ranks (N ranks == one big batch, as the
+        single-process reference computes them).  ``allreduce(t)`` must SUM-all-reduce the f32 device tensor ``t`` in
+        place on the current stream; default: ``torch.distributed.all_reduce``.  world_size <= 1 switches it off."""
+        self._need_gpu()
+        if world_size <= 1:
+            _lib.check(self.lib.vdqn_net_set_bn_sync(self.handle, None, None, 1), "vdqn_net_set_bn_sync")
+            self._bn_sync_cb = None
+            return
+        if allreduce is None:
+            import torch.distributed as dist
+
+            def allreduce(t):
+                dist.all_reduce(t)
+        owners = self._sync_buffers = getattr(self, "_sync_buffers", [])
+
+        def cb(user, buf, count, stream):
+            # `buf` lies inside one of the activation workspaces this engine was handed: wrap it as a tensor view
+            for ref in owners:
+                t = ref()
+                if t is None:
+                    continue
+                off = buf - t.data_ptr()
+                if 0 <= off and off + 4 * count <= t.numel():
+                    allreduce(t[off:off + 4 * count].view(torch.float32))
+                    return
+            raise _lib.VdqnError("SyncBN: statistics buffer is not inside a registered activation workspace")
+        self._bn_sync_cb = _lib.ALLREDUCE_FN(cb)  # keep the trampoline alive
+        _lib.check(self.lib.vdqn_net_set_bn_sync(self.handle, C.cast(self._bn_sync_cb, C.c_void_p), None, int(world_size)),
+                   "vdqn_net_set_bn_sync")
+
+    def register_sync_buffer(self, t: torch.Tensor) -> None:
+        import weakref
+        lst = self._sync_buffers = getattr(self, "_sync_buffers", [])
+        lst[:] = [r for r in lst if r() is not None]
+        if not any(r() is t for r in lst):
+            lst.append(weakref.ref(t))
+
     def forward_train(self, frames: torch.Tensor, src_kind: int, n_samples: int) -> torch.Tensor:
         """ARCHITECTURE='basic' with the module in train mode: batch statistics per frame slot, running statistics and
         num_batches_tracked updated (one model call, archs/HabitatDQNMultiAction.py:44-54 under model.train())."""
@@ -167,6 +206,7 @@ class NetEngine:
         with torch.cuda.device(self.device):
             q = torch.empty((n_samples, self.num_classes * self.action_dim), dtype=torch.float32, device=self.device)
             acts = self._acts_for(n_samples)
+            self.register_sync_buffer(acts)
             self._packed_version = -1  # self.packed now holds the un-folded weights
             _lib.check(self.lib.vdqn_net_forward_train(self.handle, _ptr(self.params), _ptr(self.bnstats), _ptr(self.packed),
                                                        _ptr(frames), src_kind, n_samples, _ptr(acts), _ptr(q), _stream()),
@@ -203,6 +243,7 @@ class TDStepper:
             self.packed_target = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
             self.acts_online = torch.empty(net.acts_bytes(batch if self.gtb else 2 * batch), dtype=torch.uint8, device=dev)
             self.acts_target = None if self.gtb else torch.empty(net.acts_bytes(batch), dtype=torch.uint8, device=dev)
+            net.register_sync_buffer(self.acts_online)
             self.bwd = torch.empty(net.bwd_bytes(batch), dtype=torch.uint8, device=dev)
             self.grads = torch.zeros(nt, dtype=torch.float32, device=dev)
             self.exp_avg = torch.zeros(nt, dtype=torch.float32, device=dev)
