@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvdqn.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
