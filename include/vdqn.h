@@ -156,6 +156,10 @@ int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, flo
 int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img,
                         int32_t dtype, void* stream);
 
+/* Row-wise softmax over the first n_valid columns of x[rows][ld] (f32), written to y[rows][ld] (other columns 0):
+ * `torch.softmax(x, dim=1)` of the inverse-action model's 3-way output (archs/inverse_action2.py:95). n_valid <= 64. */
+int vdqn_softmax_rows(const float* x, float* y, int32_t rows, int32_t ld, int32_t n_valid, void* stream);
+
 /* torch.optim.Adam step (train_q_network.py:124,227) over one flat f32 range:
  *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * Hyper-parameters are doubles like torch's python scalars (1-b2 is formed in double before rounding to f32). */
@@ -254,6 +258,13 @@ int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnsta
  * q_out: f32 [n_samples][num_classes*action_dim] (HabitatDQNMultiAction.forward, archs/...:44-54). */
 int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples,
                      void* acts, float* q_out, void* stream);
+
+/* The frozen ResNet-18 trunk only (eval-mode BatchNorm folded): frames -> 512 x 7 x 7 features, left in the `acts`
+ * workspace at vdqn_net_act_offset(net, n_samples, "o7") as NHWC [n_samples*F][7][7][512].  Serves the inverse-action
+ * model (archs/inverse_action2.py:50-56,72-77: `self.resnet18(k)`, `self.resnet18(k_plus_one)`), whose head is built
+ * from vdqn_conv2d calls by video_dqn_amd/inverse_model.py. */
+int vdqn_net_trunk_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples,
+                           void* acts, void* stream);
 
 /* SyncBN for ARCHITECTURE='basic' under data parallelism (without it N ranks are not one big batch).
  * `fn` must SUM-all-reduce `count` f32 at `buf` (device memory inside the `acts` workspace passed to the forward/step

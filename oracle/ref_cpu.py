@@ -294,3 +294,41 @@ def adam_reference(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     denom = v.sqrt() / math.sqrt(bc2) + eps
     p = p - (lr / bc1) * (m / denom)
     return p, m, v
+
+
+# ----------------------------------------------------------------------------------------------
+# archs/inverse_action2.py:45-100  the inverse-action model used to label actions of new video data
+# (dataset/process_episodes_real.py:84-95,164-179: model.eval(); acts = model(be, ae)[1].argmax(1))
+# ----------------------------------------------------------------------------------------------
+class InverseActionModel(nn.Module):
+    def __init__(self):
+        super().__init__()
+        trunk = resnet18()
+        self.resnet18 = nn.Sequential(*list(trunk.children())[:-2])  # :50-52
+        self.resnet18.eval()  # :55-57 frozen
+        for p in self.resnet18.parameters():
+            p.requires_grad = False
+        self.conv1 = nn.Conv2d(1024, 256, kernel_size=1)  # :60
+        self.conv2 = nn.Conv2d(256, 256, kernel_size=3)  # :61
+        self.conv3 = nn.Conv2d(256, 64, kernel_size=3)  # :62
+        self.dropout1 = nn.Dropout2d(0.5)  # :63
+        self.dropout2 = nn.Dropout2d(0.5)  # :64
+        self.fc1 = nn.Linear(64 * 3 * 3, 128)  # :65
+        self.fc2 = nn.Linear(128, 3)  # :66
+        self.fc_accuracy = nn.Linear(3, 3)  # :69
+
+    def forward(self, k, k_plus_one):  # :72-100
+        self.resnet18.eval()
+        a = self.resnet18(k)
+        b = self.resnet18(k_plus_one)
+        x = torch.cat([a, b], dim=1)
+        x = torch.relu(self.conv1(x))
+        x = torch.relu(self.conv2(x))
+        x = torch.relu(self.conv3(x))
+        x = x.view(x.size(0), -1)
+        x = torch.relu(self.fc1(x))
+        x = self.dropout1(x)
+        x = self.fc2(x)
+        encoding = torch.softmax(x, dim=1)
+        y = self.fc_accuracy(x)
+        return encoding, y

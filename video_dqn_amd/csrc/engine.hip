@@ -28,7 +28,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 4; }
+extern "C" int vdqn_abi_version(void) { return 5; }
 
 namespace {
 
@@ -815,7 +815,7 @@ int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const voi
 
 // forward over n_samples samples whose packed input already sits at `t_in`
 int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t_in, int n_samples, unsigned char* acts, const ActLayout& A,
-                 hipStream_t st) {
+                 hipStream_t st, bool trunk_only = false) {
   const int n = n_samples * net->cfg.num_frames;
   const int dt = net->cfg.dtype;
   if (A.c1 >= 0) {  // 'basic' eval path keeps the separate kernels (its train path needs the raw conv output anyway)
@@ -839,6 +839,7 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
     RC(run_conv(net, c2, packed, acts + A.h[b], acts + A.o[b], n, identity, 1, nullptr, st));
     x = acts + A.o[b];
   }
+  if (trunk_only) return VDQN_OK;  // the 512 x 7 x 7 features are in o7
   if (net->basic()) {
     RC(vdqn_avgpool_fwd(x, acts + A.avg, n, 49, 512, dt, st));
     RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.avg, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
@@ -1048,6 +1049,17 @@ extern "C" int vdqn_net_forward(vdqn_net* net, const void* packed, const void* f
   hipError_t e = hipMemcpy2DAsync(q_out, (size_t)nq * 4, ab + A.qf, 64 * 4, (size_t)nq * 4, (size_t)n_samples, hipMemcpyDeviceToDevice, st);
   VDQN_CHECK(e == hipSuccess, "vdqn_net_forward: q copy failed: %s", hipGetErrorString(e));
   return VDQN_OK;
+}
+
+extern "C" int vdqn_net_trunk_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples, void* acts,
+                                      void* stream) {
+  VDQN_CHECK(net && packed && frames && acts, "vdqn_net_trunk_forward: null arg");
+  VDQN_CHECK(n_samples >= 1 && n_samples <= net->cfg.max_batch, "vdqn_net_trunk_forward: n_samples %d exceeds max_batch %d", n_samples, net->cfg.max_batch);
+  hipStream_t st = (hipStream_t)stream;
+  const ActLayout A = act_layout(net, n_samples);
+  unsigned char* ab = (unsigned char*)acts;
+  RC(vdqn_pack_input(frames, src_kind, ab + A.t_in, n_samples * net->cfg.num_frames, net->cfg.dtype, st));
+  return forward_impl(net, (const unsigned char*)packed, ab + A.t_in, n_samples, ab, A, st, true);
 }
 
 extern "C" int vdqn_net_forward_train(vdqn_net* net, const float* params, float* bnstats, void* packed, const void* frames, int32_t src_kind,

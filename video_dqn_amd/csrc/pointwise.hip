@@ -408,6 +408,23 @@ extern "C" int vdqn_maxpool_bwd(const void* gy, const uint8_t* idx, const void* 
   return VDQN_OK;
 }
 
+__global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int ld, int n_valid) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float m = -INFINITY;
+  for (int j = 0; j < n_valid; ++j) m = fmaxf(m, x[(size_t)r * ld + j]);
+  float sum = 0.f;
+  for (int j = 0; j < n_valid; ++j) sum += expf(x[(size_t)r * ld + j] - m);
+  for (int j = 0; j < ld; ++j) y[(size_t)r * ld + j] = j < n_valid ? expf(x[(size_t)r * ld + j] - m) / sum : 0.f;
+}
+
+extern "C" int vdqn_softmax_rows(const float* x, float* y, int32_t rows, int32_t ld, int32_t n_valid, void* stream) {
+  VDQN_CHECK(x && y && rows > 0 && ld > 0 && n_valid > 0 && n_valid <= ld && n_valid <= 64, "vdqn_softmax_rows: bad args");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, y, rows, ld, n_valid);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
 extern "C" int vdqn_td_loss(const vdqn_td_args* a, void* stream) {
   VDQN_CHECK(a && a->q_before && a->q_after_online && a->q_after_target && a->act && a->rew && a->term && a->loss, "vdqn_td_loss: null arg");
   VDQN_CHECK(!a->use_valid || a->valid, "vdqn_td_loss: use_valid without valid mask");

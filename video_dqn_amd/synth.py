@@ -192,3 +192,33 @@ def make_batch(seed: int, batch: int, num_frames: int = 1, action_dim: int = 3, 
     valid = torch.ones((batch, 5), dtype=torch.int64)
     tup = (normalise_frames(fb), normalise_frames(fa), act, rew, term, gt, valid)
     return tup, (fb, fa)
+
+
+def make_inverse_state_dict(seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """A full state_dict of the inverse-action model (archs/inverse_action2.py:45-70: ``resnet18.<i>.*`` for the
+    Sequential over the ResNet children [:-2], then conv1..3, fc1, fc2, fc_accuracy), deterministic like make_state_dict."""
+    base = make_state_dict(seed)
+    seq = {"conv1": 0, "bn1": 1, "layer1": 4, "layer2": 5, "layer3": 6, "layer4": 7}
+    sd = OrderedDict()
+    for k, v in base.items():
+        if not k.startswith("resnet.") or k.startswith("resnet.fc."):
+            continue
+        parts = k.split(".")
+        sd["resnet18." + ".".join([str(seq[parts[1]])] + parts[2:])] = v
+
+    def conv(name, co, ci, ksz):
+        a = (6.0 / (ci * ksz * ksz)) ** 0.5
+        sd[name + ".weight"] = torch.from_numpy(uniform(seed, "inv." + name + ".weight", (co, ci, ksz, ksz), -a, a))
+        sd[name + ".bias"] = torch.from_numpy(uniform(seed, "inv." + name + ".bias", (co,), -0.1, 0.1))
+
+    def lin(name, out_f, in_f, scale=1.0):
+        a = scale * (3.0 / in_f) ** 0.5
+        sd[name + ".weight"] = torch.from_numpy(uniform(seed, "inv." + name + ".weight", (out_f, in_f), -a, a))
+        sd[name + ".bias"] = torch.from_numpy(uniform(seed, "inv." + name + ".bias", (out_f,), -0.1, 0.1))
+    conv("conv1", 256, 1024, 1)
+    conv("conv2", 256, 256, 3)
+    conv("conv3", 64, 256, 3)
+    lin("fc1", 128, 576, 1.4)
+    lin("fc2", 3, 128, 1.4)
+    lin("fc_accuracy", 3, 3, 1.0)
+    return sd
