@@ -23,6 +23,9 @@ def tag_of(kernel_name: str):
             return f"stem_conv_pool<{dt}>"
         size = "256x64" if bm == 256 else str(bn)
         return f"igemm<{dt},{size},{('fwd', 'dgrad', 'dgrad_s2')[mode]}>"
+    m = re.search(r"igemm_win_kernel<(unsigned short|float), (\d+), (\d+)>", kernel_name)
+    if m:
+        return f"igemm_win<{'bf16' if m[1] == 'unsigned short' else 'f32'},{m[2]},{('fwd', 'dgrad')[int(m[3])]}>"
     m = re.search(r"wgrad_kernel<(unsigned short|float), (\d+)>", kernel_name)
     if m:
         return f"wgrad<{'bf16' if m[1] == 'unsigned short' else 'f32'},{m[2]}>"
