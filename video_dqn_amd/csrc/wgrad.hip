@@ -339,23 +339,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // byte the block does three times the MFMAs of wgrad_kernel (which restages both operands for every tap).
 // Grid: (co tile, kernel row, ci tile) x split of the pixel range.
 // ---------------------------------------------------------------------------------------------------------
-template <int BT>
+template <int BCO, int BCI>
 __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) {
   typedef bf16raw T;
   constexpr int E16 = 8;
-  constexpr int RB = BT * 2;
-  constexpr int CPR = RB / 16;
-  constexpr int KSUB = wg_ksub<T, BT>();
+  constexpr int RBG = BCO * 2, RBX = BCI * 2;      // bytes per staged gy / x row (one pixel)
+  constexpr int CPRG = RBG / 16, CPRX = RBX / 16;
+  constexpr bool WSPLIT = (BCO == 64 && BCI == 64);  // every wave owns the whole 64x64 tile for one 32-pixel sub-step
+  constexpr int KSUB = WSPLIT ? 4 : 2;
   constexpr int KP = 32 * KSUB;
-  constexpr int NL = (KP * CPR) / 256;
+  constexpr int NLG = (KP * CPRG) / 256;
   constexpr int WR = KP + 8;                       // window rows (KP + 2 needed)
-  constexpr int NLX = (WR * CPR + 255) / 256;      // 16-byte slots per thread for the window (the last pass is partial)
-  constexpr bool WSPLIT = (BT == 64);
-  constexpr int NFR = 4;
+  constexpr int NLX = (WR * CPRX + 255) / 256;     // 16-byte slots per thread for the window (the last pass is partial)
+  constexpr int NFA = WSPLIT ? 4 : BCO / 32;       // 16-wide fragments per wave: output channels
+  constexpr int NFB = WSPLIT ? 4 : BCI / 32;       //                              input channels
+  static_assert((KP * CPRG) % 256 == 0 && (WR * CPRX - 256 * (NLX - 1)) % 64 == 0, "staging passes are whole waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;                         // [2][KP * RB]   gy tiles
-  unsigned char* sX = smem + 2 * KP * RB;           // [2][WR * RB]   x windows
-  unsigned char* sZ = sX + 2 * WR * RB;             // [RB]           zeros
+  unsigned char* sA = smem;                         // [2][KP * RBG]   gy tiles
+  unsigned char* sX = smem + 2 * KP * RBG;          // [2][WR * RBX]   x windows
+  unsigned char* sZ = sX + 2 * WR * RBX;            // [RBX]           zeros
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -366,12 +368,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
   t /= p.ci_tiles;
   const int kr = t % 3;
   const int co_tile = t / 3;
-  const int co0 = co_tile * BT, ci0 = ci_tile * BT;
+  const int co0 = co_tile * BCO, ci0 = ci_tile * BCI;
   const int kbeg = split * p.kchunk;
   const int kend = min(p.M, kbeg + p.kchunk);
   if (kbeg >= kend) return;
   const int nk = (kend - kbeg + KP - 1) / KP;
-  for (int i = tid; i < RB / 16; i += 256) reinterpret_cast<uint4*>(sZ)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < RBX / 16; i += 256) reinterpret_cast<uint4*>(sZ)[i] = make_uint4(0, 0, 0, 0);
 
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const unsigned long long g_ptr = (unsigned long long)p.gy, x_ptr = (unsigned long long)p.x;
@@ -381,29 +383,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
                       __builtin_amdgcn_readfirstlane(p.x_bytes), 0x00020000};
   constexpr unsigned kOobW = 0x80000000u;
   // 16-byte slot q = tid + 256 i of a staged tile: row q / CPR, source chunk (q % CPR) ^ swizzle(row) — recomputed per
-  // issue (shifts and xors) instead of held in registers: the three accumulator tiles need 192 of the 256 VGPRs
+  // issue (shifts and xors) instead of held in registers: the three accumulator tiles need most of the VGPRs
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const uint32_t lds_wave = lds_base + (uint32_t)wave_u * 1024u;
   const uint32_t ldg_b = (uint32_t)p.ldg * 2u;
   const uint32_t pix_b = (uint32_t)p.pix_stride * 2u;
-  constexpr int X_TAIL_WAVES = (WR * CPR - 256 * (NLX - 1)) / 64;  // waves that take part in the last window pass
+  constexpr int X_TAIL_WAVES = (WR * CPRX - 256 * (NLX - 1)) / 64;  // waves that take part in the last window pass
 
   auto issue_tile = [&](int kb, int buf) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int q = tid + 256 * i, lr = q / CPR;
-      const int ch = (q % CPR) ^ wg_swz<T, BT>(lr);
+    for (int i = 0; i < NLG; ++i) {
+      const int q = tid + 256 * i, lr = q / CPRG;
+      const int ch = (q % CPRG) ^ wg_swz<T, BCO>(lr);
       const int pm = kb + lr;
       const uint32_t vg = pm < kend ? (uint32_t)pm * ldg_b + (uint32_t)((co0 + ch * E16) * 2) : kOobW;
-      const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RB) + i * 4096);
+      const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RBG) + i * 4096);
       asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vg), "s"(la), "s"(rs_g) : "memory");
     }
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
       if (i == NLX - 1 && wave_u >= X_TAIL_WAVES) break;
-      const int q = tid + 256 * i, lr = q / CPR;
-      const int ch = (q % CPR) ^ wg_swz<T, BT>(lr);
+      const int q = tid + 256 * i, lr = q / CPRX;
+      const int ch = (q % CPRX) ^ wg_swz<T, BCI>(lr);
       const int pm = kb - 1 + lr;
       const bool ok = pm >= 0 && pm < p.M;
       const uint32_t pmu = ok ? (uint32_t)pm : 0u;
@@ -414,33 +416,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
       const int h = (int)oh + kr - 1;
       const bool okx = ok && ((unsigned)h < (unsigned)p.hi);
       const uint32_t vx = okx ? ((img * (uint32_t)p.hi + (uint32_t)h) * (uint32_t)p.wi + ow) * pix_b + (uint32_t)((ci0 + ch * E16) * 2) : kOobW;
-      const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RB + buf * (WR * RB) + i * 4096);
+      const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RBG + buf * (WR * RBX) + i * 4096);
       asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vx), "s"(lx), "s"(rs_x) : "memory");
     }
   };
 
-  f32x4 acc[3][NFR][NFR];
+  f32x4 acc[3][NFA][NFB];
 #pragma unroll
   for (int k3 = 0; k3 < 3; ++k3)
 #pragma unroll
-    for (int f = 0; f < NFR; ++f)
+    for (int f = 0; f < NFA; ++f)
 #pragma unroll
-      for (int j = 0; j < NFR; ++j) acc[k3][f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NFB; ++j) acc[k3][f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int wr = WSPLIT ? 0 : (wave >> 1), wc = WSPLIT ? 0 : (wave & 1);
   const int grp = lane >> 4, i16 = lane & 15;
   const int q4 = i16 >> 2, pp = i16 & 3;
   const int row = 4 * grp + q4;            // pixel row (of 32) this lane addresses in a transposing read; + 16 for the high half
   const int sub8 = (pp & 1) << 3;
-  const int szA = wg_swz<T, BT>(row);
-  typedef short s16x4v __attribute__((ext_vector_type(4)));
+  const int szA = wg_swz<T, BCO>(row);
 
   auto compute = [&](int buf, int kb) {
 #pragma unroll 1
     for (int sub0 = 0; sub0 < (WSPLIT ? 1 : KSUB); ++sub0) {
       const int sub = WSPLIT ? wave : sub0;
-      const unsigned char* a = sA + buf * (KP * RB) + sub * (32 * RB);
-      const unsigned char* xw = sX + buf * (WR * RB);
+      const unsigned char* a = sA + buf * (KP * RBG) + sub * (32 * RBG);
+      const unsigned char* xw = sX + buf * (WR * RBX);
       // image column of this lane's two pixels (rows `row` and `row + 16` of the sub-step)
       bool e_l[2], e_r[2];
 #pragma unroll
@@ -451,32 +452,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
         e_l[hh] = ow == 0;
         e_r[hh] = ow == (uint32_t)p.wo - 1;
       }
-      s16x8 af[NFR];
+      s16x8 af[NFA];
 #pragma unroll
-      for (int f = 0; f < NFR; ++f) {
-        const int cb = wr * (BT / 2) + f * 16;
-        const int off = row * RB + ((((cb >> 3) + (pp >> 1)) ^ szA) << 4) + sub8;
+      for (int f = 0; f < NFA; ++f) {
+        const int cb = wr * (BCO / 2) + f * 16;
+        const int off = row * RBG + ((((cb >> 3) + (pp >> 1)) ^ szA) << 4) + sub8;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + off + 16 * RB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + off + 16 * RBG));
         af[f] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const int jr = sub * 32 + row + ks;  // window row of the low half; high half: + 16 (same swizzle key for both)
-        const int szX = wg_swz<T, BT>(jr);
+        const int szX = wg_swz<T, BCI>(jr);
         const bool z0 = (ks == 0 && e_l[0]) || (ks == 2 && e_r[0]);
         const bool z1 = (ks == 0 && e_l[1]) || (ks == 2 && e_r[1]);
 #pragma unroll
-        for (int j = 0; j < NFR; ++j) {  // one x fragment live at a time (register budget)
-          const int cb = wc * (BT / 2) + j * 16;
-          const int off = jr * RB + ((((cb >> 3) + (pp >> 1)) ^ szX) << 4) + sub8;
+        for (int j = 0; j < NFB; ++j) {  // one x fragment live at a time (register budget)
+          const int cb = wc * (BCI / 2) + j * 16;
+          const int off = jr * RBX + ((((cb >> 3) + (pp >> 1)) ^ szX) << 4) + sub8;
           const unsigned char* p0 = z0 ? sZ + sub8 : xw + off;
-          const unsigned char* p1 = z1 ? sZ + sub8 : xw + off + 16 * RB;
+          const unsigned char* p1 = z1 ? sZ + sub8 : xw + off + 16 * RBX;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
           const s16x8 bj = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-          for (int f = 0; f < NFR; ++f)
+          for (int f = 0; f < NFA; ++f)
             acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bj), acc[ks][f][j], 0, 0, 0);
         }
       }
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
     compute(buf, kbeg + k * KP);
   }
 
-  // ---- three tap tiles -> dw (f32 atomics, 256-byte runs through LDS) ----
+  // ---- three tap tiles -> dw (f32 atomics, contiguous runs through LDS) ----
   const size_t row_len = (size_t)p.taps * p.ci;
   float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -501,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
     __syncthreads();  // staging buffers (or the previous tap's tile) are free
     if constexpr (WSPLIT) {
 #pragma unroll
-      for (int f = 0; f < NFR; ++f)
+      for (int f = 0; f < NFA; ++f)
 #pragma unroll
-        for (int j = 0; j < NFR; ++j)
+        for (int j = 0; j < NFB; ++j)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) red[wave * 4096 + (f * 16 + grp * 4 + reg) * 64 + j * 16 + i16] = acc[ks][f][j][reg];
       __syncthreads();
@@ -516,17 +517,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
       }
     } else {
 #pragma unroll
-      for (int f = 0; f < NFR; ++f)
+      for (int f = 0; f < NFA; ++f)
 #pragma unroll
-        for (int j = 0; j < NFR; ++j)
+        for (int j = 0; j < NFB; ++j)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg)
-            red[(wr * (BT / 2) + f * 16 + grp * 4 + reg) * BT + wc * (BT / 2) + j * 16 + i16] = acc[ks][f][j][reg];
+            red[(wr * (BCO / 2) + f * 16 + grp * 4 + reg) * BCI + wc * (BCI / 2) + j * 16 + i16] = acc[ks][f][j][reg];
       __syncthreads();
 #pragma unroll 8
-      for (int e = 0; e < BT * BT / 256; ++e) {
+      for (int e = 0; e < BCO * BCI / 256; ++e) {
         const int o = tid + 256 * e;
-        const int co = co0 + o / BT, ci = ci0 + o % BT;
+        const int co = co0 + o / BCI, ci = ci0 + o % BCI;
         if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, red[o]);
       }
     }
@@ -586,18 +587,20 @@ int launch_wgrad(const WgradParams& p, int tiles, int splitk, hipStream_t stream
   return VDQN_OK;
 }
 
-template <int BT>
+template <int BCO, int BCI>
 int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
-  constexpr int KP = 32 * wg_ksub<bf16raw, BT>();
-  const size_t smem = (size_t)(2 * KP + 2 * (KP + 8) + 1) * BT * 2;
+  constexpr int KP = 32 * ((BCO == 64 && BCI == 64) ? 4 : 2);
+  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * (KP + 8) + 1) * BCI * 2;
+  const size_t smem_epi = (BCO == 64 && BCI == 64) ? (size_t)4 * 64 * 64 * 4 : (size_t)BCO * BCI * 4;
+  const size_t smem = smem_stage > smem_epi ? smem_stage : smem_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_win_kernel<BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  vdqn_prof_begin(BT == 128 ? "wgrad_win<bf16,128>" : "wgrad_win<bf16,64>", 2.0 * p.M * p.co * p.taps * p.ci,
+  vdqn_prof_begin(BCO == 128 ? "wgrad_win<bf16,128x64>" : "wgrad_win<bf16,64>", 2.0 * p.M * p.co * p.taps * p.ci,
                   2.0 * ((double)p.M * p.ldg + (double)p.n_img * p.hi * p.wi * p.ci) + 4.0 * p.co * p.taps * p.ci, stream);
-  hipLaunchKernelGGL((wgrad_win_kernel<BT>), dim3(tiles * splitk), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((wgrad_win_kernel<BCO, BCI>), dim3(tiles * splitk), dim3(256), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
@@ -648,19 +651,21 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   p.kchunk = ((p.M + splitk - 1) / splitk + 127) / 128 * 128;  // multiple of every kernel variant's K-step
   int rc;
   static const int use_win = [] { const char* e = getenv("VDQN_WGRAD_WINDOW"); return e ? atoi(e) : 1; }();
-  // (64x64 tiles: 672 vs 420 TFLOP/s; for 128x128 tiles the three accumulator tiles leave no registers for fragment
-  // double-buffering and the window kernel is slower, 405-467 vs 650: VDQN_WGRAD_WINDOW=2 forces it for measurements)
-  if (use_win && (bt == 64 || use_win == 2) && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 &&
+  // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps.  Default: the
+  // 64-channel layers only (64x64 tiles, 672 vs 420 TFLOP/s).  VDQN_WGRAD_WINDOW=2 also routes the wider layers to
+  // 128(co) x 64(ci) window tiles — measured 557-601 vs 625-650 TFLOP/s for the generic 128x128 kernel, so not the default
+  if (use_win && (bt == 64 || use_win >= 2) && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 &&
       a->pix_stride == a->ci && a->wo >= 2 && a->hi == a->ho && a->wi == a->wo) {
-    // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps
-    const int wtiles = (co_pad / bt) * 3 * p.ci_tiles;
+    const int bco = bt, bci = 64;
+    p.ci_tiles = a->ci / bci;
+    const int wtiles = (co_pad / bco) * 3 * p.ci_tiles;
     int wsplit = a->splitk > 0 ? a->splitk : 512 / wtiles;
     const int max_split = (p.M + 255) / 256;
     if (wsplit > max_split) wsplit = max_split;
     if (wsplit < 1) wsplit = 1;
     p.splitk = wsplit;
     p.kchunk = ((p.M + wsplit - 1) / wsplit + 127) / 128 * 128;
-    rc = bt == 128 ? launch_wgrad_win<128>(p, wtiles, wsplit, st) : launch_wgrad_win<64>(p, wtiles, wsplit, st);
+    rc = bt == 128 ? launch_wgrad_win<128, 64>(p, wtiles, wsplit, st) : launch_wgrad_win<64, 64>(p, wtiles, wsplit, st);
   } else
   if (a->dtype == VDQN_BF16) rc = bt == 128 ? launch_wgrad<bf16raw, 128>(p, tiles, splitk, st) : launch_wgrad<bf16raw, 64>(p, tiles, splitk, st);
   else rc = bt == 128 ? launch_wgrad<float, 128>(p, tiles, splitk, st) : launch_wgrad<float, 64>(p, tiles, splitk, st);
