@@ -51,6 +51,12 @@ CONV_CASES = [
     (1, 128, 256, 28, 3, 2, 1),
     (3, 64, 64, 24, 3, 1, 1),   # 64-column layer, M not a multiple of the tile
     (2, 64, 64, 56, 3, 1, 1),   # layer1 geometry
+    # window kernels (3x3 / stride 1 / pad 1): edge geometry
+    (40, 64, 64, 3, 3, 1, 1),   # 9 pixels per image: one tile / one window spans 14 images
+    (7, 128, 64, 2, 3, 1, 1),   # 2-pixel rows: every pixel is a left or a right border
+    (1, 64, 64, 5, 3, 1, 1),    # M = 25 < one tile
+    (3, 512, 512, 7, 3, 1, 1),  # layer4 geometry, 8 channel chunks per tap
+    (2, 256, 128, 14, 3, 1, 1), # layer3 geometry, co != ci
 ]
 
 
