@@ -110,3 +110,32 @@ def test_run_train_basic_arch_defaults(tmp_path):
     with torch.no_grad():
         from helpers import relerr
         assert relerr(model(tup[0].cuda()), ref(tup[0])) < 6e-2
+
+
+def test_run_train_on_feather_jpeg_dataset_and_shards(tmp_path):
+    """C1-style plumbing on real files: config dir -> feather + JPEG frames -> loader (uint8, normalise fused on the GPU)
+    -> TD updates -> checkpoint; the same run from decoded-frame shards sees identical batches, so with one loader worker
+    and the same seed the two runs end with the same parameters; the inverse-action labelling utility writes the column
+    the loader reads."""
+    pytest.importorskip("pyarrow")  # feather I/O (present in the build container; skip where the image lacks it)
+    pytest.importorskip("PIL")
+    from test_shards_cpu import _make_dataset
+    from video_dqn_amd.config import ExperimentConfig
+    from video_dqn_amd.shards import build_shards
+    from video_dqn_amd.trainer import run_train
+    feather = _make_dataset(tmp_path, n=9)
+    shards = str(tmp_path / "shards")
+    build_shards(feather, shards, shard_frames=4, log=lambda *a: None)
+    finals = []
+    for tag, dataset in (("jpeg", feather), ("shards", shards)):
+        folder = tmp_path / f"exp_{tag}"
+        folder.mkdir()
+        (folder / "config.yml").write_text(
+            f"DATASET: '{dataset}'\nPANORAMA: False\nLOSS_CLIP: 'rect'\nARCHITECTURE: 'extra_capacity'\nLEARNING_RATE: 0.0001\n"
+            "GAMMA: 0.99\nUSE_INVERSE_ACTIONS: True\nCHECKPOINT_INTERVAL: 2\nNUM_STEPS: 2\nSEED: 4\nBATCH_SIZE: 4\nNUM_WORKERS: 0\n"
+            "COMPUTE_DTYPE: 'f32'\n")
+        cfg = ExperimentConfig(str(folder), device="cuda", tensorboard=False)
+        model, stepper, running = run_train(cfg)
+        assert os.path.exists(folder / "models" / "sample2.torch") and np.isfinite(running)
+        finals.append(model.engine.params.cpu().clone())
+    assert torch.equal(finals[0], finals[1]) or (finals[0] - finals[1]).abs().max().item() < 5e-4  # f32 atomics order only
