@@ -139,3 +139,27 @@ def test_run_train_on_feather_jpeg_dataset_and_shards(tmp_path):
         assert os.path.exists(folder / "models" / "sample2.torch") and np.isfinite(running)
         finals.append(model.engine.params.cpu().clone())
     assert torch.equal(finals[0], finals[1]) or (finals[0] - finals[1]).abs().max().item() < 5e-4  # f32 atomics order only
+
+    # frames resident in HBM: device-side gather == the loader's batches for the same indices; the trainer runs from it
+    from video_dqn_amd.shards import DeviceFrameStore, ShardDataset
+    for kw in (dict(inverse_actions=True), dict(one_action=True, value_learning=True, previous_images=True)):
+        store = DeviceFrameStore(shards, "cuda", **kw)
+        ds = ShardDataset(shards, **kw)
+        idx = [5, 0, 7, 3]
+        ref = ds.__getitems__(idx)[0]
+        got = store.gather(torch.tensor(idx, device="cuda"))
+        assert torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1]) and got[2] == 0
+        assert torch.equal(got[3].cpu(), ref[2]) and torch.equal(got[4].cpu(), ref[3].float()) and torch.equal(got[5].cpu(), ref[4].float())
+        assert torch.equal(got[6].cpu(), ref[6].float())
+        gt_ref = ref[5].float() if ref[5].dim() == 2 else ref[5].float().view(-1, 1).expand(-1, 5)
+        assert torch.equal(torch.nan_to_num(got[7].cpu(), nan=-1.0), torch.nan_to_num(gt_ref, nan=-1.0))
+    folder = tmp_path / "exp_resident"
+    folder.mkdir()
+    (folder / "config.yml").write_text(
+        f"DATASET: '{shards}'\nPANORAMA: False\nLOSS_CLIP: 'rect'\nARCHITECTURE: 'extra_capacity'\nUSE_INVERSE_ACTIONS: True\n"
+        "CHECKPOINT_INTERVAL: 3\nNUM_STEPS: 3\nSEED: 4\nBATCH_SIZE: 4\nNUM_WORKERS: 0\nDEVICE_RESIDENT_DATA: 'on'\n")
+    logs = []
+    cfg = ExperimentConfig(str(folder), device="cuda", tensorboard=False)
+    model, stepper, running = run_train(cfg, log=lambda *a: logs.append(" ".join(str(x) for x in a)))
+    assert any("resident in HBM" in l for l in logs) and np.isfinite(running)
+    assert os.path.exists(folder / "models" / "sample3.torch")

@@ -10,7 +10,8 @@
 
 Keys added by this build (all optional, defaults reproduce the reference): BATCH_SIZE (the reference
 hard-codes 16, train_q_network.py:98), NUM_WORKERS (8), COMPUTE_DTYPE ('bf16' | 'f32'), NUM_FRAMES (0 = the
-reference's rule: 4 if PANORAMA or PREVIOUS_IMAGES else 1), SYNTHETIC_DATA (train on generated frames), SYNC_BN (ARCHITECTURE='basic' on several GPUs: global BatchNorm
+reference's rule: 4 if PANORAMA or PREVIOUS_IMAGES else 1), SYNTHETIC_DATA (train on generated frames), DEVICE_RESIDENT_DATA ('auto' | 'on' | 'off': keep a decoded-frame shard
+dataset in HBM and gather minibatches on the device), SYNC_BN (ARCHITECTURE='basic' on several GPUs: global BatchNorm
 statistics, so N ranks equal the reference's single big batch; default True).
 """
 from __future__ import annotations
@@ -125,6 +126,7 @@ def get_cfg_defaults() -> CfgNode:
     c.NUM_FRAMES = 0
     c.SYNTHETIC_DATA = False
     c.SYNC_BN = True
+    c.DEVICE_RESIDENT_DATA = "auto"
     return c
 
 

@@ -115,6 +115,47 @@ class ShardDataset(data.Dataset):
             self._maps = [np.load(p, mmap_mode="r") for p in self._paths]
         return torch.from_numpy(np.array(self._maps[i // self.shard_frames][i % self.shard_frames]))
 
+    def __getitems__(self, indices):
+        """Batched fetch (torch DataLoader calls this with the whole index list of a batch when it exists): frames are
+        gathered shard by shard with one fancy-indexed copy each, straight into the batch tensors — no per-sample Python
+        work, no second collate copy.  Returns the already collated 7-tuple; pair it with ``collate_fn=collate_batches``."""
+        idx = np.asarray(indices, dtype=np.int64)
+        if self._maps is None:
+            self._maps = [np.load(p, mmap_mode="r") for p in self._paths]
+        nf = 4 if self.previous_images else 1
+
+        def gather(table):
+            fr = table[idx][:, :nf].reshape(-1)
+            out = np.empty((fr.shape[0], 224, 224, 3), dtype=np.uint8)
+            shard = fr // self.shard_frames
+            for s in np.unique(shard):
+                sel = np.nonzero(shard == s)[0]
+                loc = fr[sel] % self.shard_frames
+                order = np.argsort(loc, kind="stable")
+                out[sel[order]] = self._maps[s][loc[order]]
+            t = torch.from_numpy(out)
+            return t.view(len(idx), nf, 224, 224, 3) if self.previous_images else t
+        bi, ai = gather(self.before), gather(self.after)
+        detections = self.detector_score[idx]
+        reward = detections if self.confidence_reward else (detections > detection_thresholds).astype(np.int64)
+        valid = np.ones_like(reward)
+        if self.value_learning:
+            steps = self.steps_to_reward[idx]
+            gt = np.power(np.ones((len(idx), 5)) * self.gamma, steps)
+            gt[steps == np.inf] = np.nan
+        else:
+            gt = np.full((len(idx),), np.nan)
+        if self.inverse_actions:
+            action = self.actions[idx].astype(np.int64)
+        elif self.slam_actions:
+            raise NotImplementedError("not implemented")
+        elif self.one_action:
+            action = np.zeros(len(idx), dtype=np.int64)
+        else:
+            raise Exception("not implemented")
+        rew_t = torch.from_numpy(np.ascontiguousarray(reward))
+        return [(bi, ai, torch.from_numpy(action), rew_t, rew_t.clone(), torch.from_numpy(gt), torch.from_numpy(valid))]
+
     def __getitem__(self, index):
         if self.previous_images:
             bi = torch.stack([self._frame(int(i)) for i in self.before[index]])
@@ -141,6 +182,98 @@ class ShardDataset(data.Dataset):
         else:
             raise Exception("not implemented")
         return bi, ai, action, reward, reward, gt, valid_mask
+
+
+class DeviceFrameStore:
+    """The whole decoded-frame dataset resident in HBM (MI355X: 288 GB = 1.9 M frames of 224x224x3 uint8).
+
+    The DataLoader path tops out at 10-20 k samples/s on the GPU box's host (tools/bench_loader.py: worker -> shared
+    memory -> pinned memory copies of 77 MB batches), a third to a half of what one GPU consumes (34 k tuples/s).  With
+    the frames in HBM a minibatch is an index gather on the device — no host traffic at all — and the loop runs at the
+    speed of bench.py.  Semantics are those of ``ShardDataset`` (same labels, same 7-tuple, frames as uint8) with the
+    loader's shuffle + drop_last (train_q_network.py:98,114) done by a seeded device permutation per epoch; under data
+    parallelism every rank holds the full store and takes the rank-strided slice of each epoch's permutation."""
+
+    def __init__(self, location, device, **flags):
+        ds = ShardDataset(location, **flags)
+        self.flags = ds
+        self.device = torch.device(device)
+        maps = [np.load(p, mmap_mode="r") for p in ds._paths]
+        n_frames = sum(m.shape[0] for m in maps)
+        self.frames = torch.empty((n_frames, 224, 224, 3), dtype=torch.uint8, device=self.device)
+        lo = 0
+        for m in maps:  # shard by shard through pinned staging: never more than one shard on the host
+            t = torch.from_numpy(np.ascontiguousarray(m))
+            self.frames[lo:lo + t.shape[0]].copy_(t.pin_memory() if torch.cuda.is_available() else t, non_blocking=False)
+            lo += t.shape[0]
+        nf = 4 if ds.previous_images else 1
+        self.nf = nf
+        self.before = torch.from_numpy(ds.before[:, :nf].astype(np.int64)).to(self.device)
+        self.after = torch.from_numpy(ds.after[:, :nf].astype(np.int64)).to(self.device)
+        all_idx = np.arange(len(ds))
+        lab = self._labels(ds, all_idx)
+        self.act, self.rew, self.term, self.gt, self.valid = (x.to(self.device) for x in lab)
+
+    @staticmethod
+    def _labels(ds, idx):
+        detections = ds.detector_score[idx]
+        reward = detections if ds.confidence_reward else (detections > detection_thresholds).astype(np.int64)
+        valid = np.ones_like(reward)
+        if ds.value_learning:
+            steps = ds.steps_to_reward[idx]
+            gt = np.power(np.ones((len(idx), 5)) * ds.gamma, steps)
+            gt[steps == np.inf] = np.nan
+        else:
+            gt = np.full((len(idx), 5), np.nan)
+        if ds.inverse_actions:
+            action = ds.actions[idx].astype(np.int64)
+        elif ds.slam_actions:
+            raise NotImplementedError("not implemented")
+        elif ds.one_action:
+            action = np.zeros(len(idx), dtype=np.int64)
+        else:
+            raise Exception("not implemented")
+        rew_t = torch.from_numpy(np.ascontiguousarray(reward)).float()
+        return (torch.from_numpy(action), rew_t, rew_t.clone(), torch.from_numpy(gt).float(), torch.from_numpy(valid).float())
+
+    def __len__(self):
+        return self.before.shape[0]
+
+    def bytes(self):
+        return self.frames.numel()
+
+    def gather(self, idx: torch.Tensor):
+        """Device batch for sample indices ``idx`` (int64 device tensor), in the order trainer._to_device_batch produces:
+        (before, after, src_kind=0, act, rew, term, valid, gt)."""
+        b = self.frames.index_select(0, self.before.index_select(0, idx).reshape(-1))
+        a = self.frames.index_select(0, self.after.index_select(0, idx).reshape(-1))
+        if self.nf > 1:
+            b = b.view(idx.shape[0], self.nf, 224, 224, 3)
+            a = a.view(idx.shape[0], self.nf, 224, 224, 3)
+        return (b, a, 0, self.act.index_select(0, idx), self.rew.index_select(0, idx), self.term.index_select(0, idx),
+                self.valid.index_select(0, idx), self.gt.index_select(0, idx))
+
+    def batches(self, batch_size: int, seed: int, rank: int = 0, world_size: int = 1):
+        """Endless stream of device batches: per epoch one seeded permutation (identical on every rank), rank r takes
+        perm[r::world], drop_last."""
+        epoch = 0
+        n = len(self)
+        per_rank = (n // world_size // batch_size) * batch_size
+        if per_rank == 0:
+            raise ValueError(f"dataset of {n} samples is smaller than one global batch ({batch_size} x {world_size})")
+        while True:
+            g = torch.Generator(device="cpu")
+            g.manual_seed(seed + epoch)
+            perm = torch.randperm(n, generator=g)[rank::world_size][:per_rank].to(self.device)
+            for lo in range(0, per_rank, batch_size):
+                yield self.gather(perm[lo:lo + batch_size])
+            epoch += 1
+            print("reset iterator")
+
+
+def collate_batches(items):
+    """collate_fn for ShardDataset.__getitems__: the fetch already produced the collated batch."""
+    return items[0]
 
 
 if __name__ == "__main__":

@@ -136,6 +136,7 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
     log(f"Using: {config.device}")
     B = int(config.BATCH_SIZE)
     params = {"batch_size": B, "num_workers": int(config.NUM_WORKERS), "drop_last": True}
+    store = None  # DeviceFrameStore when the decoded frames live in HBM
     if config.SYNTHETIC_DATA or config.DATASET in ("none", "synthetic"):
         nf = config.NUM_FRAMES or (4 if (config.PANORAMA or config.PREVIOUS_IMAGES) else 1)
         dataset = SyntheticTupleDataset(length=max(4 * B * world_size, 1024), num_frames=nf,
@@ -145,6 +146,19 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                   inverse_actions=config.USE_INVERSE_ACTIONS, previous_images=config.PREVIOUS_IMAGES)
         if is_shard_dir(config.DATASET):  # pre-decoded uint8 frames (python -m video_dqn_amd.shards)
             dataset = ShardDataset(config.DATASET, **kw)
+            resident = str(getattr(config, "DEVICE_RESIDENT_DATA", "auto")).lower()
+            if resident not in ("auto", "on", "off"):
+                raise ValueError("DEVICE_RESIDENT_DATA must be 'auto', 'on' or 'off'")
+            if resident != "auto":
+                resident = resident == "on"
+            else:  # frames + 32 GiB of headroom must fit in the GPU's free memory
+                n_frames = sum(np.load(p_, mmap_mode="r").shape[0] for p_ in dataset._paths)
+                free, _ = torch.cuda.mem_get_info(torch.device(config.device))
+                resident = n_frames * 224 * 224 * 3 + (32 << 30) < free
+            if resident:
+                from .shards import DeviceFrameStore
+                store = DeviceFrameStore(config.DATASET, config.device, **kw)
+                log(f"dataset resident in HBM: {store.bytes() / 2**30:.2f} GiB of frames")
         else:
             dataset = QLearningRealDataset(config.DATASET, as_uint8=True, **kw)
         log(f"Load data from {config.DATASET}")
@@ -153,8 +167,12 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
     if world_size > 1:
         sampler = data.distributed.DistributedSampler(dataset, num_replicas=world_size, rank=rank, shuffle=True,
                                                       seed=config.SEED, drop_last=True)
+    extra = {}
+    if isinstance(dataset, ShardDataset):  # batched fetch: one gather per shard and batch instead of per-sample copies + collate
+        from .shards import collate_batches
+        extra["collate_fn"] = collate_batches
     loader = data.DataLoader(dataset, **params, shuffle=(sampler is None), sampler=sampler, pin_memory=True,
-                             persistent_workers=params["num_workers"] > 0)
+                             persistent_workers=params["num_workers"] > 0, **extra)
     log(len(dataset))
 
     model = build_model(config, max_batch=2 * B)
@@ -167,7 +185,10 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                         allreduce=(comm.launch if comm else None))
     if world_size > 1 and config.ARCHITECTURE != "extra_capacity" and getattr(config, "SYNC_BN", True):
         model.engine.set_bn_sync(world_size)  # train-mode BatchNorm over the global batch, as the single-GPU reference sees it
-    iterator = DevicePrefetcher(loopLoader(loader, on_reset=(sampler.set_epoch if sampler else None)), model.engine.device)
+    if store is not None:  # minibatches are gathered on the device; no loader, no host copies
+        iterator = store.batches(B, config.SEED, rank, world_size)
+    else:
+        iterator = DevicePrefetcher(loopLoader(loader, on_reset=(sampler.set_epoch if sampler else None)), model.engine.device)
     os.makedirs(f"{config.folder}/models", exist_ok=True)
     sample_number = resume_from + 1
     if resume_from > -1:  # :192-198
