@@ -145,6 +145,7 @@ def test_run_train_on_feather_jpeg_dataset_and_shards(tmp_path):
     for kw in (dict(inverse_actions=True), dict(one_action=True, value_learning=True, previous_images=True)):
         store = DeviceFrameStore(shards, "cuda", **kw)
         ds = ShardDataset(shards, **kw)
+        ds.batched_fetch = True
         idx = [5, 0, 7, 3]
         ref = ds.__getitems__(idx)[0]
         got = store.gather(torch.tensor(idx, device="cuda"))

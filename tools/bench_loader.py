@@ -33,9 +33,8 @@ def run(root, workers, batch=256, batches=40, batched_fetch=True):
     ds = ShardDataset(root, inverse_actions=True)
     kw = dict(batch_size=batch, shuffle=True, drop_last=True, num_workers=workers, pin_memory=True, persistent_workers=workers > 0)
     if batched_fetch:
+        ds.batched_fetch = True
         kw["collate_fn"] = collate_batches
-    else:
-        ds.__class__ = type("PerSample", (ShardDataset,), {"__getitems__": None})
     loader = data.DataLoader(ds, **kw)
     it = iter(loader)
     for _ in range(3):

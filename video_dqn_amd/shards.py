@@ -118,7 +118,10 @@ class ShardDataset(data.Dataset):
     def __getitems__(self, indices):
         """Batched fetch (torch DataLoader calls this with the whole index list of a batch when it exists): frames are
         gathered shard by shard with one fancy-indexed copy each, straight into the batch tensors — no per-sample Python
-        work, no second collate copy.  Returns the already collated 7-tuple; pair it with ``collate_fn=collate_batches``."""
+        work, no second collate copy.  Opt-in: set ``dataset.batched_fetch = True`` AND pass ``collate_fn=collate_batches``
+        (then the already collated 7-tuple is returned); otherwise this behaves like per-sample ``__getitem__``."""
+        if not getattr(self, "batched_fetch", False):  # plain DataLoader (default collate): per-sample semantics
+            return [self[int(i)] for i in indices]
         idx = np.asarray(indices, dtype=np.int64)
         if self._maps is None:
             self._maps = [np.load(p, mmap_mode="r") for p in self._paths]

@@ -170,6 +170,7 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
     extra = {}
     if isinstance(dataset, ShardDataset):  # batched fetch: one gather per shard and batch instead of per-sample copies + collate
         from .shards import collate_batches
+        dataset.batched_fetch = True
         extra["collate_fn"] = collate_batches
     loader = data.DataLoader(dataset, **params, shuffle=(sampler is None), sampler=sampler, pin_memory=True,
                              persistent_workers=params["num_workers"] > 0, **extra)
