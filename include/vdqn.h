@@ -160,6 +160,15 @@ int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, voi
  * `torch.softmax(x, dim=1)` of the inverse-action model's 3-way output (archs/inverse_action2.py:95). n_valid <= 64. */
 int vdqn_softmax_rows(const float* x, float* y, int32_t rows, int32_t ld, int32_t n_valid, void* stream);
 
+/* Training of the inverse-action model (train_inverse_model.py:86-112): mean nn.CrossEntropyLoss over `rows` samples of
+ * f32 logits[rows][ld] (first n_cls columns) and its gradient (softmax - onehot) * inv_count as `dtype` elements;
+ * dropout with a caller-supplied 0/1 mask: out = x * mask * scale (forward and backward); y += alpha * x (Adam's
+ * weight_decay term, train_inverse_model.py:190). */
+int vdqn_softmax_ce(const float* logits, const int64_t* labels, float* loss, void* dlogits, int32_t rows, int32_t ld,
+                    int32_t n_cls, float inv_count, int32_t dtype, void* stream);
+int vdqn_mask_scale(const void* x, const void* mask, void* out, int64_t n, float scale, int32_t dtype, void* stream);
+int vdqn_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);
+
 /* torch.optim.Adam step (train_q_network.py:124,227) over one flat f32 range:
  *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * Hyper-parameters are doubles like torch's python scalars (1-b2 is formed in double before rounding to f32). */

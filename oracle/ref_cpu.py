@@ -332,3 +332,35 @@ class InverseActionModel(nn.Module):
         encoding = torch.softmax(x, dim=1)
         y = self.fc_accuracy(x)
         return encoding, y
+
+
+# ----------------------------------------------------------------------------------------------
+# train_inverse_model.py:30-83  the TRAINING script's own copy of the model (an extra ReLU after fc2, one dropout)
+# and one optimisation step of its loop (:86-112): CrossEntropyLoss, Adam(lr, weight_decay), StepLR per epoch (:190-199)
+# ----------------------------------------------------------------------------------------------
+class InverseTrainModel(InverseActionModel):
+    def forward(self, k, k_plus_one, dropout_mask=None):  # :59-83
+        self.resnet18.eval()
+        x = torch.cat([self.resnet18(k), self.resnet18(k_plus_one)], dim=1)
+        x = torch.relu(self.conv1(x))
+        x = torch.relu(self.conv2(x))
+        x = torch.relu(self.conv3(x))
+        x = x.view(x.size(0), -1)
+        x = torch.relu(self.fc1(x))
+        if dropout_mask is not None:  # the mask torch's Dropout2d(0.5) drew in the golden run, replayed
+            x = x * dropout_mask * 2.0
+        elif self.training:
+            x = self.dropout1(x)
+        x = torch.relu(self.fc2(x))
+        return self.fc_accuracy(x)
+
+
+def inverse_train_step(model, optimizer, be, ae, act, dropout_mask=None):
+    """train_inverse_model.py:93-112 for one minibatch; returns (loss, y)."""
+    model.train()
+    optimizer.zero_grad()
+    y = model(be, ae, dropout_mask)
+    loss = nn.CrossEntropyLoss()(y, act)
+    loss.backward()
+    optimizer.step()
+    return loss.item(), y.detach()

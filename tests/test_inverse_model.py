@@ -75,3 +75,40 @@ def test_gpu_forward_matches_reference_golden(ginv, dtype, tol):
     m.train()
     with pytest.raises(Exception):
         m(be.cuda(), ae.cuda())
+
+
+@pytest.mark.gpu
+def test_gpu_training_steps_match_reference_golden():
+    """Two optimisation steps of train_inverse_model.py (reference model class + loop statements, goldens G10) with the
+    dropout masks of the golden run replayed: loss, logits, every head gradient, post-Adam parameters (f32)."""
+    from video_dqn_amd.inverse_model import InverseActionModel
+    from video_dqn_amd.inverse_train import InverseTrainer
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_inverse_train.npz"), allow_pickle=False)
+    m = InverseActionModel(dtype="f32", device="cuda", max_batch=8)
+    m.load_state_dict(synth.make_inverse_state_dict(21), strict=True)
+    tr = InverseTrainer(m, lr=1e-4, weight_decay=0.0)
+    assert tr.names == list(g["g10_trainable"])
+    B, lr = 6, 1e-4
+    for step in (1, 2):
+        be = synth.normalise_frames(synth.make_frames_uint8(70 + step, "be", B, 1, structured=True))
+        ae = synth.normalise_frames(synth.make_frames_uint8(70 + step, "ae", B, 1, structured=True))
+        act = torch.from_numpy(synth.randint(70 + step, "act", (B,), 3))
+        loss, y = tr.step(be.cuda(), ae.cuda(), act.cuda(), torch.from_numpy(g[f"g10_s{step}_mask"]))
+        torch.cuda.synchronize()
+        k = f"g10_s{step}"
+        np.testing.assert_allclose(loss.item(), float(g[f"{k}_loss"]), rtol=1e-3)
+        ref_y = torch.from_numpy(g[f"{k}_y"])
+        assert ((y.cpu() - ref_y).abs().max() / ref_y.abs().max()).item() < 1e-3
+        for n in tr.names:
+            gr = tr.gviews[n].flatten().cpu()
+            idx = synth.randint(1234, "idx." + n, (min(16, gr.numel()),), gr.numel())
+            amax = float(g[f"{k}_gabsmax_{n}"])
+            if step == 1:
+                np.testing.assert_allclose(gr.double().norm().item(), float(g[f"{k}_gnorm_{n}"]), rtol=2e-3, err_msg=n)
+                assert np.abs(gr[idx].numpy() - g[f"{k}_gsamp_{n}"]).max() <= 3e-3 * amax + 1e-12, n
+            pd = np.abs(tr.views[n].flatten().cpu()[idx].numpy() - g[f"{k}_psamp_{n}"])
+            assert pd.max() <= 2.5 * lr * step, n  # Adam's first steps are sign-like: at most one flipped sign per step
+    # the trained head is what inference now uses
+    m.eval()
+    enc, y = m(be.cuda(), ae.cuda())
+    assert torch.isfinite(y).all() and abs(enc.sum().item() - B) < 1e-3

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvdqn.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -107,6 +107,9 @@ _SIGS = {
     "vdqn_net_forward": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vdqn_net_trunk_forward": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "vdqn_softmax_rows": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vdqn_softmax_ce": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "vdqn_mask_scale": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_i32, c_vp]),
+    "vdqn_axpy": (C.c_int, [c_vp, c_vp, c_f32, c_i64, c_vp]),
     "vdqn_net_forward_train": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vdqn_net_td_forward": (C.c_int, [c_vp, C.POINTER(StepArgs), c_vp]),
     "vdqn_net_backward_stage": (C.c_int, [c_vp, C.POINTER(StepArgs), c_i32, c_vp]),

@@ -425,6 +425,70 @@ extern "C" int vdqn_softmax_rows(const float* x, float* y, int32_t rows, int32_t
   return VDQN_OK;
 }
 
+// mean cross-entropy over rows of logits[rows][ld] (first n_cls columns) against int64 labels, and its gradient
+// (softmax - onehot) * inv_count written as T into dlogits[rows][ld] (columns >= n_cls zero): nn.CrossEntropyLoss()
+// of train_inverse_model.py:103-104 and its backward
+template <typename T>
+__global__ void softmax_ce_kernel(const float* __restrict__ x, const int64_t* __restrict__ label, float* __restrict__ loss, T* __restrict__ dx,
+                                  int rows, int ld, int n_cls, float inv_count) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  float my = 0.f;
+  if (r < rows) {
+    float m = -INFINITY;
+    for (int j = 0; j < n_cls; ++j) m = fmaxf(m, x[(size_t)r * ld + j]);
+    float sum = 0.f;
+    for (int j = 0; j < n_cls; ++j) sum += expf(x[(size_t)r * ld + j] - m);
+    const int lab = (int)label[r];
+    my = (logf(sum) + m - x[(size_t)r * ld + lab]) * inv_count;
+    for (int j = 0; j < ld; ++j) {
+      float g = 0.f;
+      if (j < n_cls) g = (expf(x[(size_t)r * ld + j] - m) / sum - (j == lab ? 1.f : 0.f)) * inv_count;
+      dx[(size_t)r * ld + j] = from_f32<T>(g);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) my += __shfl_down(my, o, 64);
+  if ((threadIdx.x & 63) == 0 && my != 0.f) atomicAdd(loss, my);
+}
+
+// out = x * mask * scale (dropout forward and backward with a caller-supplied 0/1 mask of the same dtype)
+template <typename T>
+__global__ void mask_scale_kernel(const T* __restrict__ x, const T* __restrict__ mask, T* __restrict__ out, long n, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = from_f32<T>(to_f32<T>(x[i]) * to_f32<T>(mask[i]) * scale);
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
+extern "C" int vdqn_softmax_ce(const float* logits, const int64_t* labels, float* loss, void* dlogits, int32_t rows, int32_t ld, int32_t n_cls,
+                               float inv_count, int32_t dtype, void* stream) {
+  VDQN_CHECK(logits && labels && loss && dlogits && rows > 0 && n_cls > 0 && n_cls <= ld, "vdqn_softmax_ce: bad args");
+  VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_softmax_ce: bad dtype");
+  if (dtype == VDQN_BF16) hipLaunchKernelGGL((softmax_ce_kernel<bf16raw>), dim3((rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, labels, loss, (bf16raw*)dlogits, rows, ld, n_cls, inv_count);
+  else hipLaunchKernelGGL((softmax_ce_kernel<float>), dim3((rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, labels, loss, (float*)dlogits, rows, ld, n_cls, inv_count);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_mask_scale(const void* x, const void* mask, void* out, int64_t n, float scale, int32_t dtype, void* stream) {
+  VDQN_CHECK(x && mask && out && n > 0, "vdqn_mask_scale: bad args");
+  VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_mask_scale: bad dtype");
+  const int g = grid_for(n, 4096);
+  if (dtype == VDQN_BF16) hipLaunchKernelGGL((mask_scale_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)x, (const bf16raw*)mask, (bf16raw*)out, (long)n, scale);
+  else hipLaunchKernelGGL((mask_scale_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)mask, (float*)out, (long)n, scale);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+extern "C" int vdqn_axpy(float* y, const float* x, float alpha, int64_t n, void* stream) {
+  VDQN_CHECK(y && x && n > 0, "vdqn_axpy: bad args");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, (long)n);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
 extern "C" int vdqn_td_loss(const vdqn_td_args* a, void* stream) {
   VDQN_CHECK(a && a->q_before && a->q_after_online && a->q_after_target && a->act && a->rew && a->term && a->loss, "vdqn_td_loss: null arg");
   VDQN_CHECK(!a->use_valid || a->valid, "vdqn_td_loss: use_valid without valid mask");

@@ -13,7 +13,7 @@ the use the Q-learning data pipeline makes of it: ``dataset/process_episodes_rea
 * The frozen trunk runs through ``vdqn_net_trunk_forward`` (both frames in one 2B pass), the head through ``vdqn_conv2d``
   (1x1 over the 1024-channel concat, two valid 3x3 convs, three linears) and ``vdqn_softmax_rows``.  torch is used for
   device memory and for re-laying-out the head weights once per load; there is no CPU arithmetic and no fallback.
-* Training of this model (``train_inverse_model.py``: dropout, cross-entropy, StepLR) is not part of this package.
+* Training of this model: ``video_dqn_amd/inverse_train.py`` (``train_inverse_model.py``'s loop on the same kernels).
 """
 from __future__ import annotations
 
@@ -127,7 +127,7 @@ class InverseActionModel(nn.Module):
     def forward(self, k, k_plus_one):  # archs/inverse_action2.py:72-100 (eval mode: dropout is the identity)
         eng = self.engine
         if self.training:
-            raise _lib.VdqnError("InverseActionModel runs in eval mode only (call .eval()); training it is out of this package's scope")
+            raise _lib.VdqnError("InverseActionModel.forward is the eval-mode (labelling) path: call .eval(); training goes through inverse_train.InverseTrainer")
         if k.dtype == torch.uint8:
             src_kind, frames = 0, torch.cat([k, k_plus_one], 0)
         else:
