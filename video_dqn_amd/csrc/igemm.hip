@@ -27,6 +27,8 @@
 
 #include "common.h"
 
+int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, hipStream_t st);  // stem.hip
+
 namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -1044,5 +1046,9 @@ extern "C" int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float
   p.wt_bytes = 64 * p.ktot * esz;
   p.vec_ok = 1;
   hipStream_t st = (hipStream_t)stream;
+  // bf16: the persistent kernel of stem.hip (weights in registers, double-buffered windows; 0.62 vs 0.70 ms per step for the
+  // one-tile-per-workgroup MODE 3 path below, which f32 uses and VDQN_STEM_PERSISTENT=0 selects)
+  static const bool persistent = [] { const char* e = getenv("VDQN_STEM_PERSISTENT"); return !(e && e[0] == '0'); }();
+  if (dtype == VDQN_BF16 && persistent) return vdqn_stem_bf16(t_in, wt, bias, pool, idx, n_img, st);
   return dtype == VDQN_BF16 ? launch_igemm<bf16raw, 256, 64, 3>(p, st) : launch_igemm<float, 256, 64, 3>(p, st);
 }

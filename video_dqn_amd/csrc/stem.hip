@@ -1,0 +1,219 @@
+// The ResNet stem for bf16 as one persistent kernel: conv1 7x7/2 (a 4x4/1 convolution over the packed space-to-depth
+// operand of vdqn_pack_input) + folded BatchNorm + ReLU + MaxPool2d(3, 2, 1)
+// (torchvision resnet.py conv1/bn1/relu/maxpool; archs/HabitatDQNMultiAction.py:30).
+//
+// Tile = a 16x16 patch of conv pixels (rows 14 ty - 1 .., cols 14 tx - 1 ..) that contains every window of a 7x7 patch
+// of pooled pixels; 64 tiles per image.  What makes this kernel different from the generic implicit GEMM (igemm.hip,
+// MODE 3, still used for f32):
+//   * K-step kr of conv row py reads the packed rows of conv row py + 1 at K-step kr - 1, so ONE staged window of 19 x 16
+//     rows (window row wy*16 + px = the 128 bytes at packed pixel (y0 + wy, x0 + px)) serves all four K-steps: fragments
+//     of step kr are read 16 rows further down.  38 KiB staged per tile instead of 4 x 32 KiB.
+//   * Workgroups are persistent (two per CU) and walk the tile list with a stride of gridDim.x; the 64 x 256 weight matrix
+//     is read ONCE per wave into registers (its 32 MFMA B-fragments = 128 VGPRs) and never touches LDS.
+//   * That leaves LDS for two windows: the LDS-DMA of tile t+1 runs underneath the MFMAs and the pooling epilogue of tile t.
+//   * No barrier and no DMA inside a tile's K loop.
+// Epilogue as in igemm.hip MODE 3: bias + ReLU -> bf16 patch in LDS (aliasing the window just consumed) -> 49 pooled pixels
+// x 64 channels with the first-maximum-wins rule of maxpool_fwd_kernel.  Results are bit-identical to vdqn_conv2d followed
+// by vdqn_maxpool_fwd (same K order, same rounding points).
+#include "common.h"
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct StemParams {
+  const bf16raw* t_in;   // [n][115][115][16]
+  const bf16raw* wt;     // [64][256]
+  const float* bias;     // [64]
+  bf16raw* pool;         // [n][56][56][64]
+  uint8_t* idx;          // [n][56][56][64]
+  int n_img, n_tiles;
+};
+
+constexpr int kWRows = 320;                    // 19 * 16 = 304 window rows, rounded up to the 32-row staging pass
+constexpr int kWBytes = kWRows * 128;          // one window buffer
+constexpr int kSmem = 2 * kWBytes;  // two windows = 80 KiB: two workgroups per CU (the weights live in registers)
+constexpr unsigned kOobS = 0x80000000u;
+
+__global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem;                    // [2][320 rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int lrow = tid >> 3;
+  const int lchunk_a = (tid & 7) ^ (lrow & 7);
+  const int lchunk_b = (tid & 7) ^ ((((lrow >> 4) & 1) << 2) | (lrow & 3));  // permuted weight rows, see igemm.hip (CPL = 16)
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t lds_wave = lds_base + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (8 * 128);
+  constexpr int PSTR = 32 * 128;  // 32 rows per staging pass
+  constexpr long long kImgBytes = 115ll * 115 * 16 * 2;
+
+  // ---- weights: this wave's fragments of all four K-steps, once, into REGISTERS (128 VGPRs): fragment j of K-step kr,
+  // K half h = 16 bytes of weight row (i16 >> 2) * 16 + j * 4 + (i16 & 3) (the permuted order of igemm.hip) ----
+  u32x4 fb[4][2][4];
+  {
+    const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.wt) + (size_t)((lane & 15) >> 2) * 16 * 512 + (size_t)(lane & 3) * 512;
+#pragma unroll
+    for (int kr = 0; kr < 4; ++kr)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          fb[kr][h][j] = *reinterpret_cast<const u32x4*>(wrow + (size_t)j * 4 * 512 + kr * 128 + ((lane >> 4) + 4 * h) * 16);
+  }
+  // stage the window of tile t into buffer `buf` (10 pieces per thread-row group)
+  auto issue_window = [&](int t, int buf) {
+    const int img = t >> 6, ty = (t >> 3) & 7, tx = t & 7;
+    const int y0 = 14 * ty - 1, x0 = 14 * tx - 1;
+    const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.t_in + (long long)img * kImgBytes);
+    const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)), (int)kImgBytes, 0x00020000};
+    uint32_t vw[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int R = lrow + 32 * i;
+      const int sy = y0 + (R >> 4);
+      const bool ok = (R < 304) && ((unsigned)sy < 115u);
+      // packed column -1 / 115 (only read for conv columns that are never pooled) wraps inside the image or falls out of
+      // the descriptor's range (zeros): either way harmless
+      vw[i] = ok ? (uint32_t)((sy * 115 + x0 + (R & 15)) * 32 + lchunk_a * 16) : kOobS;
+    }
+    const uint32_t l0 = lds_wave + (uint32_t)(buf * kWBytes);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const uint32_t l_ = l0 + (uint32_t)(2 * q * PSTR);
+      asm volatile(
+          "s_nop 4\n\t"
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, 0 offen lds\n\t"
+          "s_add_u32 m0, %2, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds"
+          ::"v"(vw[2 * q]), "v"(vw[2 * q + 1]), "s"(l_), "s"(rs_a), "n"(PSTR)
+          : "memory", "scc");
+    }
+  };
+
+  const int coff0 = ((g ^ (i16 & 7)) << 4), coff1 = (((g + 4) ^ (i16 & 7)) << 4);
+
+  int t = blockIdx.x, buf = 0;
+  if (t < p.n_tiles) issue_window(t, 0);
+  for (; t < p.n_tiles; t += gridDim.x, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // window t visible; everyone is done pooling the previous tile (its patch lived in buf ^ 1)
+    if (t + (int)gridDim.x < p.n_tiles) issue_window(t + gridDim.x, buf ^ 1);
+
+    // ---- 4 K-steps straight out of LDS: acc[f][j] = pixels (4 wave + f, i16), channels g*16 + j*4 + reg ----
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* a_rd = sW + buf * kWBytes + (wave * 64 + i16) * 128;
+#pragma unroll
+    for (int kr = 0; kr < 4; ++kr) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 fa[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fa[f] = *reinterpret_cast<const u32x4*>(a_rd + (kr * 16 + f * 16) * 128 + (h ? coff1 : coff0));
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[kr][h][j]), __builtin_bit_cast(bf16x8, fa[f]), acc[f][j], 0, 0, 0);
+      }
+    }
+
+    // ---- bias + ReLU -> bf16 patch in LDS (over the window just consumed), then the 7x7 pooled pixels ----
+    __syncthreads();
+    bf16raw* sT = reinterpret_cast<bf16raw*>(sW + buf * kWBytes);
+    float bv[16];  // (re-read per tile from L2: the weights occupy the registers a resident copy would need)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(bv + 4 * e) = *reinterpret_cast<const float4*>(p.bias + g * 16 + 4 * e);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int r = wave * 64 + f * 16 + i16;
+      bf16raw ov[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ov[j * 4 + q] = f32_to_bf16(fmaxf(acc[f][j][q] + bv[j * 4 + q], 0.f));
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int chunk = (g * 2 + c) ^ (r & 7);
+        *reinterpret_cast<uint4*>(sT + (size_t)r * 64 + chunk * 8) = reinterpret_cast<const uint4*>(ov)[c];
+      }
+    }
+    __syncthreads();
+    const int img = t >> 6, ty = (t >> 3) & 7, tx = t & 7;
+    for (int item = tid; item < 49 * 8; item += 256) {
+      const int pp = item >> 3, cg = item & 7;
+      const int pi = pp / 7, pj = pp - pi * 7;
+      // post-ReLU bf16 bit patterns order like unsigned integers: key = bits << 4 | (8 - tap), one v_max_u32 per element and tap
+      uint32_t key[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) key[e] = 0u;
+      bool any = false;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int py = 2 * pi + kh, y = 14 * ty - 1 + py;
+        if ((unsigned)y >= 112u) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int px = 2 * pj + kw, x = 14 * tx - 1 + px;
+          if ((unsigned)x >= 112u) continue;
+          const int r = py * 16 + px;
+          const uint4 v = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * 8));
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+          const uint32_t tag = (uint32_t)(8 - (kh * 3 + kw));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            key[2 * q] = max(key[2 * q], ((w4[q] << 4) & 0x7fff0u) | tag);
+            key[2 * q + 1] = max(key[2 * q + 1], ((w4[q] >> 12) & 0x7fff0u) | tag);
+          }
+          any = true;
+        }
+      }
+      float best[8];
+      uint8_t bi[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        best[e] = any ? bf16_to_f32((bf16raw)(key[e] >> 4)) : -INFINITY;
+        bi[e] = any ? (uint8_t)(8u - (key[e] & 15u)) : (uint8_t)0;
+      }
+      const size_t o = (((size_t)img * 56 + 7 * ty + pi) * 56 + 7 * tx + pj) * 64 + cg * 8;
+      bf16raw ov[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(best[e]);
+      *reinterpret_cast<uint4*>(p.pool + o) = *reinterpret_cast<const uint4*>(ov);
+      *reinterpret_cast<uint2*>(p.idx + o) = *reinterpret_cast<const uint2*>(bi);
+    }
+  }
+}
+
+}  // namespace
+
+// bf16 entry used by vdqn_stem_conv_pool (igemm.hip); returns VDQN_OK or an error code
+int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+    else n_cu = prop.multiProcessorCount;
+  }
+  StemParams p;
+  p.t_in = (const bf16raw*)t_in; p.wt = (const bf16raw*)wt; p.bias = bias; p.pool = (bf16raw*)pool; p.idx = (uint8_t*)idx;
+  p.n_img = n_img;
+  p.n_tiles = n_img * 64;
+  const int grid = p.n_tiles < 2 * n_cu ? p.n_tiles : 2 * n_cu;
+  vdqn_prof_begin("stem_conv_pool<bf16>", 2.0 * n_img * 112 * 112 * 64 * 147,
+                  2.0 * ((double)n_img * 115 * 115 * 16 + 64.0 * 256 + (double)n_img * 56 * 56 * 64) + (double)n_img * 56 * 56 * 64, st);
+  hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), kSmem, st, p);
+  vdqn_prof_end(st);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
