@@ -32,6 +32,8 @@ def tag_of(kernel_name: str):
     m = re.search(r"wgrad_kernel<(unsigned short|float), (\d+)>", kernel_name)
     if m:
         return f"wgrad<{'bf16' if m[1] == 'unsigned short' else 'f32'},{m[2]}>"
+    if "stem_kernel" in kernel_name:
+        return "stem_conv_pool<bf16>"
     m = re.search(r"(\w+)_kernel", kernel_name)
     return m[1] if m else kernel_name[:40]
 

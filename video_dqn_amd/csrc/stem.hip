@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
           fb[kr][h][j] = *reinterpret_cast<const u32x4*>(wrow + (size_t)j * 4 * 512 + kr * 128 + ((lane >> 4) + 4 * h) * 16);
   }
   // stage the window of tile t into buffer `buf` (10 pieces per thread-row group)
-  auto issue_window = [&](int t, int buf) {
+  // tile ids are remapped so that the workgroups of one XCD (blockIdx % 8) walk a contiguous range of tiles: neighbouring
+  // patches share two packed rows / columns, which then hit in that XCD's L2
+  auto issue_window = [&](int t_seq, int buf) {
+    const int t = (int)xcd_remap((uint32_t)t_seq, (uint32_t)p.n_tiles);
     const int img = t >> 6, ty = (t >> 3) & 7, tx = t & 7;
     const int y0 = 14 * ty - 1, x0 = 14 * tx - 1;
     const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.t_in + (long long)img * kImgBytes);
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
       }
     }
     __syncthreads();
-    const int img = t >> 6, ty = (t >> 3) & 7, tx = t & 7;
+    const int tl = (int)xcd_remap((uint32_t)t, (uint32_t)p.n_tiles);
+    const int img = tl >> 6, ty = (tl >> 3) & 7, tx = tl & 7;
     for (int item = tid; item < 49 * 8; item += 256) {
       const int pp = item >> 3, cg = item & 7;
       const int pi = pp / 7, pj = pp - pi * 7;
