@@ -211,6 +211,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 //         overlap by two rows/columns: 30 % more MFMA work on a kernel whose cost is its output traffic)
 // WN = waves along N.  256 x 64 tiles with WN = 1 give the 64-output-channel layers the same 64x64 wave tile (16 MFMAs
 // per 8 fragment reads) as the 128x128 kernel.
+// Scheduling pattern of a K-step's block (bf16): one MFMA, one VALU, one LDS read, N times, then the remaining MFMAs.
+// The fragment reads of the NEXT K-step and their address arithmetic then issue in the shadow of this step's MFMAs instead
+// of in front of them: +4 % on the window kernel inside the step, +5-9 % per layer (experiments/README.md).
+#define VDQN_INTERLEAVE(N)                                  \
+  if constexpr (sizeof(T) == 2) {                           \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N); ++g_) {    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);    \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+    }                                                       \
+  }
 template <typename T, int BM, int BN, int MODE, int WN>
 __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) {
   constexpr int NT = BM * WN;   // threads: BM/64 x WN waves, each owning 64 x BN/WN
@@ -447,9 +458,12 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
       VDQN_ADVANCE()                                                                                                     \
       ++issued;                                                                                                          \
     }                                                                                                                    \
-    if ((K) + 1 < nk) VDQN_LOAD_FRAGS(NXT, ((K) + 1) & 1)                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    /* unconditional (the last step reads a stale buffer) so that the reads sit in ONE block with the MFMAs: every */    \
+    /* fragment read then issues behind an MFMA instead of in front of all of them (tools/probes/mfma_peak.hip) */       \
+    VDQN_LOAD_FRAGS(NXT, ((K) + 1) & 1)                                                                                  \
     VDQN_MFMA_ALL(CUR)                                                                                                   \
+    VDQN_INTERLEAVE(8 + 2 * NF)                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
   if constexpr (MODE == 3 && ESZ == 2) {
@@ -866,9 +880,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void igemm_win_kernel(const 
     _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) asm volatile("" : "+v"(fb[CUR][0][j_]), "+v"(fb[CUR][1][j_]));     \
     __builtin_amdgcn_s_barrier();                                                                                        \
     if (issued < nk) VDQN_ISSUE_STEP((K) & 1)                                                                            \
-    if ((K) + 1 < nk) VDQN_LOAD_FRAGS(NXT, ((K) + 1) & 1)                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    VDQN_LOAD_FRAGS(NXT, ((K) + 1) & 1) /* unconditional (the last step reads a stale buffer): one block with the MFMAs */ \
     VDQN_MFMA_ALL(CUR)                                                                                                   \
+    VDQN_INTERLEAVE(8 + 2 * NF)                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
   // prologue: K-steps 0 and 1 (window of group 0 + two weight tiles)

@@ -243,9 +243,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         asm volatile("" : "+v"(fa[CUR][u_][f_][0]), "+v"(fa[CUR][u_][f_][1]), "+v"(fb[CUR][u_][f_][0]), "+v"(fb[CUR][u_][f_][1])); \
     __builtin_amdgcn_s_barrier();                                                                                    \
     if ((K) + 2 < nk) issue_tile(kbeg + ((K) + 2) * KP, (K) & 1);                                                    \
-    if ((K) + 1 < nk) WG_LOAD(NXT, ((K) + 1) & 1)                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
+    /* unconditional (the last step reads a stale buffer): one block with the MFMAs, reads issued behind them */     \
+    WG_LOAD(NXT, ((K) + 1) & 1)                                                                                      \
     WG_MFMA(CUR)                                                                                                     \
+    _Pragma("unroll") for (int g_ = 0; g_ < NSUB * NFR * (NFR < 4 ? NFR : 4); ++g_) {                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                                             \
+      __builtin_amdgcn_sched_group_barrier(0x100, NFR < 4 ? 4 / NFR : 1, 0);                                         \
+    }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
     issue_tile(kbeg, 0);
