@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   const int lchunk_a = (tid & 7) ^ (lrow & 7);
   const int lchunk_b = (tid & 7) ^ ((((lrow >> 4) & 1) << 2) | (lrow & 3));  // permuted weight rows, see igemm.hip (CPL = 16)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const uint32_t lds_wave = lds_base + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (8 * 128);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t lds_wave = lds_base + (uint32_t)wave_u * (8 * 128);
+  constexpr int kBiasRow = 312;  // window rows 304..319 of buffer 0 are never staged (see issue_window)
   constexpr int PSTR = 32 * 128;  // 32 rows per staging pass
   constexpr long long kImgBytes = 115ll * 115 * 16 * 2;
 
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     }
     const uint32_t l0 = lds_wave + (uint32_t)(buf * kWBytes);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const uint32_t l_ = l0 + (uint32_t)(2 * q * PSTR);
       asm volatile(
           "s_nop 4\n\t"
@@ -92,7 +94,18 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
           ::"v"(vw[2 * q]), "v"(vw[2 * q + 1]), "s"(l_), "s"(rs_a), "n"(PSTR)
           : "memory", "scc");
     }
+    // last pass (rows 256..319): rows 304.. are padding, so the pieces of waves 2 and 3 in its second half are skipped —
+    // rows 312.. of buffer 0 hold the bias vector
+    {
+      const uint32_t l_ = l0 + (uint32_t)(8 * PSTR);
+      asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vw[8]), "s"(l_), "s"(rs_a) : "memory");
+      if (wave_u < 2) {
+        const uint32_t l2_ = l_ + (uint32_t)PSTR;
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vw[9]), "s"(l2_), "s"(rs_a) : "memory");
+      }
+    }
   };
+  if (tid < 64) reinterpret_cast<float*>(sW + kBiasRow * 128)[tid] = p.bias[tid];  // visible after the first tile's barrier
 
   const int coff0 = ((g ^ (i16 & 7)) << 4), coff1 = (((g + 4) ^ (i16 & 7)) << 4);
 
@@ -128,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     // ---- bias + ReLU -> bf16 patch in LDS (over the window just consumed), then the 7x7 pooled pixels ----
     __syncthreads();
     bf16raw* sT = reinterpret_cast<bf16raw*>(sW + buf * kWBytes);
-    float bv[16];  // (re-read per tile from L2: the weights occupy the registers a resident copy would need)
+    float bv[16];  // (re-read per tile from LDS: the weights occupy the registers a resident copy would need)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(bv + 4 * e) = *reinterpret_cast<const float4*>(p.bias + g * 16 + 4 * e);
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(bv + 4 * e) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + 4 * e) * 4);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int r = wave * 64 + f * 16 + i16;
@@ -151,44 +164,47 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     for (int item = tid; item < 49 * 8; item += 256) {
       const int pp = item >> 3, cg = item & 7;
       const int pi = pp / 7, pj = pp - pi * 7;
+      // Straight-line: all nine taps are read up front (one exposed LDS latency per item instead of nine).  Only the taps of
+      // conv row / column -1 can be outside the image (first tile row / column, first pooled row / column): they are read too
+      // (the patch row exists) and masked out of the maximum.  The centre tap is always valid, so every key ends up tagged.
+      const uint32_t row0 = (ty == 0 && pi == 0) ? 0u : 0x7fff0u, col0 = (tx == 0 && pj == 0) ? 0u : 0x7fff0u;
+      uint4 v[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int r = (2 * pi + kh) * 16 + 2 * pj + kw;
+          v[kh * 3 + kw] = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * 8));
+        }
       // post-ReLU bf16 bit patterns order like unsigned integers: key = bits << 4 | (8 - tap), one v_max_u32 per element and tap
       uint32_t key[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) key[e] = 0u;
-      bool any = false;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int py = 2 * pi + kh, y = 14 * ty - 1 + py;
-        if ((unsigned)y >= 112u) continue;
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int px = 2 * pj + kw, x = 14 * tx - 1 + px;
-          if ((unsigned)x >= 112u) continue;
-          const int r = py * 16 + px;
-          const uint4 v = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * 8));
-          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-          const uint32_t tag = (uint32_t)(8 - (kh * 3 + kw));
+          const uint32_t m = (kh == 0 ? row0 : 0x7fff0u) & (kw == 0 ? col0 : 0x7fff0u);
+          const uint32_t tag = (kh == 0 || kw == 0) ? ((m >> 4) & (uint32_t)(8 - (kh * 3 + kw))) : (uint32_t)(8 - (kh * 3 + kw));
+          const uint32_t w4[4] = {v[kh * 3 + kw].x, v[kh * 3 + kw].y, v[kh * 3 + kw].z, v[kh * 3 + kw].w};
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            key[2 * q] = max(key[2 * q], ((w4[q] << 4) & 0x7fff0u) | tag);
-            key[2 * q + 1] = max(key[2 * q + 1], ((w4[q] >> 12) & 0x7fff0u) | tag);
+            key[2 * q] = max(key[2 * q], ((w4[q] << 4) & m) | tag);
+            key[2 * q + 1] = max(key[2 * q + 1], ((w4[q] >> 12) & m) | tag);
           }
-          any = true;
         }
-      }
-      float best[8];
-      uint8_t bi[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        best[e] = any ? bf16_to_f32((bf16raw)(key[e] >> 4)) : -INFINITY;
-        bi[e] = any ? (uint8_t)(8u - (key[e] & 15u)) : (uint8_t)0;
-      }
+      // key >> 4 IS the bf16 bit pattern of the maximum; 8 - (key & 15) the tap that holds it (first maximum wins)
+      uint4 ov;
+      uint2 bi;
+      ov.x = (key[0] >> 4) | ((key[1] << 12) & 0xffff0000u);
+      ov.y = (key[2] >> 4) | ((key[3] << 12) & 0xffff0000u);
+      ov.z = (key[4] >> 4) | ((key[5] << 12) & 0xffff0000u);
+      ov.w = (key[6] >> 4) | ((key[7] << 12) & 0xffff0000u);
+      bi.x = (8u - (key[0] & 15u)) | ((8u - (key[1] & 15u)) << 8) | ((8u - (key[2] & 15u)) << 16) | ((8u - (key[3] & 15u)) << 24);
+      bi.y = (8u - (key[4] & 15u)) | ((8u - (key[5] & 15u)) << 8) | ((8u - (key[6] & 15u)) << 16) | ((8u - (key[7] & 15u)) << 24);
       const size_t o = (((size_t)img * 56 + 7 * ty + pi) * 56 + 7 * tx + pj) * 64 + cg * 8;
-      bf16raw ov[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(best[e]);
-      *reinterpret_cast<uint4*>(p.pool + o) = *reinterpret_cast<const uint4*>(ov);
-      *reinterpret_cast<uint2*>(p.idx + o) = *reinterpret_cast<const uint2*>(bi);
+      *reinterpret_cast<uint4*>(p.pool + o) = ov;
+      *reinterpret_cast<uint2*>(p.idx + o) = bi;
     }
   }
 }
