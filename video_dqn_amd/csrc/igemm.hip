@@ -222,7 +222,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
     }                                                       \
   }
-template <typename T, int BM, int BN, int MODE, int WN>
+// NS = staging buffers per operand: 2 (one K-step of DMA lead; two workgroups per CU hide the rest) or 4 (three K-steps of
+// lead, counted vmcnt waits) for launches with at most one tile per CU, where nothing else hides the ~0.85 us DMA round trip
+// of every K-step (the head's skinny GEMMs: features.8, top.*).
+template <typename T, int BM, int BN, int MODE, int WN, int NS = 2>
 __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) {
   constexpr int NT = BM * WN;   // threads: BM/64 x WN waves, each owning 64 x BN/WN
   constexpr int RPS = NT / 8;   // tile rows staged per pass (8 lanes x 16 B per 128-byte row)
@@ -236,8 +239,9 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
   static_assert(NF == 2 || NF == 4, "wave tile is 64 x 32 or 64 x 64");
   constexpr int PSTR = RPS * 128;  // LDS byte distance between a thread's consecutive DMA pieces
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(NS == 2 || (NS == 4 && (MODE == 0 || MODE == 1)), "deep ring: forward / stride-1 data gradient only");
   unsigned char* sA = smem;
-  unsigned char* sB = smem + 2 * BM * 128;
+  unsigned char* sB = smem + NS * BM * 128;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
       const uint32_t la2_ = la_ + 4 * PSTR;                                                                         \
       VDQN_DMA4(vo_[AROWS - 4], vo_[AROWS - 3], vo_[AROWS - 2], vo_[AROWS - 1], la2_, rs_a, zero_);                 \
     }                                                                                                               \
-    const uint32_t lb_ = lds_wave + (uint32_t)(2 * BM * 128) + (uint32_t)(BUF) * (BN * 128);                        \
+    const uint32_t lb_ = lds_wave + (uint32_t)(NS * BM * 128) + (uint32_t)(BUF) * (BN * 128);                       \
     const int so_ = (KSTEP)*128;                                                                                    \
     if constexpr (BROWS == 4) {                                                                                     \
       VDQN_DMA4(b_off[0], b_off[BROWS > 1 ? 1 : 0], b_off[BROWS > 2 ? 2 : 0], b_off[BROWS > 2 ? 3 : 0], lb_, rs_b, so_); \
@@ -447,21 +451,28 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
 #define VDQN_STEP(K, CUR, NXT)                                                                                           \
   {                                                                                                                      \
     /* own DMA pieces of tile K+1 landed; own fragment reads of tile K complete (its buffer is about to be refilled) */  \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
+    if constexpr (NS == 2) {                                                                                             \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                        \
+    } else { /* tiles K+2 .. issued-1 may stay in flight (AROWS + BROWS DMA instructions each, retired in order) */      \
+      const int ahead_ = issued - (K) - 2;                                                                               \
+      if (ahead_ >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (AROWS + BROWS)) : "memory");             \
+      else if (ahead_ == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AROWS + BROWS) : "memory");              \
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                   \
+    }                                                                                                                    \
     /* tell the compiler set CUR is complete HERE, so it does not wait for it (and for the younger reads) later */      \
     asm volatile("" : "+v"(fa[CUR][0][0]), "+v"(fa[CUR][0][1]), "+v"(fa[CUR][0][2]), "+v"(fa[CUR][0][3]),                \
                       "+v"(fa[CUR][1][0]), "+v"(fa[CUR][1][1]), "+v"(fa[CUR][1][2]), "+v"(fa[CUR][1][3]));               \
     _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) asm volatile("" : "+v"(fb[CUR][0][j_]), "+v"(fb[CUR][1][j_]));     \
     __builtin_amdgcn_s_barrier();                                                                                        \
     if (issued < nk) {                                                                                                   \
-      VDQN_ISSUE((K) & 1, ikr, iks, ic0, VDQN_WSTEP())                                                                   \
+      VDQN_ISSUE((K) & (NS - 1), ikr, iks, ic0, VDQN_WSTEP())                                                            \
       VDQN_ADVANCE()                                                                                                     \
       ++issued;                                                                                                          \
     }                                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     /* unconditional (the last step reads a stale buffer) so that the reads sit in ONE block with the MFMAs: every */    \
     /* fragment read then issues behind an MFMA instead of in front of all of them (tools/probes/mfma_peak.hip) */       \
-    VDQN_LOAD_FRAGS(NXT, ((K) + 1) & 1)                                                                                  \
+    VDQN_LOAD_FRAGS(NXT, ((K) + 1) & (NS - 1))                                                                           \
     VDQN_MFMA_ALL(CUR)                                                                                                   \
     VDQN_INTERLEAVE(8 + 2 * NF)                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
@@ -531,7 +542,14 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     VDQN_ISSUE(0, ikr, iks, ic0, VDQN_WSTEP())
     VDQN_ADVANCE()
     ++issued;
-    if (issued < nk) {
+    if constexpr (NS == 4) {
+      for (int b = 1; b < NS && issued < nk; ++b) {
+        VDQN_ISSUE(b, ikr, iks, ic0, VDQN_WSTEP())
+        VDQN_ADVANCE()
+        ++issued;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once per tile
+    } else if (issued < nk) {
       VDQN_ISSUE(1, ikr, iks, ic0, VDQN_WSTEP())
       VDQN_ADVANCE()
       ++issued;
@@ -928,14 +946,14 @@ int launch_igemm_win(const IgemmParams& p, hipStream_t stream) {
   return VDQN_OK;
 }
 
-template <typename T, int BM, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE, int NS = 2>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   // 256x64 tiles: 4 waves of 64x64 (WN = 1); everything else a (BM/64) x 2 wave grid
   constexpr int WN = (BM == 256 && BN == 64) ? 1 : 2;
-  const size_t smem = 2 * (BM + BN) * 128;
+  const size_t smem = NS * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, MODE, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, MODE, WN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
@@ -957,7 +975,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
                     2.0 * p.M * p.co * p.ktot,
                     esz * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))),
                     stream);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, MODE, WN>), dim3(grid), dim3(BM * WN), smem, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, MODE, WN, NS>), dim3(grid), dim3(BM * WN), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
@@ -965,6 +983,11 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
 
 template <typename T, int BM, int BN>
 int launch_mode(const IgemmParams& p, int mode, hipStream_t st) {
+  if constexpr (BM == 128) {
+    // at most one tile per CU and a long K loop: nothing but a deeper ring hides the DMA round trip of every K-step
+    static const bool deep_on = !getenv("VDQN_IGEMM_DEEP") || atoi(getenv("VDQN_IGEMM_DEEP")) != 0;
+    if (mode == 0 && deep_on && p.tiles_m * p.tiles_n <= 256 && p.nk >= 8) return launch_igemm<T, BM, BN, 0, 4>(p, st);
+  }
   if (mode == 0) return launch_igemm<T, BM, BN, 0>(p, st);
   if (mode == 1) return launch_igemm<T, BM, BN, 1>(p, st);
   if constexpr (BM == 128) return launch_igemm<T, BM, BN, 2>(p, st);
