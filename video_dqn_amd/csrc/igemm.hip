@@ -946,6 +946,278 @@ int launch_igemm_win(const IgemmParams& p, hipStream_t stream) {
   return VDQN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent kernel for the 64 -> 64 channel 3x3 / stride 1 / pad 1 convolutions (ResNet layer1; MODE 0 forward, MODE 1 data
+// gradient), bf16.  These layers have 9 K-steps per tile: with the generic scheme every one of them costs a DMA round trip
+// and a barrier, and a tile spends ~12 us on 1 us of MFMA work.  Here the whole weight matrix of a wave's 32 output channels
+// (9 taps x 64 channels x 32 = 36 fragments) lives in REGISTERS (144 VGPRs) for the life of the workgroup, so only the
+// activations are staged: ONE window of 128 + 2 W + 2 consecutive input pixels (window row j = pixel m0 - W - 1 + j) serves
+// all nine taps of a 128-pixel tile — tap (kr, ks) of tile row r reads window row r + W kr + ks; lanes whose tap falls off the
+// image (first / last row or column) read a zero row.  The window is double-buffered (the DMA of tile t + 1 runs under tile t),
+// the K loop has no barrier and no wait, workgroups are persistent (two per CU) and walk the tile list; the epilogue is
+// igemm_epilogue (same fragment layout as the 128 x 64 tiles of the other kernels).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kC64WinRows = 248;                 // 128 + 2 * 56 + 2 = 242 rows, rounded up to the 8-row DMA piece
+constexpr int kC64WinBytes = kC64WinRows * 128;
+constexpr int kC64RegTaps = 7;                   // taps whose weight fragments live in registers; the rest are read from LDS
+constexpr int kC64Smem = 2 * kC64WinBytes + 128 + 512 + 256 + (9 - kC64RegTaps) * 8192;  // windows, zero row, column-sum scratch, bias, LDS taps
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, const int n_tiles, const FastDiv d_wo, const FastDiv d_howo) {
+  using T = bf16raw;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sZ = smem + 2 * kC64WinBytes;
+  float* sScratch = reinterpret_cast<float*>(sZ + 128);       // [2 wave rows][64] partial column sums
+  float* sBias = reinterpret_cast<float*>(sZ + 128 + 512);
+  unsigned char* sWt = sZ + 128 + 512 + 256;  // [9 - kC64RegTaps][64 channels][128 B], chunk c of row r stored at c ^ (r & 7)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int W = p.wo, H = p.ho;
+  if (tid < 8) reinterpret_cast<uint4*>(sZ)[tid] = make_uint4(0, 0, 0, 0);
+  if (tid >= 64 && tid < 128) sBias[tid - 64] = p.bias ? p.bias[tid - 64] : 0.f;
+  // output / residual / mask / column-sum buffers as buffer resources: rows past M get an out-of-range offset, so every
+  // lane issues the same instructions whatever its rows are (loads return 0, stores are dropped)
+  const int io_bytes = (int)((long long)p.M * p.ldo * 2);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, io_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.resid), 0, p.resid ? io_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mask), 0, p.mask ? io_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_cs = __builtin_amdgcn_make_buffer_rsrc(p.colsum_part, 0, p.colsum_part ? (int)((long long)n_tiles * p.ldo * 4) : 0, 0x00020000);
+  // The stores of a tile are HELD in registers and issued at the top of the next tile, behind that tile's barrier and window
+  // DMA: the wait in front of the barrier then never sees a young store (vmcnt counts stores too), and the stores drain under
+  // the next tile's MFMAs.  (With the stores issued in the epilogue the loop spent more than half its time on that wait.)
+  u32x4 held[4] = {};
+  uint32_t held_off[4] = {kOob, kOob, kOob, kOob};
+  float held_cs = 0.f;
+  uint32_t held_cs_off = kOob;
+
+  // ---- weights -> registers: fragment j (of 2) of tap t, K half h = 16 bytes of weight row wc*32 + (i16>>2)*8 + j*4 + (i16&3)
+  // (the permuted row order the epilogue expects, CPL = 8) at K offset t*64 + h*32 + g*8 ----
+  // (all nine taps = 144 VGPRs made the compiler spill inside the K loop, and every reload waits vmcnt(0) = for the stores and
+  // the next window; the last taps therefore stay in LDS: 4 extra fragment reads per tap and tile)
+  u32x4 fw[kC64RegTaps][2][2];
+  const int wrow0 = wc * 32 + (i16 >> 2) * 8 + (i16 & 3);  // + j*4: this lane's weight rows
+  for (int i = tid; i < (9 - kC64RegTaps) * 512; i += 256) {
+    const int tt = i >> 9, r = (i >> 3) & 63, c = i & 7;
+    *reinterpret_cast<uint4*>(sWt + tt * 8192 + r * 128 + ((c ^ (r & 7)) << 4)) =
+        *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.wt) + (size_t)r * (576 * 2) + (kC64RegTaps + tt) * 128 + c * 16);
+  }
+  {
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wt) + (size_t)wrow0 * (576 * 2) + g * 16;
+#pragma unroll
+    for (int t = 0; t < kC64RegTaps; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[t][h][j] = *reinterpret_cast<const u32x4*>(wbase + (size_t)j * 4 * (576 * 2) + t * 128 + h * 64);
+  }
+
+  const unsigned long long a_ptr = (unsigned long long)p.in;
+  const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane((int)p.in_bytes), 0x00020000};
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t lds_wave = lds_base + (uint32_t)wave_u * (8 * 128);
+  const int lrow = tid >> 3;                       // window row (mod 32) this thread stages
+  const int lchunk = (tid & 7) ^ (lrow & 7);       // source-side swizzle: LDS chunk c of window row j holds source chunk c ^ (j & 7)
+  constexpr int PSTR = 32 * 128;
+
+  // stage the window of (remapped) tile tl into buffer buf: 8 passes of 32 rows; rows 248.. (wave 3 of the last pass) do not exist
+  auto issue_window = [&](int tl, int buf) {
+    const int q0 = tl * 128 - W - 1;  // input pixel of window row 0
+    uint32_t vo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = q0 + lrow + 32 * i;
+      vo[i] = ((unsigned)q < (unsigned)p.M) ? (uint32_t)q * 128u + (uint32_t)(lchunk * 16) : kOob;
+    }
+    const uint32_t l0 = lds_wave + (uint32_t)(buf * kC64WinBytes);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const uint32_t l_ = l0 + (uint32_t)(2 * q * PSTR);
+      asm volatile(
+          "s_nop 4\n\t"
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, 0 offen lds\n\t"
+          "s_add_u32 m0, %2, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds"
+          ::"v"(vo[2 * q]), "v"(vo[2 * q + 1]), "s"(l_), "s"(rs_a), "n"(PSTR)
+          : "memory", "scc");
+    }
+    {
+      const uint32_t l_ = l0 + (uint32_t)(6 * PSTR);
+      asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vo[6]), "s"(l_), "s"(rs_a) : "memory");
+      if (wave_u < 3) {
+        const uint32_t l2_ = l_ + (uint32_t)PSTR;
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vo[7]), "s"(l2_), "s"(rs_a) : "memory");
+      }
+    }
+  };
+
+  int t = blockIdx.x, buf = 0;
+  if (t < n_tiles) issue_window((int)xcd_remap((uint32_t)t, (uint32_t)n_tiles), 0);
+  for (; t < n_tiles; t += gridDim.x, buf ^= 1) {
+    const int tl = (int)xcd_remap((uint32_t)t, (uint32_t)n_tiles);
+    const int m0 = tl * 128;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // window t visible; everyone is done with the other buffer (and with the scratch)
+    if (t + (int)gridDim.x < n_tiles) issue_window((int)xcd_remap((uint32_t)(t + gridDim.x), (uint32_t)n_tiles), buf ^ 1);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b128(held[f], r_out, (int)held_off[f], 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(held_cs), r_cs, (int)held_cs_off, 0, 0);
+
+    // edge bits of this lane's four pixels: 1 top row, 2 bottom row, 4 left column, 8 right column
+    uint32_t edge[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint32_t m = (uint32_t)(m0 + wr * 64 + f * 16 + i16);
+      const uint32_t rem = m - fastdiv(m, d_howo) * d_howo.div;
+      const uint32_t oh = fastdiv(rem, d_wo), ow = rem - oh * d_wo.div;
+      edge[f] = (oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u);
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* a_rd = smem + buf * kC64WinBytes + (wr * 64 + i16) * 128;
+    const unsigned char* z_rd = sZ + (g << 4);
+    // 18 steps (tap, K half); the forward reads input pixel m + (kr-1) W + (ks-1), the data gradient m + (1-kr) W + (1-ks)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kr = tap / 3, ks = tap % 3;
+      const int ky = MODE == 0 ? kr : 2 - kr, kx = MODE == 0 ? ks : 2 - ks;  // window offsets
+      const uint32_t tapbits = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u);
+      const int off = W * ky + kx;           // wave-uniform window row offset of this tap
+      const int key = (i16 + off) & 7;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int coff = ((g + 4 * h) ^ key) << 4;
+        u32x4 fa[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const bool z = (edge[f] & tapbits) != 0u;
+          fa[f] = *reinterpret_cast<const u32x4*>(z ? z_rd + 64 * h : a_rd + (f * 16 + off) * 128 + coff);
+        }
+        u32x4 wj[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (tap < kC64RegTaps) wj[j] = fw[tap < kC64RegTaps ? tap : 0][h][j];
+          else wj[j] = *reinterpret_cast<const u32x4*>(sWt + (tap - kC64RegTaps) * 8192 + (wrow0 + j * 4) * 128 + (((g + 4 * h) ^ ((wrow0 + j * 4) & 7)) << 4));
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wj[j]), __builtin_bit_cast(bf16x8, fa[f]), acc[f][j], 0, 0, 0);
+      }
+    }
+    // ---- epilogue (the arithmetic of igemm_epilogue, CPL = 8): lane (i16, g) owns channels ncol .. ncol + 7 of pixels f*16 + i16 ----
+    {
+      const int ncol = wc * 32 + g * 8;
+      float bv[8];
+      *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(sBias + ncol);
+      *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(sBias + ncol + 4);
+      uint32_t off[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int m = m0 + wr * 64 + f * 16 + i16;
+        off[f] = m < p.M ? (uint32_t)(m * p.ldo + ncol) * 2u : kOob;
+      }
+      u32x4 rv[4], mv[4];
+      if (p.resid) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) rv[f] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)off[f], 0, 0);
+      }
+      if (p.mask) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) mv[f] = __builtin_amdgcn_raw_buffer_load_b128(r_msk, (int)off[f], 0, 0);
+      }
+      float cs[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + bv[j * 4 + r];
+        if (p.resid) {
+          const bf16raw* pr = reinterpret_cast<const bf16raw*>(&rv[f]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32(pr[e]);
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.mask) {
+          const bf16raw* pm = reinterpret_cast<const bf16raw*>(&mv[f]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16_to_f32(pm[e]) > 0.f) ? v[e] : 0.f;
+        }
+        bf16raw ov[8];
+        const float live = off[f] != kOob ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ov[e] = f32_to_bf16(v[e]);
+          cs[e] += live * bf16_to_f32(ov[e]);
+        }
+        held[f] = *reinterpret_cast<const u32x4*>(ov);
+        held_off[f] = off[f];
+      }
+      if (p.colsum_part) {  // uniform: partial column sums of this tile -> colsum_part[tile][ldo]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t_ = cs[e];
+          t_ += __shfl_xor(t_, 1, 64);
+          t_ += __shfl_xor(t_, 2, 64);
+          t_ += __shfl_xor(t_, 4, 64);
+          t_ += __shfl_xor(t_, 8, 64);
+          cs[e] = t_;
+        }
+        // (the scratch was last read before this tile's top barrier)
+        if (i16 == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sScratch[wr * 64 + ncol + e] = cs[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 64) {
+          held_cs = sScratch[tid] + sScratch[64 + tid];
+          held_cs_off = (uint32_t)(tl * p.ldo + tid) * 4u;
+        }
+      }
+    }
+  }
+  // the last tile's stores
+#pragma unroll
+  for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b128(held[f], r_out, (int)held_off[f], 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(held_cs), r_cs, (int)held_cs_off, 0, 0);
+}
+
+template <int MODE>
+int launch_conv64(const IgemmParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, kC64Smem);
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int n_tiles = (p.M + 127) / 128;
+  const int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
+  vdqn_prof_begin(MODE == 0 ? "conv64<bf16,fwd>" : "conv64<bf16,dgrad>", 2.0 * p.M * p.co * p.ktot,
+                  2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
+  hipLaunchKernelGGL((conv64_kernel<MODE>), dim3(grid), dim3(256), kC64Smem, stream, p, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo));
+  vdqn_prof_end(stream);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
 template <typename T, int BM, int BN, int MODE, int NS = 2>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   // 256x64 tiles: 4 waves of 64x64 (WN = 1); everything else a (BM/64) x 2 wave grid
@@ -1044,6 +1316,12 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   // 64-column layers with many rows: 256-row tiles, 8 waves (more MFMA work per DMA round trip, half the weight traffic)
   // (VDQN_BM256_MIN_ROWS overrides the row threshold: tests lower it to reach this variant with small tensors, a huge value disables it)
   // 3x3 / stride 1 / pad 1: the window kernel (one staged activation window per kernel row and channel chunk)
+  // 64 -> 64 channels, bf16: the persistent kernel with the weights in registers (VDQN_CONV64=0 falls back to the window kernel)
+  static const int use_c64 = [] { const char* e = getenv("VDQN_CONV64"); return e ? atoi(e) : 1; }();
+  if (use_c64 && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && mode != 2 && a->ci == 64 && a->co == 64 &&
+      a->pix_stride == 64 && a->hi == a->ho && a->wi == a->wo && a->wo >= 2 && a->wo <= 56 && p.in_bytes < 0x7fffffffLL && (long long)p.M * 128 < 0x7fffffffLL &&
+      a->out && !a->out_f32 && p.vec_ok && (long long)p.M * a->ldo * 2 < 0x7fffffffLL)
+    return mode == 0 ? launch_conv64<0>(p, st) : launch_conv64<1>(p, st);
   static const int use_win = [] { const char* e = getenv("VDQN_IGEMM_WINDOW"); return e ? atoi(e) : 1; }();
   if (use_win && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && mode != 2 && a->pix_stride == a->ci && a->wo >= 2) {
     if (a->dtype == VDQN_BF16) {
