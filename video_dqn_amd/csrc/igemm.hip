@@ -959,6 +959,7 @@ int launch_igemm_win(const IgemmParams& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kC64WinRows = 248;                 // 128 + 2 * 56 + 2 = 242 rows, rounded up to the 8-row DMA piece
 constexpr int kC64WinBytes = kC64WinRows * 128;
+constexpr int kC64LoadTap = 4;                   // K-loop tap in front of which the epilogue's residual / mask loads are issued
 constexpr int kC64RegTaps = 7;                   // taps whose weight fragments live in registers; the rest are read from LDS
 constexpr int kC64Smem = 2 * kC64WinBytes + 128 + 512 + 256 + (9 - kC64RegTaps) * 8192;  // windows, zero row, column-sum scratch, bias, LDS taps
 
@@ -1080,9 +1081,29 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
       for (int j = 0; j < 2; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned char* a_rd = smem + buf * kC64WinBytes + (wr * 64 + i16) * 128;
     const unsigned char* z_rd = sZ + (g << 4);
+    // epilogue operands: offsets now, the residual / mask loads are issued in the middle of the K loop (tap kC64LoadTap) so
+    // that the remaining taps' MFMAs cover most of their latency
+    const int ncol = wc * 32 + g * 8;
+    uint32_t off[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int m = m0 + wr * 64 + f * 16 + i16;
+      off[f] = m < p.M ? (uint32_t)(m * p.ldo + ncol) * 2u : kOob;
+    }
+    u32x4 rv[4], mv[4];
     // 18 steps (tap, K half); the forward reads input pixel m + (kr-1) W + (ks-1), the data gradient m + (1-kr) W + (1-ks)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+      if (tap == kC64LoadTap) {
+        if (p.resid) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) rv[f] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)off[f], 0, 0);
+        }
+        if (p.mask) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) mv[f] = __builtin_amdgcn_raw_buffer_load_b128(r_msk, (int)off[f], 0, 0);
+        }
+      }
       const int kr = tap / 3, ks = tap % 3;
       const int ky = MODE == 0 ? kr : 2 - kr, kx = MODE == 0 ? ks : 2 - ks;  // window offsets
       const uint32_t tapbits = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u);
@@ -1112,25 +1133,9 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     }
     // ---- epilogue (the arithmetic of igemm_epilogue, CPL = 8): lane (i16, g) owns channels ncol .. ncol + 7 of pixels f*16 + i16 ----
     {
-      const int ncol = wc * 32 + g * 8;
       float bv[8];
       *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(sBias + ncol);
       *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(sBias + ncol + 4);
-      uint32_t off[4];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const int m = m0 + wr * 64 + f * 16 + i16;
-        off[f] = m < p.M ? (uint32_t)(m * p.ldo + ncol) * 2u : kOob;
-      }
-      u32x4 rv[4], mv[4];
-      if (p.resid) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) rv[f] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)off[f], 0, 0);
-      }
-      if (p.mask) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) mv[f] = __builtin_amdgcn_raw_buffer_load_b128(r_msk, (int)off[f], 0, 0);
-      }
       float cs[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) cs[e] = 0.f;
