@@ -290,3 +290,30 @@ def test_conv_256_row_tile_variant():
                         "-k", "(conv_forward or conv_dgrad or stem or linear) and not variant"], env=env, cwd=root,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("geom", [(3, 10, 6), (2, 5, 17), (24, 56, 56)])
+def test_conv64_persistent_kernel_geometries(geom):
+    """bf16 64 -> 64 channel 3x3 convs run the persistent kernel (weights in registers, one window per tile, deferred stores):
+    non-square images, and more tiles (588) than resident workgroups (512) so that every workgroup walks several tiles."""
+    from video_dqn_amd import ops
+    n, h, w_ = geom
+    dtype = torch.bfloat16
+    x = q(rnd(11, "x", (n, 64, h, w_)), dtype)
+    w = q(rnd(12, "w", (64, 64, 3, 3), -0.1, 0.1), dtype)
+    b = rnd(13, "b", (64,))
+    res = q(rnd(14, "r", (n, 64, h, w_)), dtype)
+    ref = F.relu(F.conv2d(x, w, b, 1, 1) + res)
+    out = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=h, wo=w_, co=64, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
+    torch.cuda.synchronize()
+    assert relerr(out.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    # data gradient with mask, residual and per-tile column sums
+    gy = q(rnd(15, "gy", (n, 64, h, w_)), dtype)
+    xact = q(rnd(16, "xa", (n, 64, h, w_)), dtype)
+    refg = (F.grad.conv2d_input((n, 64, h, w_), w, gy, 1, 1) + res) * (xact > 0)
+    wd = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)
+    got, part = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=w_, co=64, r=3, s=3, stride=1, pad=1, mode=1, resid=nhwc(res, dtype), mask=nhwc(xact, dtype),
+                           want_colsum=True)
+    torch.cuda.synchronize()
+    assert relerr(got.float().cpu().permute(0, 3, 1, 2), refg) < TOL[dtype]
+    assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
