@@ -57,6 +57,50 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const void* __restrict_
   }
 }
 
+// uint8 HWC source, two packed rows per block: the four source rows (672 bytes each) are read as 16-byte vectors into LDS and
+// every thread builds one packed pixel from there (the per-pixel version above issues twelve single-byte loads per thread).
+// Same arithmetic, so the same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_rows_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst) {
+  __shared__ uint4 rows[4][42];
+  const int n = blockIdx.y, y0 = 2 * blockIdx.x;  // packed rows y0, y0 + 1 -> source rows 2 (y0 - 2) .. + 3
+  const int tid = threadIdx.x;
+  const int Y0 = 2 * (y0 - 2);
+  if (tid < 168) {
+    const int r = tid / 42, c = tid - r * 42, Y = Y0 + r;
+    rows[r][c] = ((unsigned)Y < 224u) ? reinterpret_cast<const uint4*>(src + ((size_t)n * 224 + Y) * 672)[c] : make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  const int yy = tid / 115, x = tid - yy * 115, y = y0 + yy;
+  if (tid >= 230 || y >= 115) return;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const int ys = y - 2, xs = x - 2;
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = 0.f;
+  if ((unsigned)ys < 112u && (unsigned)xs < 112u) {
+    const uint8_t* b0 = reinterpret_cast<const uint8_t*>(rows[2 * yy]) + 6 * xs;
+    const uint8_t* b1 = reinterpret_cast<const uint8_t*>(rows[2 * yy + 1]) + 6 * xs;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      v[e] = (((float)b0[e] / 255.0f) - mean[e % 3]) / stdv[e % 3];
+      v[6 + e] = (((float)b1[e] / 255.0f) - mean[e % 3]) / stdv[e % 3];
+    }
+  }
+  T* d = dst + ((size_t)n * 115 * 115 + (size_t)y * 115 + x) * 16;
+  if constexpr (sizeof(T) == 2) {
+    uint32_t w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+    reinterpret_cast<uint4*>(d)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    reinterpret_cast<uint4*>(d)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) reinterpret_cast<float4*>(d)[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // max-pool 3x3 / stride 2 / pad 1 (NHWC), first maximum wins (torch CPU semantics)
 // ---------------------------------------------------------------------------------------------------------
@@ -364,6 +408,12 @@ extern "C" int vdqn_pack_input(const void* src, int32_t src_kind, void* dst, int
   VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_pack_input: bad dtype");
   const int g = grid_for((long)n_img * 115 * 115);
   ProfScope ps_("pack_input", 0.0, (double)n_img * (224.0 * 224 * 3 * (src_kind == 0 ? 1 : 4) + 115.0 * 115 * 16 * (dtype == VDQN_BF16 ? 2 : 4)), (hipStream_t)stream);
+  if (src_kind == 0 && n_img <= 65535 && (((uintptr_t)src) & 15) == 0) {  // frames are 150528 = 16 * 9408 bytes: every source row is 16-byte aligned
+    if (dtype == VDQN_BF16) hipLaunchKernelGGL((pack_input_rows_kernel<bf16raw>), dim3(58, n_img), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (bf16raw*)dst);
+    else hipLaunchKernelGGL((pack_input_rows_kernel<float>), dim3(58, n_img), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (float*)dst);
+    VDQN_LAUNCH_CHECK();
+    return VDQN_OK;
+  }
   if (dtype == VDQN_BF16) hipLaunchKernelGGL((pack_input_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, src, src_kind, (bf16raw*)dst, n_img);
   else hipLaunchKernelGGL((pack_input_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, src, src_kind, (float*)dst, n_img);
   VDQN_LAUNCH_CHECK();
