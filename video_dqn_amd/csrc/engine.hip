@@ -1094,13 +1094,15 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
 
-  RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
+  // the frames are packed on the side stream while the main stream folds the weights (two small kernels each); the target
+  // pass then simply continues on the side stream: it only reads the packed input and its own weights
   const int64_t frame_bytes = (int64_t)115 * 115 * 16 * net->esz;
-  RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, st));
-  if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, st));
-  hipStream_t tst = st;  // stream of the target-network forward
+  hipStream_t tst = fork_side(net, st);  // == st when the overlap is off
+  RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, tst));
+  if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
+  RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
+  if (tst != st) join_side(net, st);  // packed input ready for the online pass
   if (!gtb) {
-    tst = fork_side(net, st);  // the packed input is ready; the target pass only reads it and its own weights
     const ActLayout T = act_layout(net, B);
     RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst));
   }
@@ -1227,6 +1229,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   const unsigned char* pk = (const unsigned char*)a->packed_online;
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
+  bool split_conv1 = false;  // stage 2, extra_capacity: conv1's weight gradient is unfolded separately (see below)
 
   if (net->basic()) {
     if (stage == 0) {
@@ -1269,9 +1272,11 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
     // bn1's shift gradient = column sums of g_c1 = column sums of g_pool (max-pool routes every pooled gradient element
     // to exactly one input position), which block 0's dgrad epilogue already produced as partials
+    split_conv1 = net->overlap && net->side && net->l_conv1 == net->layer_stage_first[2] && net->layer_stage_count[2] > 1;
+    if (split_conv1) join_side(net, st);  // the other layers' weight gradients: unfolded while conv1's (the last, 0.25 ms) still runs
     RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
   }
-  join_side(net, st);  // every weight gradient of this stage is complete before it is unfolded
+  if (!split_conv1) join_side(net, st);  // every weight gradient of this stage is complete before it is unfolded
   int max_co = 0;
   for (int i = net->layer_stage_first[stage]; i < net->layer_stage_first[stage] + net->layer_stage_count[stage]; ++i)
     max_co = net->layers[i].co > max_co ? net->layers[i].co : max_co;
@@ -1300,8 +1305,16 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
       set(net->l_b_conv1[b], W.p_h[b], (int64_t)n * sp * sp, planes, 1, 0);
     }
   }
-  hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, st, net->fold, pt, net->layer_stage_first[stage],
-                     a->params, a->bnstats, (const unsigned char*)bw, a->grads, net->basic() ? 1 : 0);
+  if (split_conv1) {
+    hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage] - 1), dim3(256), 0, st, net->fold, pt, net->layer_stage_first[stage] + 1,
+                       a->params, a->bnstats, (const unsigned char*)bw, a->grads, 0);
+    join_side(net, st);
+    hipLaunchKernelGGL(unfold_kernel, dim3(net->layers[net->l_conv1].co, 1), dim3(256), 0, st, net->fold, pt, net->l_conv1, a->params, a->bnstats,
+                       (const unsigned char*)bw, a->grads, 0);
+  } else {
+    hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, st, net->fold, pt, net->layer_stage_first[stage],
+                       a->params, a->bnstats, (const unsigned char*)bw, a->grads, net->basic() ? 1 : 0);
+  }
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }
