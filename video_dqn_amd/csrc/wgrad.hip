@@ -593,6 +593,144 @@ int launch_wgrad(const WgradParams& p, int tiles, int splitk, hipStream_t stream
   return VDQN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of the stem (conv1 as the 4x4/1 convolution over the packed space-to-depth frame, bf16):
+//   dw[co][ky][kx*16 + c] += sum over conv pixels (y, x) of g_c1[y][x][co] * packed[y + ky][x + kx][c]
+// The generic kernel treats every ky as a tap with a 64-wide "channel" dimension (4 packed pixels x 16) and stages, per 64
+// pixels and tap, an 8 KiB gradient tile and an 8 KiB input tile whose rows overlap by 96 of 128 bytes: 32 FLOP per staged
+// byte, i.e. bound by the L2 -> LDS fill rate (~420 TFLOP/s on the padded K).  Here a workgroup walks whole conv rows: per
+// row it stages the 112 x 64 gradient tile ONCE for all four ky and the four packed input rows y .. y+3 as they lie in memory
+// (115 x 32 bytes each, no duplication); wave ky reads its B fragments at a shift of kx packed pixels.  Rows are padded to
+// 128 pixels with gradient rows that stay zero (4 x 32-pixel MFMA sub-steps, 12.5 % padding).  Partial 64 x 256 results are
+// added to dw with f32 atomics like the generic kernel's.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSwGyBytes = 128 * 128;             // [128 pixel rows][64 co] bf16; rows 112.. are never staged and stay zero
+constexpr int kSwXRow = 4096 + 128;               // one packed input row: 128 px x 32 B (115 real) + a zero tail for the kx shift
+constexpr int kSwBuf = kSwGyBytes + 4 * kSwXRow;  // 33280 bytes
+constexpr int kSwSmem = 2 * kSwBuf;
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16raw* __restrict__ gy, const bf16raw* __restrict__ x, float* __restrict__ dw,
+                                                            int total_rows, int rows_per_block, int gy_bytes, int x_bytes) {
+  using T = bf16raw;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ky = __builtin_amdgcn_readfirstlane(wave);  // wave = kernel row
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(total_rows, r0 + rows_per_block);
+  if (r0 >= r1) return;
+  // the parts of both buffers the DMA never writes: gradient rows 112..127 and the tail of every packed row
+  for (int i = tid; i < 2 * (128 + 32); i += 256) {
+    const int b = i / 160, k = i - b * 160;
+    unsigned char* d = k < 128 ? smem + b * kSwBuf + 112 * 128 + k * 16 : smem + b * kSwBuf + kSwGyBytes + ((k - 128) >> 3) * kSwXRow + 4096 + ((k - 128) & 7) * 16;
+    *reinterpret_cast<uint4*>(d) = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long g_ptr = (unsigned long long)gy, x_ptr = (unsigned long long)x;
+  const i32x4 rs_g = {__builtin_amdgcn_readfirstlane((int)(unsigned)g_ptr), __builtin_amdgcn_readfirstlane((int)((g_ptr >> 32) & 0xffff)), gy_bytes, 0x00020000};
+  const i32x4 rs_x = {__builtin_amdgcn_readfirstlane((int)(unsigned)x_ptr), __builtin_amdgcn_readfirstlane((int)((x_ptr >> 32) & 0xffff)), x_bytes, 0x00020000};
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // per-lane parts of the source offsets: gradient piece = 8 pixel rows x 128 B (source chunk XOR-swizzled like wgrad_kernel's
+  // 64-wide tiles), input piece = 32 packed pixels x 32 B
+  const int g_jj = lane >> 3;
+  const uint32_t x_lane = (uint32_t)((lane >> 1) * 32 + (lane & 1) * 16);
+
+  auto issue_row = [&](int R, int buf) {
+    const int img = R / 112, y = R - img * 112;
+    const uint32_t g_row0 = (uint32_t)(img * 12544 + y * 112);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int piece = ky + 4 * k;  // wave-uniform
+      if (piece < 14) {
+        const int row = piece * 8 + g_jj;
+        const uint32_t vg = (g_row0 + (uint32_t)row) * 128u + (uint32_t)((((lane & 7) ^ wg_swz<T, 64>(row)) << 4));
+        const uint32_t l_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)(buf * kSwBuf + piece * 1024)));
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vg), "s"(l_), "s"(rs_g) : "memory");
+      }
+    }
+    const uint32_t x_row0 = (uint32_t)((img * 115 + y + ky) * 115) * 32u + x_lane;
+    const uint32_t lx = lds_base + (uint32_t)(buf * kSwBuf + kSwGyBytes + ky * kSwXRow);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t vx = x_row0 + (uint32_t)(j * 1024);
+      const uint32_t l_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lx + (uint32_t)(j * 1024)));
+      asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vx), "s"(l_), "s"(rs_x) : "memory");
+    }
+  };
+
+  f32x4 acc[4][4];  // [co fragment][kx]
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int grp = lane >> 4, i16 = lane & 15;
+  const int q = i16 >> 2, pp = i16 & 3;
+  const int row = 4 * grp + q;  // pixel row (of 32) this lane addresses in a transposing read; the high half is 16 rows on
+  const int sz = wg_swz<T, 64>(row);
+  int offa[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) offa[f] = row * 128 + (((((f * 16) >> 3) + (pp >> 1)) ^ sz) << 4) + ((pp & 1) << 3);
+  const int offb = row * 32 + pp * 8;
+
+  issue_row(r0, 0);
+  int buf = 0;
+  for (int R = r0; R < r1; ++R, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // row R landed for every wave; every wave is done with the other buffer
+    if (R + 1 < r1) issue_row(R + 1, buf ^ 1);
+    const unsigned char* a = smem + buf * kSwBuf;
+    const unsigned char* b = smem + buf * kSwBuf + kSwGyBytes + ky * kSwXRow;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      s16x8 af[4], bfr[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const unsigned char* pa = a + sub * (32 * 128) + offa[f];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 16 * 128));
+        af[f] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const unsigned char* pb = b + (sub * 32 + kx) * 32 + offb;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pb);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + 16 * 32));
+        bfr[kx] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx)
+          acc[f][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bfr[kx]), acc[f][kx], 0, 0, 0);
+    }
+  }
+  // C layout: col (lane & 15) -> kx*16 + c, row ((lane >> 4) * 4 + reg) -> co
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) atomicAdd(dw + (size_t)(f * 16 + grp * 4 + reg) * 256 + ky * 64 + kx * 16 + i16, acc[f][kx][reg]);
+}
+
+int launch_stem_wgrad(const WgradParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSwSmem);
+    attr_set = true;
+  }
+  const int total_rows = p.n_img * 112;
+  const int grid = total_rows < 512 ? total_rows : 512;
+  const int rpb = (total_rows + grid - 1) / grid;
+  vdqn_prof_begin("wgrad_stem<bf16>", 2.0 * p.M * 64 * 147, 2.0 * ((double)p.M * 64 + (double)p.n_img * 115 * 115 * 16) + 4.0 * 64 * 256, stream);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((total_rows + rpb - 1) / rpb), dim3(256), kSwSmem, stream, (const bf16raw*)p.gy, (const bf16raw*)p.x, p.dw, total_rows,
+                     rpb, p.gy_bytes, p.x_bytes);
+  vdqn_prof_end(stream);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
 template <int BCO, int BCI>
 int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
   constexpr int KP = 32 * ((BCO == 64 && BCI == 64) ? 4 : 2);
@@ -660,6 +798,11 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps.  Default: the
   // 64-channel layers only (64x64 tiles, 672 vs 420 TFLOP/s).  VDQN_WGRAD_WINDOW=2 also routes the wider layers to
   // 128(co) x 64(ci) window tiles — measured 557-601 vs 625-650 TFLOP/s for the generic 128x128 kernel, so not the default
+  static const int use_stem = [] { const char* e = getenv("VDQN_WGRAD_STEM"); return e ? atoi(e) : 1; }();
+  if (use_stem && a->dtype == VDQN_BF16 && a->r == 4 && a->s == 1 && a->ci == 64 && a->pix_stride == 16 && a->hi == 115 && a->wi == 115 && a->ho == 112 &&
+      a->wo == 112 && a->co == 64 && a->ldg == 64 && a->stride == 1 && a->pad == 0 && a->splitk <= 0) {
+    rc = launch_stem_wgrad(p, st);
+  } else
   if (use_win && (bt == 64 || use_win >= 2) && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 &&
       a->pix_stride == a->ci && a->wo >= 2 && a->hi == a->ho && a->wi == a->wo) {
     const int bco = bt, bci = 64;
