@@ -798,14 +798,14 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps.  Default: the
   // 64-channel layers only (64x64 tiles, 672 vs 420 TFLOP/s).  VDQN_WGRAD_WINDOW=2 also routes the wider layers to
   // 128(co) x 64(ci) window tiles — measured 557-601 vs 625-650 TFLOP/s for the generic 128x128 kernel, so not the default
+  // 64 x 64 window tiles also win on the 128- and 256-channel layers (layer2 / layer3: 705 vs 645 TFLOP/s) as long as tiles x
+  // split fills one round of 512 blocks; layer4 (192 tiles -> 384 blocks) stays on the generic 128 x 128 kernel (650 vs 605)
+  const bool small_win = bt == 64 || (long long)co_pad * a->ci <= 256 * 256;
   static const int use_stem = [] { const char* e = getenv("VDQN_WGRAD_STEM"); return e ? atoi(e) : 1; }();
   if (use_stem && a->dtype == VDQN_BF16 && a->r == 4 && a->s == 1 && a->ci == 64 && a->pix_stride == 16 && a->hi == 115 && a->wi == 115 && a->ho == 112 &&
       a->wo == 112 && a->co == 64 && a->ldg == 64 && a->stride == 1 && a->pad == 0 && a->splitk <= 0) {
     rc = launch_stem_wgrad(p, st);
   } else
-  // 64 x 64 window tiles also win on the 128- and 256-channel layers (layer2 / layer3: 705 vs 645 TFLOP/s) as long as tiles x
-  // split fills one round of 512 blocks; layer4 (192 tiles -> 384 blocks) stays on the generic 128 x 128 kernel (650 vs 605)
-  const bool small_win = bt == 64 || (long long)co_pad * a->ci <= 256 * 256;
   if (use_win && (small_win || use_win >= 2) && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 &&
       a->pix_stride == a->ci && a->wo >= 2 && a->hi == a->ho && a->wi == a->wo) {
     const int bco = (small_win || use_win >= 3) ? 64 : bt, bci = 64;  // VDQN_WGRAD_WINDOW=2: 128 x 64 tiles for layer4, =3: 64 x 64 everywhere
