@@ -29,7 +29,7 @@ def tag_of(kernel_name: str):
     m = re.search(r"igemm_win_kernel<(unsigned short|float), (\d+), (\d+)>", kernel_name)
     if m:
         return f"igemm_win<{'bf16' if m[1] == 'unsigned short' else 'f32'},{m[2]},{('fwd', 'dgrad')[int(m[3])]}>"
-    m = re.search(r"wgrad_win_kernel<(\d+)>", kernel_name)
+    m = re.search(r"wgrad_win_kernel<(\d+)(?:, \d+)?>", kernel_name)
     if m:
         return f"wgrad_win<bf16,{m[1]}>"
     m = re.search(r"wgrad_kernel<(unsigned short|float), (\d+)>", kernel_name)
