@@ -57,6 +57,11 @@ CONV_CASES = [
     (1, 64, 64, 5, 3, 1, 1),    # M = 25 < one tile
     (3, 512, 512, 7, 3, 1, 1),  # layer4 geometry, 8 channel chunks per tap
     (2, 256, 128, 14, 3, 1, 1), # layer3 geometry, co != ci
+    # nine-tap window kernel (bf16, 128-column tiles, W <= 28): edge geometry
+    (2, 128, 128, 28, 3, 1, 1), # layer2 geometry: the 192-row window fills the LDS budget
+    (7, 128, 128, 2, 3, 1, 1),  # 2-pixel rows and columns: every tap of every pixel but the centre one is masked somewhere
+    (40, 128, 128, 3, 3, 1, 1), # 9 pixels per image: one window spans 15 images
+    (1, 128, 256, 5, 3, 1, 1),  # M = 25 < one tile, two column tiles
 ]
 
 
@@ -314,6 +319,33 @@ def test_conv64_persistent_kernel_geometries(geom):
     wd = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)
     got, part = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=w_, co=64, r=3, s=3, stride=1, pad=1, mode=1, resid=nhwc(res, dtype), mask=nhwc(xact, dtype),
                            want_colsum=True)
+    torch.cuda.synchronize()
+    assert relerr(got.float().cpu().permute(0, 3, 1, 2), refg) < TOL[dtype]
+    assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
+
+
+@pytest.mark.parametrize("geom", [(3, 10, 6), (2, 5, 17), (5, 28, 28)])
+def test_nine_tap_window_kernel_nonsquare(geom):
+    """bf16 3x3 convs with 128-column tiles run igemm_win9 (one staged window per channel chunk for all nine taps): non-square
+    images (row pitch != column count) and the widest supported rows, forward (residual + ReLU) and data gradient (mask +
+    column sums)."""
+    from video_dqn_amd import ops
+    n, h, w_ = geom
+    dtype = torch.bfloat16
+    ci, co = 128, 256
+    x = q(rnd(21, "x", (n, ci, h, w_)), dtype)
+    w = q(rnd(22, "w", (co, ci, 3, 3), -0.1, 0.1), dtype)
+    b = rnd(23, "b", (co,))
+    res = q(rnd(24, "r", (n, co, h, w_)), dtype)
+    ref = F.relu(F.conv2d(x, w, b, 1, 1) + res)
+    out = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=h, wo=w_, co=co, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
+    torch.cuda.synchronize()
+    assert relerr(out.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    gy = q(rnd(25, "gy", (n, co, h, w_)), dtype)
+    xact = q(rnd(26, "xa", (n, ci, h, w_)), dtype)
+    refg = F.grad.conv2d_input((n, ci, h, w_), w, gy, 1, 1) * (xact > 0)
+    wd = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)
+    got, part = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=w_, co=ci, r=3, s=3, stride=1, pad=1, mode=1, mask=nhwc(xact, dtype), want_colsum=True)
     torch.cuda.synchronize()
     assert relerr(got.float().cpu().permute(0, 3, 1, 2), refg) < TOL[dtype]
     assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
