@@ -1380,16 +1380,17 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
           for (int e = 0; e < 8; ++e) v[e] = (bf16_to_f32(pm[e]) > 0.f) ? v[e] : 0.f;
         }
         bf16raw ov[8];
-        const float live = off[f] != kOob ? 1.f : 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ov[e] = f32_to_bf16(v[e]);
-          cs[e] += live * bf16_to_f32(ov[e]);
+        for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(v[e]);
+        if constexpr (MODE == 1) {  // column sums exist for the data gradient only (the dispatch keeps a forward call that asks for them off this kernel)
+          const float live = off[f] != kOob ? 1.f : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[e] += live * bf16_to_f32(ov[e]);
         }
         held[f] = *reinterpret_cast<const u32x4*>(ov);
         held_off[f] = off[f];
       }
-      if (p.colsum_part) {  // uniform: partial column sums of this tile -> colsum_part[tile][ldo]
+      if (MODE == 1 && p.colsum_part) {  // uniform: partial column sums of this tile -> colsum_part[tile][ldo]
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float t_ = cs[e];
@@ -1544,7 +1545,7 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   static const int use_c64 = [] { const char* e = getenv("VDQN_CONV64"); return e ? atoi(e) : 1; }();
   if (use_c64 && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && mode != 2 && a->ci == 64 && a->co == 64 &&
       a->pix_stride == 64 && a->hi == a->ho && a->wi == a->wo && a->wo >= 2 && a->wo <= 56 && p.in_bytes < 0x7fffffffLL && (long long)p.M * 128 < 0x7fffffffLL &&
-      a->out && !a->out_f32 && p.vec_ok && (long long)p.M * a->ldo * 2 < 0x7fffffffLL)
+      a->out && !a->out_f32 && p.vec_ok && (long long)p.M * a->ldo * 2 < 0x7fffffffLL && (mode == 1 || !a->colsum_part))
     return mode == 0 ? launch_conv64<0>(p, st) : launch_conv64<1>(p, st);
   static const int use_win = [] { const char* e = getenv("VDQN_IGEMM_WINDOW"); return e ? atoi(e) : 1; }();
   if (use_win && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && mode != 2 && a->pix_stride == a->ci && a->wo >= 2) {
