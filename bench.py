@@ -9,6 +9,11 @@ synthetic 224x224 RGB frames — BASELINE.json's metric on its config[1] (ResNet
 
 One process per GPU; for N > 1 the flat gradient is all-reduced over RCCL in three buckets as the staged
 backward completes them (weak scaling: 256 samples per GPU).  Rank 0 prints ONE JSON line.
+
+Called WITHOUT a launcher, ``--gpus N`` (N > 1) starts the N rank processes itself: the parent does so before any
+GPU call (it never initialises HIP), relays rank 0's JSON line and exits with the ranks' code
+(video_dqn_amd/launch.py).  ``VDQN_BENCH_SINGLE_DEVICE=1 python bench.py --gpus 2 --backend gloo`` runs the N > 1
+path on a 1-GPU box (functional check only: the ranks share the device).
 """
 from __future__ import annotations
 
@@ -48,7 +53,21 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="skip the event-profiled steps (roofline = null)")
     ap.add_argument("--profile-steps", type=int, default=5)
-    return ap.parse_args()
+    ap.add_argument("--pool", type=int, default=4,
+                    help="distinct synthetic minibatches resident in HBM, used round-robin (4 x 77 MB of frames at batch 256 do "
+                         "not fit the 256 MiB Infinity Cache together, so no step reads its frames from cache)")
+    ap.add_argument("--loss-kind", default="l2", choices=["l2", "huber"], help="l2 = the reference's loss (train_q_network.py:167)")
+    ap.add_argument("--c4", action="store_true",
+                    help="BASELINE config 4's timing window: at least 2200 timed steps so that two target refreshes "
+                         "(every 1000 updates) fall inside it")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and issue the bucketed all-reduces even with one rank (RCCL and the "
+                         "stream ordering of the exchange exercised on a single GPU)")
+    args = ap.parse_args()
+    if args.c4:
+        args.steps = max(args.steps, 2200)
+        args.target_update_interval = 1000
+    return args
 
 
 def cpu_baseline(batch: int, budget_s: float = 25.0):
@@ -103,12 +122,17 @@ def pmc_traffic(kernel: str, batch: int, frames: int, dtype: str, arch: str = "e
 
 def main():
     args = parse()
+    from video_dqn_amd import launch
+    if args.gpus > 1 and not launch.in_rank_env():
+        # no launcher around us: become one.  Nothing above has touched the GPU (importing torch does not), so the
+        # children are started from a HIP-free parent that only waits for them.
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    out_stream = launch.claim_stdout()  # the JSON line goes here; fd 1 now points at stderr (native-library chatter)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     if os.environ.get("VDQN_BENCH_SINGLE_DEVICE") == "1":
@@ -116,8 +140,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(launch.free_port())
         dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if args.backend == "nccl" else {}))
 
     from video_dqn_amd import _lib, synth
@@ -128,20 +155,26 @@ def main():
     ec = args.arch == "extra_capacity"
     net = NetEngine(3, 5, F, ec, args.dtype, 2 * B, device=dev)
     net.load_tensors(synth.make_state_dict(4, extra_capacity=ec, num_frames=F))  # same seed on every rank: replicas start identical
-    comm = BucketAllReduce(world) if world > 1 else None
+    comm = BucketAllReduce(world, force=args.force_dist) if use_dist else None
     if world > 1 and not ec:
         net.set_bn_sync(world)  # 'basic': global BatchNorm statistics (N ranks == one big batch)
     stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=args.target_update_interval,
-                    world_size=world, allreduce=(comm.launch if comm else None))
+                    world_size=world, allreduce=(comm.launch if comm else None), loss_kind=args.loss_kind)
 
-    # synthetic minibatch, resident in HBM before the timed region: uint8 frames (normalise fused into packing)
+    # synthetic minibatches, resident in HBM before the timed region: uint8 frames (normalise fused into packing).
+    # `--pool` distinct ones are used round-robin so that a step does not find its frames in the Infinity Cache.
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    before = torch.randint(0, 256, (B, F, 224, 224, 3), dtype=torch.uint8, device=dev, generator=g)
-    after = torch.randint(0, 256, (B, F, 224, 224, 3), dtype=torch.uint8, device=dev, generator=g)
-    act = torch.randint(0, 3, (B,), dtype=torch.int64, device=dev, generator=g)
-    rew = (torch.rand((B, 5), device=dev, generator=g) < 0.05).float()
-    term = rew.clone()
+    n_pool = max(1, args.pool if args.h2d == "none" else 1)
+    pool = []
+    for _ in range(n_pool):
+        b_ = torch.randint(0, 256, (B, F, 224, 224, 3), dtype=torch.uint8, device=dev, generator=g)
+        a_ = torch.randint(0, 256, (B, F, 224, 224, 3), dtype=torch.uint8, device=dev, generator=g)
+        act_ = torch.randint(0, 3, (B,), dtype=torch.int64, device=dev, generator=g)
+        rew_ = (torch.rand((B, 5), device=dev, generator=g) < 0.05).float()
+        pool.append((b_, a_, act_, rew_, rew_.clone()))
+    before, after, act, rew, term = pool[0]
+    pool_i = {"i": 0}
 
     if args.h2d != "none":
         host = [t.cpu().pin_memory() for t in (before, after)]
@@ -173,7 +206,9 @@ def main():
             state["i"] = i + 1
             b, a = bufs[i & 1]
             return stp.step(b, a, 0, act, rew, term, finish_allreduce=(comm.finish if comm else None))
-        return stp.step(before, after, 0, act, rew, term, finish_allreduce=(comm.finish if comm else None))
+        b_, a_, act_, rew_, term_ = pool[pool_i["i"] % n_pool]
+        pool_i["i"] += 1
+        return stp.step(b_, a_, 0, act_, rew_, term_, finish_allreduce=(comm.finish if comm else None))
 
     for _ in range(args.warmup):
         one_step()
@@ -189,11 +224,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [round(1e3 * elapsed / args.steps, 3)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [round(1e3 * x.item() / args.steps, 3) for x in allt]
+        elapsed = max(x.item() for x in allt)  # MAX over ranks
     loss_val = float(loss.item())
+    refreshes = (stp.sample_number // args.target_update_interval) - (args.warmup // args.target_update_interval)
 
     # ---- live per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel ----
     roofline = None
@@ -228,6 +267,8 @@ def main():
             ach = v["flops"] / v["ms"] / 1e9
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B, F, args.dtype, args.arch),
+                        "traffic_source": "profiles/pmc_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "command (PMC cannot be collected from inside the process), per launch",
                         "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
                         "alg_flops_per_launch": round(v["flops"] / v["launches"]),
                         "alg_bytes_per_launch": round(v["bytes"] / v["launches"]),
@@ -248,10 +289,16 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if args.h2d == "none" else f"synthetic, uint8 frames copied from pinned host memory every step ({args.h2d})",
             "config": {"workload": f"HabitatDQNMultiAction ResNet-18 {args.arch}, 5 categories x 3 actions, full TD update "
-                                   "(online fwd on [s;s'], target fwd on s', Double-DQN target + L2 TD loss, backward, Adam)",
+                                   f"(online fwd on [s;s'], target fwd on s', Double-DQN target + {'L2' if args.loss_kind == 'l2' else 'Huber'} TD loss, backward, Adam)",
                        "batch_per_gpu": B, "global_batch": B * world, "frames_per_sample": F, "frame": "224x224x3 uint8 (normalise fused)",
                        "parallelism": f"dp{world}", "target_update_interval": args.target_update_interval,
-                       "gamma": 0.99, "loss_clip": "rect", "lr": 1e-4},
+                       "gamma": 0.99, "loss_clip": "rect", "lr": 1e-4, "loss_kind": args.loss_kind,
+                       "minibatch_pool": n_pool},
+            "per_rank_ms_per_step": per_rank_ms,
+            "target_refreshes_in_window": refreshes,
+            "allreduce": ({"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "buckets_bytes": comm.bucket_bytes,
+                           "overlapped_with": "backward stages 1-2 (bucket s is launched when stage s's unfold_grads is queued)"}
+                          if comm else None),
             "model_tflops": round(value * gflop_tuple / 1e3, 2),
             "model_frac_of_bf16_peak": round(value * gflop_tuple / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "loss": loss_val,
@@ -262,8 +309,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=out_stream, flush=True)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -85,8 +85,12 @@ typedef struct vdqn_conv_args {
 int vdqn_conv2d(const vdqn_conv_args* a, void* stream);
 
 /* Weight gradient of the same layer:  dw[n][r][s][c] += sum_m gy[m, n] * x[pix(m,r,s), c]
- * (f32 atomics into a pre-zeroed dw; split over `splitk` pixel ranges).  If dbias != NULL it also
+ * (split over `splitk` pixel ranges whose partial tiles are added into dw with f32 atomics).  If dbias != NULL it also
  * accumulates dbias[n] += sum_m gy[m, n].
+ * Deterministic mode (the reference pins cudnn.deterministic = True, train_q_network.py:88-89): with `workspace` set
+ * (vdqn_conv2d_wgrad_workspace_bytes gives the size) every split stores its partial tile into its own copy of dw with plain
+ * stores and a second kernel adds the copies to dw in split order — the result no longer depends on the order in which the
+ * blocks finish, two runs are bit-identical.
  * Replaces: the convolution_backward/addmm weight-gradient kernels behind loss.backward(),
  * train_q_network.py:226. */
 typedef struct vdqn_wgrad_args {
@@ -98,8 +102,11 @@ typedef struct vdqn_wgrad_args {
   int32_t ho, wo, co, ldg;
   int32_t r, s, stride, pad;
   int32_t splitk, dtype;
+  void* workspace;          /* NULL: atomics; else >= vdqn_conv2d_wgrad_workspace_bytes(a) bytes, 16-byte aligned */
+  int64_t workspace_bytes;
 } vdqn_wgrad_args;
 int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream);
+int64_t vdqn_conv2d_wgrad_workspace_bytes(const vdqn_wgrad_args* a);  /* -1 on invalid arguments */
 
 /* Input packing: normalise + space-to-depth the 224x224 RGB frames into the conv1 operand
  * [n][115][115][16] (2x2x3 -> 12 channels + 4 zero, 2-pixel zero border top/left, 1 bottom/right), so the
@@ -122,8 +129,11 @@ int vdqn_maxpool_bwd(const void* gy, const uint8_t* idx, const void* x, void* gx
 /* Fused Double-DQN target + TD loss + dLoss/dQ  (train_q_network.py:134-169,180).
  *   Qb = q_before[b,c,act[b]]; a* = argmax_a q_after_online[b,c,:] (first max); Qa = q_after_target[b,c,a*]
  *   Qa *= (1 - term); y = linear ? rew + (Qa - 0.1) : rew + gamma*Qa; rect clip -> clamp(y,0,1)
- *   l = 0.5 (Qb - y)^2 (* valid if use_valid); loss += inv_count * sum l;
- *   dq[b, c*A+a] = (a == act[b]) ? (Qb - y) * (valid) * inv_count : 0   (rows of ldq elems, zero padded)
+ *   d = Qb - y;  loss_kind 0 (the reference, :167): l = 0.5 d^2, dl = d
+ *                loss_kind 1 (Huber / smooth-L1 with beta 1, the option archs/HabitatDQNMultiAction.py:25 leaves as a
+ *                TODO): l = |d| < 1 ? 0.5 d^2 : |d| - 0.5, dl = clamp(d, -1, 1)
+ *   l *= valid if use_valid; loss += inv_count * sum l;
+ *   dq[b, c*A+a] = (a == act[b]) ? dl * (valid) * inv_count : 0   (rows of ldq elems, zero padded)
  * q_* are f32 [batch][ldq]; act i64; rew/term/valid f32 [batch][n_cat]; loss is a pre-zeroed f32 scalar. */
 typedef struct vdqn_td_args {
   const float* q_before;
@@ -139,6 +149,8 @@ typedef struct vdqn_td_args {
   int32_t batch, n_cat, n_act, ldq;
   float gamma, inv_count;
   int32_t clip_rect, linear, use_valid, dtype;
+  int32_t loss_kind;      /* 0 = half squared error (reference), 1 = Huber */
+  int32_t deterministic;  /* 1: the loss is summed by ONE block in a fixed order (no cross-block atomics) */
 } vdqn_td_args;
 int vdqn_td_loss(const vdqn_td_args* a, void* stream);
 
@@ -207,6 +219,10 @@ typedef struct vdqn_net_config {
                               0: 'basic' (defaults.py:14 — train-mode BatchNorm, average pool + one Linear) */
   int32_t dtype;           /* VDQN_F32 | VDQN_BF16 */
   int32_t max_batch;       /* largest per-call sample count B the workspaces are sized for */
+  int32_t deterministic;   /* 1: run-to-run bit-identical updates (the reference's cudnn.deterministic = True,
+                              train_q_network.py:88-89): weight gradients through the two-stage ordered reduction of
+                              vdqn_conv2d_wgrad (its workspace is part of `bwd`), the loss summed by one block.
+                              ARCHITECTURE='basic' keeps atomic sums in its train-mode BatchNorm statistics. */
 } vdqn_net_config;
 
 typedef struct vdqn_net vdqn_net;
@@ -317,6 +333,7 @@ typedef struct vdqn_step_args {
   float* grads;               /* flat f32 [trainable_numel] */
   float* loss;                /* f32 scalar (device) */
   float* q_before;            /* optional f32 [B][15] copy of Q(s) */
+  int32_t loss_kind;          /* vdqn_td_args.loss_kind (TD branch only) */
 } vdqn_step_args;
 int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream);
 int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream);

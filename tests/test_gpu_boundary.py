@@ -81,6 +81,33 @@ def test_run_train_checkpoint_resume_and_load_model_number(tmp_path):
     assert torch.equal(q3, q2)
 
 
+def test_bootstrap_branch_loads_model_and_optimizer(tmp_path):
+    """BOOTSTRAP (train_q_network.py:200-206): the run starts from another run's checkpoint — model AND Adam state —
+    instead of silently training from scratch; a missing file raises as in the reference."""
+    from video_dqn_amd.config import ExperimentConfig
+    from video_dqn_amd.trainer import run_train
+    base = ("DATASET: 'synthetic'\nPANORAMA: False\nLOSS_CLIP: 'rect'\nARCHITECTURE: 'extra_capacity'\nLEARNING_RATE: 0.0001\n"
+            "GAMMA: 0.99\nCHECKPOINT_INTERVAL: 2\nNUM_STEPS: 2\nSEED: 4\nBATCH_SIZE: 4\nNUM_WORKERS: 0\nCOMPUTE_DTYPE: 'f32'\n")
+    src = tmp_path / "gt"
+    src.mkdir()
+    (src / "config.yml").write_text(base)
+    m0, st0, _ = run_train(ExperimentConfig(str(src), device="cuda", tensorboard=False))
+    ckpt = src / "models" / "sample2.torch"
+    dst = tmp_path / "boot"
+    dst.mkdir()
+    (dst / "config.yml").write_text(base.replace("NUM_STEPS: 2", "NUM_STEPS: 1") + f"BOOTSTRAP: True\nBOOTSTRAP_CHECKPOINT: '{ckpt}'\n")
+    logs = []
+    m1, st1, _ = run_train(ExperimentConfig(str(dst), device="cuda", tensorboard=False), log=lambda *a: logs.append(" ".join(map(str, a))))
+    assert any("BOOTSTRAP" in l for l in logs) and any(str(ckpt) in l for l in logs)
+    assert st1.adam_step == 3  # two steps restored from the checkpoint + one update here
+    snap = torch.load(ckpt, map_location="cpu")
+    w0, w1 = snap["model_state_dict"]["top.4.weight"], m1.state_dict()["top.4.weight"].cpu()
+    assert (w0 - w1).abs().max().item() < 3e-4 and not torch.equal(w0, w1)  # one lr=1e-4 Adam step away from the checkpoint
+    (dst / "config.yml").write_text(base + "BOOTSTRAP: True\nBOOTSTRAP_CHECKPOINT: '/nonexistent/epoch99.torch'\n")
+    with pytest.raises(FileNotFoundError):
+        run_train(ExperimentConfig(str(dst), device="cuda", tensorboard=False))
+
+
 def test_run_train_basic_arch_defaults(tmp_path):
     """defaults.py's own configuration: ARCHITECTURE 'basic' + PANORAMA (F = 4): the loop trains, BatchNorm statistics and
     num_batches_tracked advance, and the checkpoint loads strictly into the reference class layout (244 keys)."""
@@ -117,8 +144,8 @@ def test_run_train_on_feather_jpeg_dataset_and_shards(tmp_path):
     -> TD updates -> checkpoint; the same run from decoded-frame shards sees identical batches, so with one loader worker
     and the same seed the two runs end with the same parameters; the inverse-action labelling utility writes the column
     the loader reads."""
-    pytest.importorskip("pyarrow")  # feather I/O (present in the build container; skip where the image lacks it)
-    pytest.importorskip("PIL")
+    import PIL  # noqa: F401  (hard requirements of this data path: a missing one must fail the run, not skip it)
+    import pyarrow  # noqa: F401
     from test_shards_cpu import _make_dataset
     from video_dqn_amd.config import ExperimentConfig
     from video_dqn_amd.shards import build_shards

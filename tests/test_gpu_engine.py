@@ -371,3 +371,60 @@ def test_side_stream_overlap_matches_serial():
             assert abs(l - res[0][1]) <= 1e-6 * abs(res[0][1])
             assert relerr(g, res[0][0]) < 1e-5, rep
     net.lib.vdqn_net_set_overlap(net.handle, 1)
+
+
+@pytest.mark.parametrize("dtype,B", [("bf16", 16), ("f32", 6)])
+def test_deterministic_mode_is_bit_identical_run_to_run(dtype, B):
+    """DETERMINISTIC / VDQN_DETERMINISTIC=1 (the reference pins cudnn.deterministic = True, train_q_network.py:88-89): every
+    weight gradient goes through the two-stage ordered reduction instead of f32 atomics and the loss is summed by one block,
+    so two runs from the same state are BIT-identical over three updates (side stream on: the order in which blocks or
+    streams finish must not matter), and agree with the atomic mode to summation-order accuracy."""
+    from video_dqn_amd.engine import NetEngine, TDStepper
+
+    def run(det):
+        net = NetEngine(3, 5, 1, True, dtype, 2 * B, deterministic=det)
+        net.load_tensors(synth.make_state_dict(7))
+        stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=2)
+        losses, g1 = [], None
+        for step in range(3):
+            (tup, raw) = synth.make_batch(700 + step, B, 1, structured=True, reward_p=0.3)
+            stp.step(torch.from_numpy(raw[0]).to(DEV), torch.from_numpy(raw[1]).to(DEV), 0, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV))
+            torch.cuda.synchronize()
+            losses.append(stp.loss.item())
+            if step == 0:
+                g1 = stp.grads.clone()
+        return net.params.clone(), stp.exp_avg_sq.clone(), losses, g1
+
+    a, b, c = run(True), run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and torch.equal(a[3], b[3])
+    # same arithmetic as the atomic mode, only the summation order differs (first update, before Adam amplifies rounding)
+    assert relerr(a[3], c[3]) < (1e-5 if dtype == "f32" else 1e-4)
+    assert abs(a[2][0] - c[2][0]) <= 1e-6 * abs(c[2][0])
+
+
+def test_deterministic_wgrad_operator_matches_atomic_mode():
+    """vdqn_conv2d_wgrad with a workspace (ordered two-stage reduction) against the atomic mode, every kernel variant:
+    window 64x64 (layer1-3 geometry), generic 128 (layer4, stride 2), generic 64 (1x1 / stride 2), the stem kernel."""
+    from video_dqn_amd import ops
+    cases = [(6, 14, 64, 64, 3, 1, 1), (5, 7, 512, 512, 3, 1, 1), (4, 14, 128, 256, 3, 2, 1), (4, 14, 128, 256, 1, 2, 0), (3, 9, 256, 256, 3, 1, 1)]
+    for n, hi, ci, co, k, stride, pad in cases:
+        ho = (hi + 2 * pad - k) // stride + 1
+        x = torch.from_numpy(synth.uniform(n * 100 + ci, "x", (n, hi, hi, ci), -1.0, 1.0)).to(torch.bfloat16).to(DEV)
+        gy = torch.from_numpy(synth.uniform(n * 100 + co, "gy", (n, ho, ho, co), -1.0, 1.0)).to(torch.bfloat16).to(DEV)
+        kw = dict(co=co, r=k, s=k, stride=stride, pad=pad)
+        dw_a, db_a = ops.conv2d_wgrad(gy, x, **kw)
+        dw_d1, db_d1 = ops.conv2d_wgrad(gy, x, deterministic=True, **kw)
+        dw_d2, db_d2 = ops.conv2d_wgrad(gy, x, deterministic=True, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(dw_d1, dw_d2) and torch.equal(db_d1, db_d2), (n, hi, ci, co, k)
+        assert relerr(dw_d1, dw_a) < 1e-5 and relerr(db_d1, db_a) < 1e-5, (n, hi, ci, co, k)
+    # conv1 as the 4x4/1 convolution over the packed frame (stem kernel)
+    n = 3
+    t_in = torch.from_numpy(synth.uniform(5, "t", (n, 115, 115, 16), -1.0, 1.0)).to(torch.bfloat16).to(DEV)
+    gy = torch.from_numpy(synth.uniform(6, "g", (n, 112, 112, 64), -1.0, 1.0)).to(torch.bfloat16).to(DEV)
+    kw = dict(co=64, r=4, s=1, stride=1, pad=0, ci=64, pix_stride=16, want_dbias=False)
+    a = ops.conv2d_wgrad(gy, t_in, **kw)
+    d1 = ops.conv2d_wgrad(gy, t_in, deterministic=True, **kw)
+    d2 = ops.conv2d_wgrad(gy, t_in, deterministic=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d2) and relerr(d1, a) < 1e-5

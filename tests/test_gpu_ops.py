@@ -260,6 +260,58 @@ def test_td_loss_branches_vs_golden(golden):
         np.testing.assert_allclose(dq32.cpu()[:, :15].reshape(6, 5, 3).numpy(), golden[f"g4gt_dq_{vl}"], rtol=1e-5, atol=1e-8)
 
 
+def _td_reference(qb, qo, qt, act, rew, term, vm, gamma, clip, linear, kind):
+    """The statements of process_batch (train_q_network.py:134-169,180) in torch autograd on the CPU, with the loss
+    function as a parameter: 0.5 d^2 (the reference) or smooth_l1_loss (Huber)."""
+    qb = qb.clone().requires_grad_(True)
+    B = qb.shape[0]
+    before_values = qb[torch.arange(B), :, act]
+    best = qo.argmax(dim=2)
+    q_a = qt.gather(2, best.unsqueeze(2)).squeeze(2) * (1 - term)
+    y = rew + (q_a - 0.1) if linear else rew + gamma * q_a
+    if clip:
+        y = y.clamp(0, 1)
+    if kind == "l2":
+        losses = 0.5 * (before_values - y.detach()) ** 2
+    else:
+        losses = torch.nn.functional.smooth_l1_loss(before_values, y.detach(), reduction="none")
+    if vm is not None:
+        losses = losses * vm
+    loss = losses.mean()
+    loss.backward()
+    return loss.item(), qb.grad
+
+
+@pytest.mark.parametrize("kind", ["l2", "huber"])
+def test_td_loss_float_rewards_and_huber(kind):
+    """CONFIDENCE_REWARD gives non-binary f32 rewards (dataloaders/q_learning_real.py:78-80), and LOSS_KIND='huber' is this
+    build's selectable variant: both against torch autograd over the reference's statements.  TD errors are spread over
+    [-3, 3] so that both Huber branches (|d| < 1 and beyond) are taken."""
+    from video_dqn_amd import ops
+    B, A = 37, 3
+    for s, clip, linear, use_vm in ((1, True, False, False), (2, False, False, True), (3, False, True, False)):
+        qb = torch.from_numpy(synth.uniform(40 + s, "qb", (B, 5, A), -2.0, 3.0))
+        qo = torch.from_numpy(synth.uniform(40 + s, "qo", (B, 5, A), -1.0, 2.0))
+        qt = torch.from_numpy(synth.uniform(40 + s, "qt", (B, 5, A), -1.0, 2.0))
+        act = torch.from_numpy(synth.randint(40 + s, "act", (B,), A))
+        rew = torch.from_numpy(synth.uniform(40 + s, "rew", (B, 5), 0.0, 1.0))  # detector confidences, not 0/1
+        term = torch.from_numpy((synth.uniform(40 + s, "term", (B, 5)) < 0.2).astype(np.float32))
+        vm = torch.from_numpy((synth.uniform(40 + s, "vm", (B, 5)) < 0.7).astype(np.float32)) if use_vm else None
+        ref_loss, ref_dq = _td_reference(qb, qo, qt, act, rew, term, vm, 0.99, clip, linear, kind)
+
+        def pad(t):
+            o = torch.zeros((B, 64)); o[:, :15] = t.reshape(B, 15)
+            return o.to(DEV)
+        loss, dq, dq32 = ops.td_loss(pad(qb), pad(qo), pad(qt), act.to(DEV), rew.to(DEV), term.to(DEV), vm.to(DEV) if use_vm else None,
+                                     gamma=0.99, clip_rect=clip, linear=linear, loss_kind=kind)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(loss.item(), ref_loss, rtol=3e-6)
+        np.testing.assert_allclose(dq32.cpu()[:, :15].reshape(B, 5, A).numpy(), ref_dq.numpy(), rtol=1e-5, atol=1e-9)
+        if kind == "huber":
+            d = (dq32.cpu()[:, :15].abs() * (5 * B)).flatten()
+            assert (d > 0.999).any() and ((d > 0) & (d < 0.999)).any()  # both branches were exercised
+
+
 def test_adam_matches_torch():
     from video_dqn_amd import ops
     n = 100003

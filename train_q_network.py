@@ -3,7 +3,8 @@
 (reference ``train_q_network.py:253-296``).  The public names evaluation code imports from the reference
 module — ``build_model``, ``load_model_number``, ``run_train`` — are re-exported here.
 
-Multi-GPU (new): launch with ``python -m torch.distributed.run --nproc-per-node N train_q_network.py <dir>``;
+Multi-GPU (new): ``-g 0,1,2,3`` starts one rank per listed GPU from this process (before anything touches the GPU:
+video_dqn_amd/launch.py), or launch with ``python -m torch.distributed.run --nproc-per-node N train_q_network.py <dir>``;
 each rank takes GPU LOCAL_RANK and a disjoint shard of every shuffled epoch.
 """
 import argparse
@@ -34,6 +35,13 @@ if __name__ == "__main__":
     parser.add_argument("config", help="folder containing config file")
     args = parser.parse_args()
 
+    from video_dqn_amd import launch
+    gpu_ids = [g for g in args.gpu.split(",") if g != ""]
+    if len(gpu_ids) > 1 and not launch.in_rank_env():
+        # one rank per listed GPU; this parent never initialises HIP and exits with the ranks' code
+        single = os.environ.get("VDQN_SINGLE_DEVICE") == "1"  # functional test: every rank on the first listed GPU
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], len(gpu_ids),
+                                    {"HIP_VISIBLE_DEVICES": gpu_ids[0] if single else args.gpu}))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -43,11 +51,15 @@ if __name__ == "__main__":
     from video_dqn_amd.config import ExperimentConfig
     from video_dqn_amd.trainer import run_train
 
+    if os.environ.get("VDQN_SINGLE_DEVICE") == "1":  # functional test of the N > 1 path on a 1-GPU box (with gloo)
+        local_rank = 0
     device = f"cuda:{local_rank}" if world > 1 else "cuda"
     if world > 1:
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        backend = os.environ.get("VDQN_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" for functional tests on one GPU
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world,
+                                             **({"device_id": torch.device(device)} if backend == "nccl" else {}))
     config = ExperimentConfig(args.config, device=device, remove=args.delete and rank == 0, resume=args.resume or rank != 0,
                               tensorboard=(rank == 0))
     if rank == 0:

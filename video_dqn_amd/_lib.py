@@ -8,10 +8,11 @@ import os
 import torch  # noqa: F401  -- must come first: libvdqn binds to the ROCm runtime torch has already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvdqn.so")
+# VDQN_LIB=<name> loads lib/libvdqn_<name>.so (a variant built with VDQN_LIB_OUT=<name>: A/B and diagnostic builds)
+LIB_PATH = os.path.join(_HERE, "lib", f"libvdqn{'_' + os.environ['VDQN_LIB'] if os.environ.get('VDQN_LIB') else ''}.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -30,7 +31,7 @@ class WgradArgs(C.Structure):
                 ("n_img", c_i32), ("hi", c_i32), ("wi", c_i32), ("ci", c_i32), ("pix_stride", c_i32),
                 ("ho", c_i32), ("wo", c_i32), ("co", c_i32), ("ldg", c_i32),
                 ("r", c_i32), ("s", c_i32), ("stride", c_i32), ("pad", c_i32),
-                ("splitk", c_i32), ("dtype", c_i32)]
+                ("splitk", c_i32), ("dtype", c_i32), ("workspace", c_vp), ("workspace_bytes", c_i64)]
 
 
 class TdArgs(C.Structure):
@@ -38,12 +39,12 @@ class TdArgs(C.Structure):
                 ("rew", c_vp), ("term", c_vp), ("valid", c_vp), ("loss", c_vp), ("dq", c_vp), ("dq_f32", c_vp),
                 ("batch", c_i32), ("n_cat", c_i32), ("n_act", c_i32), ("ldq", c_i32),
                 ("gamma", c_f32), ("inv_count", c_f32),
-                ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("dtype", c_i32)]
+                ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("dtype", c_i32), ("loss_kind", c_i32), ("deterministic", c_i32)]
 
 
 class NetConfig(C.Structure):
     _fields_ = [("action_dim", c_i32), ("num_classes", c_i32), ("num_frames", c_i32), ("extra_capacity", c_i32),
-                ("dtype", c_i32), ("max_batch", c_i32)]
+                ("dtype", c_i32), ("max_batch", c_i32), ("deterministic", c_i32)]
 
 
 class ParamInfo(C.Structure):
@@ -64,7 +65,7 @@ class StepArgs(C.Structure):
                 ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("train_on_ground_truth", c_i32),
                 ("value_learning", c_i32),
                 ("acts_online", c_vp), ("acts_target", c_vp), ("bwd", c_vp), ("grads", c_vp), ("loss", c_vp),
-                ("q_before", c_vp)]
+                ("q_before", c_vp), ("loss_kind", c_i32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, c_vp, c_vp, c_i64, c_vp)  # vdqn_allreduce_fn(user, buf, count, stream)
@@ -76,6 +77,7 @@ _SIGS = {
     "vdqn_profile_collect": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "vdqn_conv2d": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
     "vdqn_conv2d_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
+    "vdqn_conv2d_wgrad_workspace_bytes": (c_i64, [C.POINTER(WgradArgs)]),
     "vdqn_pack_input": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "vdqn_maxpool_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_maxpool_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

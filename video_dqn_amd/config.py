@@ -12,7 +12,12 @@ Keys added by this build (all optional, defaults reproduce the reference): BATCH
 hard-codes 16, train_q_network.py:98), NUM_WORKERS (8), COMPUTE_DTYPE ('bf16' | 'f32'), NUM_FRAMES (0 = the
 reference's rule: 4 if PANORAMA or PREVIOUS_IMAGES else 1), SYNTHETIC_DATA (train on generated frames), DEVICE_RESIDENT_DATA ('auto' | 'on' | 'off': keep a decoded-frame shard
 dataset in HBM and gather minibatches on the device), SYNC_BN (ARCHITECTURE='basic' on several GPUs: global BatchNorm
-statistics, so N ranks equal the reference's single big batch; default True).
+statistics, so N ranks equal the reference's single big batch; default True), DETERMINISTIC (run-to-run bit-identical
+updates — the reference's cudnn.deterministic = True, train_q_network.py:88-89 — at a small throughput cost), LOSS_KIND ('l2' = the reference's half
+squared TD error, train_q_network.py:167; 'huber' = smooth-L1, the option archs/HabitatDQNMultiAction.py:25 leaves open),
+PRETRAINED_WEIGHTS (path of a torchvision resnet18 state_dict: the reference builds models.resnet18(pretrained=True),
+archs/HabitatDQNMultiAction.py:11, which needs a download this build cannot make), BOOTSTRAP_CHECKPOINT (the file the
+BOOTSTRAP branch loads; default = the path hard-coded at train_q_network.py:202).
 """
 from __future__ import annotations
 
@@ -24,7 +29,8 @@ import shutil
 
 import yaml
 
-VALID_VALUES = {"LOSS_CLIP": ["sigmoid", "rect", "none"]}  # experiment_config.py:10
+VALID_VALUES = {"LOSS_CLIP": ["sigmoid", "rect", "none"],  # experiment_config.py:10
+                "LOSS_KIND": ["l2", "huber"]}
 
 
 class CfgNode(dict):
@@ -127,6 +133,10 @@ def get_cfg_defaults() -> CfgNode:
     c.SYNTHETIC_DATA = False
     c.SYNC_BN = True
     c.DEVICE_RESIDENT_DATA = "auto"
+    c.DETERMINISTIC = False
+    c.LOSS_KIND = "l2"
+    c.PRETRAINED_WEIGHTS = ""
+    c.BOOTSTRAP_CHECKPOINT = "logs/trained_gt_0.99/models/epoch99.torch"
     return c
 
 

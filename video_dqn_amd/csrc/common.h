@@ -59,6 +59,12 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
 
 void vdqn_set_error(const char* fmt, ...);
 
+// Per-device launch state (profile.hip).  hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's copy
+// of a kernel, and the CU count differs per device, so neither may be cached process-wide: both are keyed by hipGetDevice()
+// and guarded by a mutex (engines on several GPUs, launches from several host threads).
+void vdqn_ensure_dyn_smem(const void* kernel, size_t bytes);
+int vdqn_num_cus();
+
 // launch profiler hooks (profile.hip); no-ops unless vdqn_profile_enable(1)
 void vdqn_prof_begin(const char* tag, double flops, double bytes, hipStream_t st);
 void vdqn_prof_end(hipStream_t st);

@@ -12,6 +12,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -28,7 +29,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 6; }
+extern "C" int vdqn_abi_version(void) { return 7; }
 
 namespace {
 
@@ -86,6 +87,7 @@ struct BwdLayout {
   int64_t dq, g_l1, g_l0, g_f8, g_o[8], g_h[8], dsg[8], g_pool, g_c1;
   int64_t p_l1, p_l0, p_f8, p_o[8], p_h[8], p_pool;  // per-128-row-tile column sums written by the dgrad epilogues
   int64_t g_avg, g_or[8], g_dsr[8];  // 'basic' only: gradient of the pooled features / of the raw conv2, downsample outputs
+  int64_t det_ws, det_ws_bytes;      // deterministic mode: the weight-gradient kernels' partial copies (one layer at a time)
   int64_t total;
 };
 
@@ -112,6 +114,7 @@ struct vdqn_net {
   // kernels fill the tail rounds of the main kernels (784..3136-block grids on 512 resident blocks).
   BnSync bn_sync = {nullptr, nullptr, nullptr, 1};  // SyncBN hook ('basic' under data parallelism)
   int overlap = 1;
+  int bwd_samples = 0;  // batch of the update in flight (set by vdqn_net_td_forward; sizes the bwd workspace layout)
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
@@ -680,6 +683,9 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
   return L;
 }
 
+vdqn_wgrad_args wgrad_shape_args(const vdqn_net* net, const Layer& L, int n_units);
+int64_t wgrad_max_imgs(const vdqn_net* net, const Layer& L);
+
 BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
   const int64_t F = net->cfg.num_frames, n = (int64_t)n_samples * F, e = net->esz;
   BwdLayout L;
@@ -717,6 +723,18 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
     L.p_o[b] = take((tiles(n * sp * sp) + 4) * planes * 4);  // +4: stride-2 dgrad rounds tiles per parity class
     L.p_h[b] = take(tiles(n * sp * sp) * planes * 4);
   }
+  L.det_ws = -1;
+  L.det_ws_bytes = 0;
+  if (net->cfg.deterministic) {
+    for (const Layer& ly : net->layers) {
+      const int64_t units = ly.per_sample ? n_samples : n;
+      const int64_t mx = wgrad_max_imgs(net, ly);
+      if (mx < 1) continue;  // run_wgrad reports it
+      const vdqn_wgrad_args wa = wgrad_shape_args(net, ly, (int)std::min(units, mx));
+      L.det_ws_bytes = std::max(L.det_ws_bytes, vdqn_conv2d_wgrad_workspace_bytes(&wa));
+    }
+    L.det_ws = take(L.det_ws_bytes);
+  }
   L.g_avg = -1;
   for (int b = 0; b < 8; ++b) L.g_or[b] = L.g_dsr[b] = -1;
   if (net->basic()) {
@@ -743,6 +761,28 @@ void prof_layer(const Layer& L, int n_units) {
   if (strncmp(nm, "resnet.", 7) == 0) nm += 7;
   snprintf(buf, sizeof(buf), "%s n%d", nm, n_units);
   g_prof_suffix = buf;
+}
+
+// the geometry part of a layer's weight-gradient call (no pointers): what vdqn_conv2d_wgrad_workspace_bytes needs
+vdqn_wgrad_args wgrad_shape_args(const vdqn_net* net, const Layer& L, int n_units) {
+  vdqn_wgrad_args a;
+  memset(&a, 0, sizeof(a));
+  a.n_img = n_units; a.hi = L.hi; a.wi = L.wi; a.ci = L.k_ci; a.pix_stride = L.pix_stride;
+  a.ho = L.ho; a.wo = L.wo; a.co = L.co_pad; a.ldg = L.co_pad;
+  a.r = L.k_r; a.s = L.k_s;
+  a.stride = L.kind == K_CONV1_S2D ? 1 : L.stride;
+  a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
+  a.splitk = 0; a.dtype = net->cfg.dtype;
+  return a;
+}
+// images one vdqn_conv2d_wgrad call can take for layer L (< 2^24 output pixels, < 2 GiB per operand: 32-bit buffer offsets)
+int64_t wgrad_max_imgs(const vdqn_net* net, const Layer& L) {
+  const int64_t esz = net->esz;
+  const int64_t pix = (int64_t)L.ho * L.wo, gy_img = pix * L.co_pad * esz, x_img = (int64_t)L.hi * L.wi * L.pix_stride * esz;
+  int64_t m = ((1ll << 24) - 1) / pix;
+  m = std::min(m, (int64_t)0x7ffffffell / gy_img);
+  m = std::min(m, (int64_t)0x7ffffffell / x_img);
+  return m;
 }
 
 int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* in, void* out, int n_units, const void* resid,
@@ -790,21 +830,37 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
 
 int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const void* gy, const void* x, int n_units, hipStream_t st,
               bool colsum_kernel = false) {
-  vdqn_wgrad_args a;
-  memset(&a, 0, sizeof(a));
+  vdqn_wgrad_args a = wgrad_shape_args(net, L, n_units);
   a.gy = gy;
   a.x = x;
   a.dw = reinterpret_cast<float*>(bwd + L.dw_off);
   a.dbias = colsum_kernel ? reinterpret_cast<float*>(bwd + L.db_off) : nullptr;  // else: dgrad-epilogue partials
-  a.n_img = n_units; a.hi = L.hi; a.wi = L.wi; a.ci = L.k_ci; a.pix_stride = L.pix_stride;
-  a.ho = L.ho; a.wo = L.wo; a.co = L.co_pad; a.ldg = L.co_pad;
-  a.r = L.k_r; a.s = L.k_s;
-  a.stride = L.kind == K_CONV1_S2D ? 1 : L.stride;
-  a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
-  a.splitk = 0; a.dtype = net->cfg.dtype;
-  g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
-  prof_layer(L, n_units);
-  return vdqn_conv2d_wgrad(&a, st);
+  if (net->cfg.deterministic) {  // all weight gradients of an update run on ONE stream, so they can share the workspace
+    const BwdLayout W = bwd_layout(net, net->bwd_samples);
+    a.workspace = bwd + W.det_ws;
+    a.workspace_bytes = W.det_ws_bytes;
+  }
+  // vdqn_conv2d_wgrad addresses < 2^24 output pixels and < 2 GiB per operand (32-bit buffer offsets): larger batches
+  // (conv1 at more than 1337 bf16 / 668 f32 frames, e.g. 12-view samples at batch 256) go through it in image ranges —
+  // dw and dbias accumulate, so the ranges simply add up.
+  const int64_t esz = net->esz;
+  const int64_t pix = (int64_t)L.ho * L.wo, gy_img = pix * L.co_pad * esz, x_img = (int64_t)L.hi * L.wi * L.pix_stride * esz;
+  const int64_t max_imgs = wgrad_max_imgs(net, L);
+  if (max_imgs < 1) {
+    vdqn_set_error("run_wgrad: one image of layer %s exceeds the weight-gradient kernel's addressing range", L.name.c_str());
+    return VDQN_ERR_INVALID;
+  }
+  for (int64_t i0 = 0; i0 < n_units; i0 += max_imgs) {
+    const int n_chunk = (int)std::min<int64_t>(max_imgs, n_units - i0);
+    a.gy = (const unsigned char*)gy + i0 * gy_img;
+    a.x = (const unsigned char*)x + i0 * x_img;
+    a.n_img = n_chunk;
+    g_prof_alg_flops = 2.0 * n_chunk * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
+    prof_layer(L, n_chunk);
+    const int rc = vdqn_conv2d_wgrad(&a, st);
+    if (rc != VDQN_OK) return rc;
+  }
+  return VDQN_OK;
 }
 
 #define RC(x)                     \
@@ -905,6 +961,7 @@ extern "C" int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out) {
   VDQN_CHECK(cfg->action_dim >= 1 && cfg->num_classes >= 1 && cfg->action_dim * cfg->num_classes <= 64, "vdqn_net_create: action_dim*num_classes must be in 1..64");
   VDQN_CHECK(cfg->num_frames >= 1 && cfg->num_frames <= 64, "vdqn_net_create: num_frames out of range");
   VDQN_CHECK(cfg->max_batch >= 1, "vdqn_net_create: max_batch");
+  VDQN_CHECK(cfg->deterministic == 0 || cfg->deterministic == 1, "vdqn_net_create: deterministic must be 0 or 1");
   vdqn_net* net = new vdqn_net();
   net->cfg = *cfg;
   net->esz = cfg->dtype == VDQN_BF16 ? 2 : 4;
@@ -1017,12 +1074,8 @@ extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const f
   const int dgrad = with_dgrad & 1, raw = (with_dgrad >> 1) & 1;
   ProfScope ps_("fold_weights", 0.0, (double)net->trainable_numel * 4.0 + (double)net->packed_bytes * (dgrad ? 1.0 : 0.5), (hipStream_t)stream);
   const size_t tile_smem = 32 * (64 * 9 + 1) * 4;  // [32 output channels][64 * taps + 1] f32
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_tile_kernel<bf16raw>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_tile_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_smem);
-    attr_set = true;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&fold_tile_kernel<bf16raw>), (size_t)tile_smem);
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&fold_tile_kernel<float>), (size_t)tile_smem);
   if (net->cfg.dtype == VDQN_BF16) {
     hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw);
     hipLaunchKernelGGL((fold_tile_kernel<bf16raw>), dim3(net->fold.n_tiles, 2), dim3(256), tile_smem, (hipStream_t)stream, net->fold, params, bnstats,
@@ -1091,6 +1144,7 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   const int ns_online = gtb ? B : 2 * B;
   const ActLayout A = act_layout(net, ns_online);
   const BwdLayout W = bwd_layout(net, B);
+  net->bwd_samples = B;
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
 
@@ -1132,6 +1186,8 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     t.batch = B; t.n_cat = net->cfg.num_classes; t.n_act = net->cfg.action_dim; t.ldq = 64;
     t.gamma = a->gamma; t.inv_count = a->inv_count;
     t.clip_rect = a->clip_rect; t.linear = a->linear; t.use_valid = a->use_valid; t.dtype = dt;
+    t.loss_kind = a->loss_kind;
+    t.deterministic = net->cfg.deterministic;
     RC(vdqn_td_loss(&t, st));
   } else {
     RC(vdqn_gt_loss(qf_online, a->act, a->gt, a->loss, bw + W.dq, nullptr, B, net->cfg.num_classes, net->cfg.action_dim, 64, a->inv_count,

@@ -928,11 +928,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void igemm_win_kernel(const 
 template <typename T, int BN, int MODE>
 int launch_igemm_win(const IgemmParams& p, hipStream_t stream) {
   const size_t smem = 2 * (128 + 8) * 128 + 2 * BN * 128 + 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_win_kernel<T, BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&igemm_win_kernel<T, BN, MODE>), (size_t)smem);
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
   const double esz = sizeof(T);
   static const char* const kTag[2][2][2] = {{{"igemm_win<bf16,64,fwd>", "igemm_win<bf16,64,dgrad>"}, {"igemm_win<bf16,128,fwd>", "igemm_win<bf16,128,dgrad>"}},
@@ -973,6 +969,13 @@ __global__ __launch_bounds__(256, 2) void igemm_win9_kernel(const IgemmParams p,
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+#ifdef VDQN_PRIO
+  {  // experiment: the wave in the odd slot of its SIMD runs at priority 1 (anti-phase of the two co-resident workgroups)
+    unsigned hwid_p;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_p));
+    if (hwid_p & 1) __builtin_amdgcn_s_setprio(VDQN_PRIO);
+  }
+#endif
   const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = (int)(lb % (uint32_t)p.tiles_n), tile_m = (int)(lb / (uint32_t)p.tiles_n);
   const int n0 = tile_n * BN, m0 = tile_m * BM;
@@ -1113,14 +1116,32 @@ __global__ __launch_bounds__(256, 2) void igemm_win9_kernel(const IgemmParams p,
     acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[SET][h_][j_]),                   \
                                                           __builtin_bit_cast(bf16x8, fa[SET][h_][f_]), acc[f_][j_], 0, 0, 0); \
   }
+#ifdef VDQN_STAMP
+  // diagnostic build only (tools/stamp_win9.py): s_memtime around the phases of every K-step, summed per workgroup by wave 0
+  unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_comp = 0, st_t = 0;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_rt_begin = __builtin_amdgcn_s_memrealtime();
+#define VDQN_ST(ACC)                                                     \
+  {                                                                      \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();          \
+    ACC += n_ - st_t;                                                    \
+    st_t = n_;                                                           \
+  }
+#else
+#define VDQN_ST(ACC)
+#endif
 #define VDQN_STEP(K, CUR, NXT)                                                                                           \
   {                                                                                                                      \
+    VDQN_ST(st_comp)                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
+    VDQN_ST(st_wait)                                                                                                     \
     asm volatile("" : "+v"(fa[CUR][0][0]), "+v"(fa[CUR][0][1]), "+v"(fa[CUR][0][2]), "+v"(fa[CUR][0][3]),                \
                       "+v"(fa[CUR][1][0]), "+v"(fa[CUR][1][1]), "+v"(fa[CUR][1][2]), "+v"(fa[CUR][1][3]));               \
     _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) asm volatile("" : "+v"(fb[CUR][0][j_]), "+v"(fb[CUR][1][j_]));     \
     __builtin_amdgcn_s_barrier();                                                                                        \
+    VDQN_ST(st_bar)                                                                                                      \
     if (issued < nk) VDQN_ISSUE_STEP((K) & 1)                                                                            \
+    VDQN_ST(st_issue)                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     VDQN_LOAD_FRAGS(NXT, ((K) + 1) & 1) /* unconditional: the step behind the last one re-reads buffers that still exist */ \
     VDQN_MFMA_ALL(CUR)                                                                                                   \
@@ -1132,10 +1153,15 @@ __global__ __launch_bounds__(256, 2) void igemm_win9_kernel(const IgemmParams p,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // window 0 and weight tiles 0 / 1 are visible
   VDQN_LOAD_FRAGS(0, 0)
+#ifdef VDQN_STAMP
+  st_t = __builtin_amdgcn_s_memtime();
+#endif
   for (int k = 0; k < nk; k += 2) {
     VDQN_STEP(k, 0, 1)
     if (k + 1 < nk) VDQN_STEP(k + 1, 1, 0)
   }
+  VDQN_ST(st_comp)
+#undef VDQN_ST
 #undef VDQN_LOAD_FRAGS
 #undef VDQN_MFMA_ALL
 #undef VDQN_STEP
@@ -1144,21 +1170,44 @@ __global__ __launch_bounds__(256, 2) void igemm_win9_kernel(const IgemmParams p,
 #undef VDQN_ISSUE_B
 #undef VDQN_DMA4
 #undef VDQN_DMA1
+#ifdef VDQN_STAMP
+  const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
   igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, p.howo, W, 0, 0);
+#ifdef VDQN_STAMP
+  if (p.pool_out && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.pool_out) + (size_t)blockIdx.x * 16;
+    o[0] = st_begin; o[1] = st_loop_end; o[2] = __builtin_amdgcn_s_memtime();
+    o[3] = st_wait; o[4] = st_bar; o[5] = st_issue; o[6] = st_comp; o[7] = (unsigned long long)nk;
+    o[8] = st_rt_begin; o[9] = __builtin_amdgcn_s_memrealtime();  // 100 MHz reference clock
+    unsigned hwid_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));
+    o[10] = hwid_;
+  }
+#endif
 }
+
+#ifdef VDQN_STAMP
+void* g_stamp_buffer = nullptr;
+#endif
 
 template <typename T, int MODE>
 int launch_igemm_win9(const IgemmParams& p, hipStream_t stream) {
   const int wrows = (128 + 2 * p.wo + 2 + 1 + 7) & ~7;
   const size_t smem = (size_t)2 * wrows * 128 + 2 * 128 * 128;
-  static size_t attr_smem = 0;
-  if (smem > attr_smem) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_win9_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_smem = smem;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&igemm_win9_kernel<T, MODE>), smem);
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
   vdqn_prof_begin(MODE == 0 ? "igemm_win<bf16,128,fwd>" : "igemm_win<bf16,128,dgrad>", 2.0 * p.M * p.co * p.ktot,
                   2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
+#ifdef VDQN_STAMP
+  IgemmParams ps = p;
+  ps.pool_out = g_stamp_buffer;
+  hipLaunchKernelGGL((igemm_win9_kernel<T, MODE>), dim3(grid), dim3(256), smem, stream, ps, wrows, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo));
+  vdqn_prof_end(stream);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+#endif
   hipLaunchKernelGGL((igemm_win9_kernel<T, MODE>), dim3(grid), dim3(256), smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo));
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
@@ -1422,17 +1471,8 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
 
 template <int MODE>
 int launch_conv64(const IgemmParams& p, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, kC64Smem);
-    attr_set = true;
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&conv64_kernel<MODE>), (size_t)kC64Smem);
+  const int n_cu = vdqn_num_cus();
   const int n_tiles = (p.M + 127) / 128;
   const int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
   vdqn_prof_begin(MODE == 0 ? "conv64<bf16,fwd>" : "conv64<bf16,dgrad>", 2.0 * p.M * p.co * p.ktot,
@@ -1448,11 +1488,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   // 256x64 tiles: 4 waves of 64x64 (WN = 1); everything else a (BM/64) x 2 wave grid
   constexpr int WN = (BM == 256 && BN == 64) ? 1 : 2;
   const size_t smem = NS * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, MODE, WN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, MODE, WN, NS>), (size_t)smem);
   const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
   const double esz = sizeof(T);
   // one tag per kernel symbol (T, BM, BN, MODE), so bench.py rows line up with rocprofv3's kernel names
@@ -1492,6 +1528,10 @@ int launch_mode(const IgemmParams& p, int mode, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef VDQN_STAMP
+extern "C" void vdqn_debug_stamp_buffer(void* p) { g_stamp_buffer = p; }  // diagnostic builds only (not part of include/vdqn.h)
+#endif
 
 extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   VDQN_CHECK(a != nullptr, "vdqn_conv2d: null args");

@@ -271,10 +271,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_rows_kernel(const T* __restri
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void td_loss_kernel(const vdqn_td_args a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = a.batch * a.ldq;
   float my_loss = 0.f;
-  if (i < total) {
+  // one element per thread; a deterministic launch is ONE block that walks all elements (fixed summation order)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int b = i / a.ldq, col = i - b * a.ldq;
     float g = 0.f;
     if (col < a.n_cat * a.n_act) {
@@ -299,8 +299,14 @@ __global__ __launch_bounds__(256) void td_loss_kernel(const vdqn_td_args a) {
         if (a.clip_rect) y = fminf(fmaxf(y, 0.f), 1.f);
         const float d = qb - y;
         const float vm = a.use_valid ? a.valid[b * a.n_cat + c] : 1.0f;
-        my_loss = 0.5f * d * d * vm;
-        g = d * vm * a.inv_count;
+        if (a.loss_kind == 1) {  // Huber, beta = 1 (torch.nn.functional.smooth_l1_loss)
+          const float ad = fabsf(d);
+          my_loss += (ad < 1.0f ? 0.5f * d * d : ad - 0.5f) * vm;
+          g = fminf(fmaxf(d, -1.0f), 1.0f) * vm * a.inv_count;
+        } else {
+          my_loss += 0.5f * d * d * vm;
+          g = d * vm * a.inv_count;
+        }
       }
     }
     if (a.dq) ((T*)a.dq)[i] = from_f32<T>(g);
@@ -544,7 +550,8 @@ extern "C" int vdqn_td_loss(const vdqn_td_args* a, void* stream) {
   VDQN_CHECK(!a->use_valid || a->valid, "vdqn_td_loss: use_valid without valid mask");
   VDQN_CHECK(a->batch > 0 && a->n_cat > 0 && a->n_act > 0 && a->ldq >= a->n_cat * a->n_act, "vdqn_td_loss: bad dims");
   VDQN_CHECK(a->dtype == VDQN_F32 || a->dtype == VDQN_BF16, "vdqn_td_loss: bad dtype");
-  const int g = (a->batch * a->ldq + 255) / 256;
+  VDQN_CHECK(a->loss_kind == 0 || a->loss_kind == 1, "vdqn_td_loss: loss_kind %d (0 = half squared error, 1 = Huber)", a->loss_kind);
+  const int g = a->deterministic ? 1 : (a->batch * a->ldq + 255) / 256;
   ProfScope ps_("td_loss", 0.0, (double)a->batch * a->ldq * 16.0, (hipStream_t)stream);
   if (a->dtype == VDQN_BF16) hipLaunchKernelGGL((td_loss_kernel<bf16raw>), dim3(g), dim3(256), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL((td_loss_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, *a);

@@ -4,6 +4,7 @@
 // cross-checked against `rocprofv3 --kernel-trace --stats` (profiles/).
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,33 @@ std::vector<std::string> g_tags;
 std::map<std::string, int> g_tag_ids;
 Rec* g_open = nullptr;
 }  // namespace
+
+void vdqn_ensure_dyn_smem(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> done;  // (kernel, device) -> largest size granted so far
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& have = done[{kernel, dev}];
+  if (bytes > have) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    have = bytes;
+  }
+}
+
+int vdqn_num_cus() {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  int& n = cus[dev & 63];
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
 
 thread_local double g_prof_alg_flops = -1.0;
 thread_local const char* g_prof_suffix = nullptr;  // engine: layer name of the next launch (VDQN_PROFILE_LAYERS=1)

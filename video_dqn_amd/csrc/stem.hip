@@ -213,18 +213,8 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 
 // bf16 entry used by vdqn_stem_conv_pool (igemm.hip); returns VDQN_OK or an error code
 int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    attr_set = true;
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
-    else n_cu = prop.multiProcessorCount;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&stem_kernel), (size_t)kSmem);
+  const int n_cu = vdqn_num_cus();
   StemParams p;
   p.t_in = (const bf16raw*)t_in; p.wt = (const bf16raw*)wt; p.bias = bias; p.pool = (bf16raw*)pool; p.idx = (uint8_t*)idx;
   p.n_img = n_img;

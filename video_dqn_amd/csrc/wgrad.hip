@@ -26,7 +26,17 @@ struct WgradParams {
   int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldg, r, s, stride, pad;
   int M, kchunk, taps, ci_tiles, gy_bytes, x_bytes, splitk;
   FastDiv d_howo, d_wo;
+  // deterministic mode: every block stores its partial tile into its split's private copy of dw (ws + split * ws_stride
+  // floats, plain stores), and wgrad_reduce_kernel sums the copies into dw in split order; nullptr = f32 atomics into dw
+  float* ws;
+  long long ws_stride;
 };
+
+// partial-sum sink of a block: an atomic into dw, or a plain store into the block's split copy (uniform branch)
+__device__ __forceinline__ void wg_emit(float* dst, bool det, float v) {
+  if (det) *dst = v;
+  else atomicAdd(dst, v);
+}
 
 template <typename T, int BT> __device__ __forceinline__ int wg_swz(int row) {
   if constexpr (sizeof(T) == 2) {
@@ -285,6 +295,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 
   // C layout: col (lane & 15) -> ci, row ((lane >> 4) * 4 + reg) -> co
   const size_t row_len = (size_t)p.taps * p.ci;
+  const bool det = p.ws != nullptr;
+  float* const dwp = det ? p.ws + (size_t)split * (size_t)p.ws_stride : p.dw;
   if constexpr (WSPLIT) {
     static_assert(!WSPLIT || KSUB == 4, "wave split needs 4 sub-steps");
     __syncthreads();  // everyone is done with the staging buffers: reuse them as 4 x [64][64] f32
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       const int o = tid + 256 * e;
       const float v = red[o] + red[4096 + o] + red[8192 + o] + red[12288 + o];
       const int co = co0 + (o >> 6), ci = ci0 + (o & 63);
-      if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, v);
+      if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, v);
     }
   } else if constexpr (sizeof(T) == 2) {
     // stage the 128x128 f32 tile through LDS so that every wave-instruction adds 256 contiguous bytes of one dw row
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     for (int e = 0; e < BT * BT / 256; ++e) {
       const int o = tid + 256 * e;
       const int co = co0 + o / BT, ci = ci0 + o % BT;
-      if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, red[o]);
+      if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, red[o]);
     }
   } else {
 #pragma unroll
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int co = co0 + wr * (BT / 2) + f * 16 + grp * 4 + reg;
-          if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, acc[f][j][reg]);
+          if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, acc[f][j][reg]);
         }
       }
   }
@@ -499,8 +511,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
     compute(buf, kbeg + k * KP);
   }
 
-  // ---- three tap tiles -> dw (f32 atomics, contiguous runs through LDS) ----
+  // ---- three tap tiles -> dw (f32 atomics, or plain stores into this split's copy; contiguous runs through LDS) ----
   const size_t row_len = (size_t)p.taps * p.ci;
+  const bool det = p.ws != nullptr;
+  float* const dwp = det ? p.ws + (size_t)split * (size_t)p.ws_stride : p.dw;
   float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
         const int o = tid + 256 * e;
         const float v = red[o] + red[4096 + o] + red[8192 + o] + red[12288 + o];
         const int co = co0 + (o >> 6), ci = ci0 + (o & 63);
-        if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, v);
+        if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, v);
       }
     } else {
 #pragma unroll
@@ -534,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
       for (int e = 0; e < BCO * BCI / 256; ++e) {
         const int o = tid + 256 * e;
         const int co = co0 + o / BCI, ci = ci0 + o % BCI;
-        if (co < p.co) atomicAdd(p.dw + (size_t)co * row_len + (size_t)tap * p.ci + ci, red[o]);
+        if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, red[o]);
       }
     }
   }
@@ -578,11 +592,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ gy, f
 template <typename T, int BT>
 int launch_wgrad(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
   const size_t smem = 4 * 32 * wg_ksub<T, BT>() * BT * sizeof(T);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_kernel<T, BT>), (size_t)smem);
   const double esz = sizeof(T);
   vdqn_prof_begin(sizeof(T) == 2 ? (BT == 128 ? "wgrad<bf16,128>" : "wgrad<bf16,64>") : (BT == 128 ? "wgrad<f32,128>" : "wgrad<f32,64>"),
                   2.0 * p.M * p.co * p.taps * p.ci,
@@ -610,7 +620,7 @@ constexpr int kSwBuf = kSwGyBytes + 4 * kSwXRow;  // 33280 bytes
 constexpr int kSwSmem = 2 * kSwBuf;
 
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16raw* __restrict__ gy, const bf16raw* __restrict__ x, float* __restrict__ dw,
-                                                            int total_rows, int rows_per_block, int gy_bytes, int x_bytes) {
+                                                            int total_rows, int rows_per_block, int gy_bytes, int x_bytes, float* __restrict__ ws) {
   using T = bf16raw;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -711,23 +721,45 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16raw* __res
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) atomicAdd(dw + (size_t)(f * 16 + grp * 4 + reg) * 256 + ky * 64 + kx * 16 + i16, acc[f][kx][reg]);
+      for (int reg = 0; reg < 4; ++reg)
+        wg_emit((ws ? ws + (size_t)blockIdx.x * (64 * 256) : dw) + (size_t)(f * 16 + grp * 4 + reg) * 256 + ky * 64 + kx * 16 + i16, ws != nullptr, acc[f][kx][reg]);
+}
+
+// deterministic mode, second stage: dw[i] += ws[0][i] + ws[1][i] + ... in split order (one thread per 4 elements)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n4, int n_splits,
+                                                           long long ws_stride) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = reinterpret_cast<const float4*>(ws)[i];
+  for (int s = 1; s < n_splits; ++s) {
+    const float4 b = reinterpret_cast<const float4*>(ws + (size_t)s * (size_t)ws_stride)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  float4 d = reinterpret_cast<float4*>(dw)[i];
+  d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+  reinterpret_cast<float4*>(dw)[i] = d;
+}
+
+int launch_wgrad_reduce(const WgradParams& p, int n_splits, long long n_elems, hipStream_t stream) {
+  const long long n4 = n_elems / 4;
+  vdqn_prof_begin("wgrad_reduce", 0.0, 4.0 * (double)n_elems * (n_splits + 2), stream);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, p.ws, p.dw, n4, n_splits, p.ws_stride);
+  vdqn_prof_end(stream);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
 }
 
 int launch_stem_wgrad(const WgradParams& p, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSwSmem);
-    attr_set = true;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&stem_wgrad_kernel), (size_t)kSwSmem);
   const int total_rows = p.n_img * 112;
   const int grid = total_rows < 512 ? total_rows : 512;
   const int rpb = (total_rows + grid - 1) / grid;
   vdqn_prof_begin("wgrad_stem<bf16>", 2.0 * p.M * 64 * 147, 2.0 * ((double)p.M * 64 + (double)p.n_img * 115 * 115 * 16) + 4.0 * 64 * 256, stream);
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3((total_rows + rpb - 1) / rpb), dim3(256), kSwSmem, stream, (const bf16raw*)p.gy, (const bf16raw*)p.x, p.dw, total_rows,
-                     rpb, p.gy_bytes, p.x_bytes);
+                     rpb, p.gy_bytes, p.x_bytes, p.ws);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
+  if (p.ws) return launch_wgrad_reduce(p, (total_rows + rpb - 1) / rpb, 64 * 256, stream);
   return VDQN_OK;
 }
 
@@ -737,11 +769,7 @@ int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t st
   const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * (KP + 8) + 1) * BCI * 2;
   const size_t smem_epi = (BCO == 64 && BCI == 64) ? (size_t)4 * 64 * 64 * 4 : (size_t)BCO * BCI * 4;
   const size_t smem = smem_stage > smem_epi ? smem_stage : smem_epi;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI>), (size_t)smem);
   vdqn_prof_begin(BCO == 128 ? "wgrad_win<bf16,128x64>" : "wgrad_win<bf16,64>", 2.0 * p.M * p.co * p.taps * p.ci,
                   2.0 * ((double)p.M * p.ldg + (double)p.n_img * p.hi * p.wi * p.ci) + 4.0 * p.co * p.taps * p.ci, stream);
   hipLaunchKernelGGL((wgrad_win_kernel<BCO, BCI>), dim3(tiles * splitk), dim3(256), smem, stream, p);
@@ -750,19 +778,91 @@ int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t st
   return VDQN_OK;
 }
 
-}  // namespace
+// Which kernel a call runs on and how its pixel range is split (shared by the launch and by the workspace-size query).
+struct WgradPlan {
+  int variant;      // 0 stem kernel, 1 window 64x64, 2 window 128x64, 3 generic
+  int bt, ci_tiles, tiles, splitk, kchunk;
+  int copies;       // partial copies of dw the deterministic mode stores (active splits, or blocks of the stem kernel)
+  long long copy_elems;  // floats per copy
+};
 
-extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
+int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
   VDQN_CHECK(a != nullptr, "vdqn_conv2d_wgrad: null args");
   VDQN_CHECK(a->dtype == VDQN_F32 || a->dtype == VDQN_BF16, "vdqn_conv2d_wgrad: bad dtype %d", a->dtype);
-  VDQN_CHECK(a->gy && a->x && a->dw, "vdqn_conv2d_wgrad: null tensor");
   VDQN_CHECK(a->ci % 64 == 0 && a->ldg % 64 == 0, "vdqn_conv2d_wgrad: ci=%d and ldg=%d must be multiples of 64", a->ci, a->ldg);
   VDQN_CHECK(a->stride == 1 || a->stride == 2, "vdqn_conv2d_wgrad: stride %d unsupported", a->stride);
   const int64_t M64 = (int64_t)a->n_img * a->ho * a->wo;
-  VDQN_CHECK(M64 > 0 && M64 < (1 << 24), "vdqn_conv2d_wgrad: %lld output pixels out of range (< 2^24)", (long long)M64);
+  VDQN_CHECK(M64 > 0 && M64 < (1 << 24), "vdqn_conv2d_wgrad: %lld output pixels out of range (< 2^24: split the batch)", (long long)M64);
   VDQN_CHECK(a->ho * a->wo < 65536, "vdqn_conv2d_wgrad: ho*wo too large");
   const int co_pad = (a->co + 63) / 64 * 64;
   VDQN_CHECK(a->ldg >= co_pad, "vdqn_conv2d_wgrad: gy rows (ldg=%d) must hold co padded to 64 (%d)", a->ldg, co_pad);
+  const int M = (int)M64, taps = a->r * a->s;
+  pl->copy_elems = (long long)co_pad * taps * a->ci;
+  const int bt = (co_pad % 128 == 0 && a->ci % 128 == 0) ? 128 : 64;
+  pl->bt = bt;
+  pl->ci_tiles = a->ci / bt;
+  pl->tiles = (co_pad / bt) * taps * pl->ci_tiles;
+  int splitk = a->splitk;
+  const int max_split = (M + 255) / 256;  // at least 8 K-steps per block
+  if (splitk <= 0) {
+    // 512 blocks = ONE round at 2 blocks per CU: measured 650 vs 555 TFLOP/s against two rounds of half-length blocks
+    // (half the f32 atomics, twice the K-steps per prologue/epilogue); fewer than 512 leaves CUs idle (384: 540)
+    static const int target = [] { const char* e = getenv("VDQN_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    splitk = target / pl->tiles;
+    if (splitk > max_split) splitk = max_split;
+    if (splitk < 1) splitk = 1;
+  }
+  pl->variant = 3;
+  static const int use_win = [] { const char* e = getenv("VDQN_WGRAD_WINDOW"); return e ? atoi(e) : 1; }();
+  static const int use_stem = [] { const char* e = getenv("VDQN_WGRAD_STEM"); return e ? atoi(e) : 1; }();
+  // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps.  64 x 64 window tiles win
+  // on the 64-channel layers (672 vs 420 TFLOP/s) and on the 128- and 256-channel layers (layer2 / layer3: 705 vs 645) as
+  // long as tiles x split fills one round of 512 blocks; layer4 (192 tiles -> 384 blocks) stays on the generic 128 x 128
+  // kernel (650 vs 605).  VDQN_WGRAD_WINDOW=2: 128(co) x 64(ci) window tiles for layer4 too, =3: 64 x 64 everywhere
+  const bool small_win = bt == 64 || (long long)co_pad * a->ci <= 256 * 256;
+  if (use_stem && a->dtype == VDQN_BF16 && a->r == 4 && a->s == 1 && a->ci == 64 && a->pix_stride == 16 && a->hi == 115 && a->wi == 115 && a->ho == 112 &&
+      a->wo == 112 && a->co == 64 && a->ldg == 64 && a->stride == 1 && a->pad == 0 && a->splitk <= 0) {
+    pl->variant = 0;
+    const int total_rows = a->n_img * 112;
+    const int grid = total_rows < 512 ? total_rows : 512;
+    const int rpb = (total_rows + grid - 1) / grid;
+    pl->copies = (total_rows + rpb - 1) / rpb;
+    pl->copy_elems = 64 * 256;
+    pl->splitk = 1;
+    pl->kchunk = M;
+    return VDQN_OK;
+  }
+  if (use_win && (small_win || use_win >= 2) && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 &&
+      a->pix_stride == a->ci && a->wo >= 2 && a->hi == a->ho && a->wi == a->wo) {
+    const int bco = (small_win || use_win >= 3) ? 64 : bt, bci = 64;
+    pl->variant = bco == 128 ? 2 : 1;
+    pl->ci_tiles = a->ci / bci;
+    pl->tiles = (co_pad / bco) * 3 * pl->ci_tiles;
+    splitk = a->splitk > 0 ? a->splitk : 512 / pl->tiles;
+    if (splitk > max_split) splitk = max_split;
+    if (splitk < 1) splitk = 1;
+  }
+  pl->splitk = splitk;
+  pl->kchunk = ((M + splitk - 1) / splitk + 127) / 128 * 128;  // multiple of every kernel variant's K-step
+  pl->copies = (M + pl->kchunk - 1) / pl->kchunk;              // splits with an empty pixel range store nothing
+  return VDQN_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t vdqn_conv2d_wgrad_workspace_bytes(const vdqn_wgrad_args* a) {
+  WgradPlan pl;
+  if (plan_wgrad(a, &pl) != VDQN_OK) return -1;
+  return (int64_t)pl.copies * pl.copy_elems * 4;
+}
+
+extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
+  WgradPlan pl;
+  const int prc = plan_wgrad(a, &pl);
+  if (prc != VDQN_OK) return prc;
+  VDQN_CHECK(a->gy && a->x && a->dw, "vdqn_conv2d_wgrad: null tensor");
+  const int64_t M64 = (int64_t)a->n_img * a->ho * a->wo;
+  const int co_pad = (a->co + 63) / 64 * 64;
   hipStream_t st = (hipStream_t)stream;
   WgradParams p;
   p.gy = a->gy; p.x = a->x; p.dw = a->dw;
@@ -773,60 +873,40 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   const long long gyb = M64 * a->ldg * (a->dtype == VDQN_BF16 ? 2 : 4);
   const long long xb = (long long)a->n_img * a->hi * a->wi * a->pix_stride * (a->dtype == VDQN_BF16 ? 2 : 4);
   VDQN_CHECK(gyb < 0x7fffffffLL && xb < 0x7fffffffLL, "vdqn_conv2d_wgrad: operand larger than 2 GiB (split the batch)");
-  VDQN_CHECK(((uintptr_t)a->gy & 15) == 0 && ((uintptr_t)a->x & 15) == 0, "vdqn_conv2d_wgrad: operands must be 16-byte aligned");
+  VDQN_CHECK(((uintptr_t)a->gy & 15) == 0 && ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->dw & 15) == 0, "vdqn_conv2d_wgrad: operands must be 16-byte aligned");
   p.gy_bytes = (int)gyb;
   p.x_bytes = (int)xb;
   p.d_howo = make_fastdiv((uint32_t)(a->ho * a->wo));
   p.d_wo = make_fastdiv((uint32_t)a->wo);
-  const int bt = (co_pad % 128 == 0 && a->ci % 128 == 0) ? 128 : 64;
-  p.ci_tiles = a->ci / bt;
-  const int tiles = (co_pad / bt) * p.taps * p.ci_tiles;
-  int splitk = a->splitk;
-  if (splitk <= 0) {
-    // 512 blocks = ONE round at 2 blocks per CU: measured 650 vs 555 TFLOP/s against two rounds of half-length blocks
-    // (half the f32 atomics, twice the K-steps per prologue/epilogue); fewer than 512 leaves CUs idle (384: 540)
-    static const int target = [] { const char* e = getenv("VDQN_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
-    splitk = target / tiles;
-    const int max_split = (p.M + 255) / 256;  // at least 8 K-steps per block
-    if (splitk > max_split) splitk = max_split;
-    if (splitk < 1) splitk = 1;
+  p.ci_tiles = pl.ci_tiles;
+  p.splitk = pl.splitk;
+  p.kchunk = pl.kchunk;
+  // deterministic mode: the caller's workspace takes one partial copy of dw per split, summed in split order afterwards
+  p.ws = nullptr;
+  p.ws_stride = pl.copy_elems;
+  if (a->workspace) {
+    VDQN_CHECK(a->workspace_bytes >= (int64_t)pl.copies * pl.copy_elems * 4, "vdqn_conv2d_wgrad: workspace of %lld bytes, %lld needed",
+               (long long)a->workspace_bytes, (long long)pl.copies * pl.copy_elems * 4);
+    VDQN_CHECK(((uintptr_t)a->workspace & 15) == 0, "vdqn_conv2d_wgrad: workspace must be 16-byte aligned");
+    p.ws = reinterpret_cast<float*>(a->workspace);
   }
-  p.splitk = splitk;
-  p.kchunk = ((p.M + splitk - 1) / splitk + 127) / 128 * 128;  // multiple of every kernel variant's K-step
   int rc;
-  static const int use_win = [] { const char* e = getenv("VDQN_WGRAD_WINDOW"); return e ? atoi(e) : 1; }();
-  // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps.  Default: the
-  // 64-channel layers only (64x64 tiles, 672 vs 420 TFLOP/s).  VDQN_WGRAD_WINDOW=2 also routes the wider layers to
-  // 128(co) x 64(ci) window tiles — measured 557-601 vs 625-650 TFLOP/s for the generic 128x128 kernel, so not the default
-  // 64 x 64 window tiles also win on the 128- and 256-channel layers (layer2 / layer3: 705 vs 645 TFLOP/s) as long as tiles x
-  // split fills one round of 512 blocks; layer4 (192 tiles -> 384 blocks) stays on the generic 128 x 128 kernel (650 vs 605)
-  const bool small_win = bt == 64 || (long long)co_pad * a->ci <= 256 * 256;
-  static const int use_stem = [] { const char* e = getenv("VDQN_WGRAD_STEM"); return e ? atoi(e) : 1; }();
-  if (use_stem && a->dtype == VDQN_BF16 && a->r == 4 && a->s == 1 && a->ci == 64 && a->pix_stride == 16 && a->hi == 115 && a->wi == 115 && a->ho == 112 &&
-      a->wo == 112 && a->co == 64 && a->ldg == 64 && a->stride == 1 && a->pad == 0 && a->splitk <= 0) {
-    rc = launch_stem_wgrad(p, st);
-  } else
-  if (use_win && (small_win || use_win >= 2) && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 &&
-      a->pix_stride == a->ci && a->wo >= 2 && a->hi == a->ho && a->wi == a->wo) {
-    const int bco = (small_win || use_win >= 3) ? 64 : bt, bci = 64;  // VDQN_WGRAD_WINDOW=2: 128 x 64 tiles for layer4, =3: 64 x 64 everywhere
-    p.ci_tiles = a->ci / bci;
-    const int wtiles = (co_pad / bco) * 3 * p.ci_tiles;
-    int wsplit = a->splitk > 0 ? a->splitk : 512 / wtiles;
-    const int max_split = (p.M + 255) / 256;
-    if (wsplit > max_split) wsplit = max_split;
-    if (wsplit < 1) wsplit = 1;
-    p.splitk = wsplit;
-    p.kchunk = ((p.M + wsplit - 1) / wsplit + 127) / 128 * 128;
-    rc = bco == 128 ? launch_wgrad_win<128, 64>(p, wtiles, wsplit, st) : launch_wgrad_win<64, 64>(p, wtiles, wsplit, st);
-  } else
-  if (a->dtype == VDQN_BF16) rc = bt == 128 ? launch_wgrad<bf16raw, 128>(p, tiles, splitk, st) : launch_wgrad<bf16raw, 64>(p, tiles, splitk, st);
-  else rc = bt == 128 ? launch_wgrad<float, 128>(p, tiles, splitk, st) : launch_wgrad<float, 64>(p, tiles, splitk, st);
+  if (pl.variant == 0) rc = launch_stem_wgrad(p, st);
+  else if (pl.variant == 2) rc = launch_wgrad_win<128, 64>(p, pl.tiles, pl.splitk, st);
+  else if (pl.variant == 1) rc = launch_wgrad_win<64, 64>(p, pl.tiles, pl.splitk, st);
+  else if (a->dtype == VDQN_BF16) rc = pl.bt == 128 ? launch_wgrad<bf16raw, 128>(p, pl.tiles, pl.splitk, st) : launch_wgrad<bf16raw, 64>(p, pl.tiles, pl.splitk, st);
+  else rc = pl.bt == 128 ? launch_wgrad<float, 128>(p, pl.tiles, pl.splitk, st) : launch_wgrad<float, 64>(p, pl.tiles, pl.splitk, st);
   if (rc != VDQN_OK) return rc;
+  if (p.ws && pl.variant != 0) {
+    rc = launch_wgrad_reduce(p, pl.copies, pl.copy_elems, st);
+    if (rc != VDQN_OK) return rc;
+  }
   if (a->dbias) {
     const int e16 = a->dtype == VDQN_BF16 ? 8 : 4;
     VDQN_CHECK(co_pad / e16 <= 256, "vdqn_conv2d_wgrad: dbias path supports up to %d channels", 256 * e16);
     int blocks = (p.M + 511) / 512;
     if (blocks > 256) blocks = 256;
+    if (a->workspace) blocks = 1;  // deterministic mode: one block sums every row (its atomics then never race)
     const int rpb = (p.M + blocks - 1) / blocks;
     vdqn_prof_begin("colsum", 0.0, (double)p.M * co_pad * (a->dtype == VDQN_BF16 ? 2 : 4), st);
     if (a->dtype == VDQN_BF16)

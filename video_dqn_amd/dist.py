@@ -19,14 +19,19 @@ import torch.distributed as dist
 
 
 class BucketAllReduce:
-    def __init__(self, world_size: int, group=None):
+    def __init__(self, world_size: int, group=None, force: bool = False):
         self.world_size = world_size
         self.group = group
+        self.force = force  # issue the collectives even at world size 1 (exercises RCCL + the stream ordering on one GPU)
         self._works: List = []
+        self.bucket_bytes: List[int] = []  # sizes of the buckets reduced in the last update, in launch order
 
     def launch(self, grad_slice: torch.Tensor, stage: int) -> None:
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force:
             return
+        if stage == 0:
+            self.bucket_bytes = []
+        self.bucket_bytes.append(grad_slice.numel() * grad_slice.element_size())
         self._works.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> None:
@@ -41,3 +46,20 @@ def shard_indices(n_items: int, rank: int, world_size: int, batch_per_rank: int,
     mine = epoch_perm[rank::world_size]
     per_rank = (n_items // world_size // batch_per_rank) * batch_per_rank
     return list(mine[:per_rank])
+
+
+def broadcast_replica_state(tensors, src: int = 0, group=None) -> None:
+    """Make every rank's copy of the given tensors (master parameters, BatchNorm statistics, Adam moments) equal to
+    rank `src`'s.  Seeding every rank alike already gives equal initial weights; the broadcast makes that a guarantee
+    (and covers a resume where only rank 0 found the checkpoint readable)."""
+    for t in tensors:
+        dist.broadcast(t, src=src, group=group)
+
+
+def agree_all(flag: bool, device=None, group=None) -> bool:
+    """True only if `flag` is true on EVERY rank (MIN all-reduce): per-rank decisions that must match across the job —
+    e.g. whether the decoded frames fit in this rank's HBM — are taken through this, so no two ranks pick different
+    data paths."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item())

@@ -9,6 +9,7 @@ Mirrors the pieces of ``train_q_network.py`` that touch the device:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, Optional
@@ -16,6 +17,8 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib
+
+LOSS_KINDS = {"l2": 0, "huber": 1}  # vdqn_td_args.loss_kind
 
 DTYPES = {"f32": _lib.VDQN_F32, "fp32": _lib.VDQN_F32, "float32": _lib.VDQN_F32,
           "bf16": _lib.VDQN_BF16, "bfloat16": _lib.VDQN_BF16}
@@ -50,7 +53,7 @@ class NetEngine:
     """One HabitatDQNMultiAction instance on the device: flat f32 master parameters + BN statistics."""
 
     def __init__(self, action_dim=3, num_classes=5, num_frames=1, extra_capacity=True, dtype="bf16",
-                 max_batch=512, device=None):
+                 max_batch=512, device=None, deterministic=None):
         self.lib = _lib.load()
         # device="cpu" gives a storage-only instance (state_dict / checkpoint plumbing); every compute entry
         # point still requires the GPU and raises otherwise — there is no CPU arithmetic in this package.
@@ -59,7 +62,13 @@ class NetEngine:
         self.extra_capacity = bool(extra_capacity)
         self.action_dim, self.num_classes, self.num_frames = action_dim, num_classes, num_frames
         self.dtype_name = "bf16" if DTYPES[dtype] == _lib.VDQN_BF16 else "f32"
-        self.cfg = _lib.NetConfig(action_dim, num_classes, num_frames, int(self.extra_capacity), DTYPES[dtype], max_batch)
+        # run-to-run bit-identical updates (the reference pins cudnn.deterministic, train_q_network.py:88-89): config key
+        # DETERMINISTIC / this argument, or VDQN_DETERMINISTIC=1 in the environment
+        if deterministic is None:
+            deterministic = os.environ.get("VDQN_DETERMINISTIC", "0") == "1"
+        self.deterministic = bool(deterministic)
+        self.cfg = _lib.NetConfig(action_dim, num_classes, num_frames, int(self.extra_capacity), DTYPES[dtype], max_batch,
+                                  int(self.deterministic))
         h = C.c_void_p()
         _lib.check(self.lib.vdqn_net_create(C.byref(self.cfg), C.byref(h)), "vdqn_net_create")
         self.handle = h
@@ -224,7 +233,7 @@ class TDStepper:
     def __init__(self, net: NetEngine, batch: int, lr: float, gamma: float, clip_rect: bool, linear: bool = False,
                  remove_before_reward: bool = False, train_on_ground_truth: bool = False, value_learning: bool = False,
                  target_update_interval: int = 8000, betas=(0.9, 0.999), eps: float = 1e-8, world_size: int = 1,
-                 allreduce=None):
+                 allreduce=None, loss_kind: str = "l2"):
         net._need_gpu()
         self.net, self.B = net, batch
         self.lib = net.lib
@@ -233,6 +242,9 @@ class TDStepper:
         self.lr, self.gamma, self.betas, self.eps = lr, gamma, betas, eps
         self.clip_rect, self.linear, self.rbr = clip_rect, linear, remove_before_reward
         self.gtb, self.value_learning = train_on_ground_truth, value_learning
+        if loss_kind not in LOSS_KINDS:
+            raise _lib.VdqnError(f"loss_kind must be one of {sorted(LOSS_KINDS)} (reference: 'l2', train_q_network.py:167)")
+        self.loss_kind = loss_kind
         self.tui = target_update_interval
         self.world_size = world_size
         self.allreduce = allreduce  # callable(tensor_slice, stage) or None
@@ -275,6 +287,7 @@ class TDStepper:
         a.train_on_ground_truth, a.value_learning = int(self.gtb), int(self.value_learning)
         a.acts_online, a.acts_target, a.bwd = _ptr(self.acts_online), _ptr(self.acts_target), _ptr(self.bwd)
         a.grads, a.loss, a.q_before = _ptr(self.grads), _ptr(self.loss), _ptr(self.q_before)
+        a.loss_kind = LOSS_KINDS[self.loss_kind]
         return a
 
     def forward_backward(self, before, after, src_kind, act, rew, term, valid=None, gt=None):

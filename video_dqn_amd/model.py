@@ -76,7 +76,7 @@ def _init_like_reference(engine: NetEngine, seed=None):
 
 class HabitatDQNMultiAction(nn.Module):
     def __init__(self, action_dim, num_classes=5, extra_capacity=False, panorama=True, num_frames=None,
-                 dtype=None, device=None, max_batch=64):
+                 dtype=None, device=None, max_batch=64, pretrained_weights=None, deterministic=None):
         super().__init__()
         self.extra_capacity = extra_capacity
         self.num_classes = num_classes
@@ -88,16 +88,25 @@ class HabitatDQNMultiAction(nn.Module):
         dtype = dtype or os.environ.get("VDQN_DTYPE", "bf16")
         if extra_capacity:
             print("Model loading with extra_capacity")  # :28
-        self.engine = NetEngine(action_dim, num_classes, num_frames, extra_capacity, dtype, max_batch, device)
+        self.engine = NetEngine(action_dim, num_classes, num_frames, extra_capacity, dtype, max_batch, device, deterministic)
         self._build_tree()
         _init_like_reference(self.engine)
-        pre = os.environ.get("VDQN_RESNET18_WEIGHTS")  # torchvision resnet18 state_dict (pretrained=True analogue, :11)
+        # models.resnet18(pretrained=True) (:11): the ImageNet weights come from a file (config key PRETRAINED_WEIGHTS, or the
+        # VDQN_RESNET18_WEIGHTS environment variable) — without one the trunk keeps its random initialisation, and
+        # `pretrained_loaded` stays False so the trainer can say so
+        pre = pretrained_weights or os.environ.get("VDQN_RESNET18_WEIGHTS")
+        self.pretrained_loaded = False
         if pre:
             sd = torch.load(pre, map_location="cpu")
+            hit = 0
             with torch.no_grad():
                 for k, v in sd.items():
                     if "resnet." + k in self.engine.slots:
                         self.engine.view("resnet." + k).copy_(v)
+                        hit += 1
+            if hit == 0:
+                raise ValueError(f"{pre}: no tensor of a torchvision resnet18 state_dict found (expected keys like 'conv1.weight')")
+            self.pretrained_loaded = True
             self.engine.mark_dirty()
 
     # ---- structure ----------------------------------------------------------------------------------
@@ -211,7 +220,9 @@ def build_model(config, max_batch=None):
     return HabitatDQNMultiAction(actions, 5, extra_capacity=(config.ARCHITECTURE == "extra_capacity"),
                                  panorama=(config.PANORAMA or config.PREVIOUS_IMAGES), num_frames=nf,
                                  dtype=getattr(config, "COMPUTE_DTYPE", None), device=config.device,
-                                 max_batch=max_batch or max(64, 2 * getattr(config, "BATCH_SIZE", 16)))
+                                 max_batch=max_batch or max(64, 2 * getattr(config, "BATCH_SIZE", 16)),
+                                 pretrained_weights=(getattr(config, "PRETRAINED_WEIGHTS", "") or None),
+                                 deterministic=(True if getattr(config, "DETERMINISTIC", False) else None))
 
 
 def load_model_number(config, number, model_loc=None):

@@ -54,8 +54,10 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
 
 
 def conv2d_wgrad(gy: torch.Tensor, x: torch.Tensor, *, co: int, r: int, s: int, stride: int, pad: int,
-                 ci: Optional[int] = None, pix_stride: Optional[int] = None, splitk: int = 0, want_dbias: bool = True):
-    """gy: [n, ho, wo, ldg]; x: [n, hi, wi, c].  Returns dw f32 [co_pad, r, s, ci] (and dbias [co_pad])."""
+                 ci: Optional[int] = None, pix_stride: Optional[int] = None, splitk: int = 0, want_dbias: bool = True,
+                 deterministic: bool = False):
+    """gy: [n, ho, wo, ldg]; x: [n, hi, wi, c].  Returns dw f32 [co_pad, r, s, ci] (and dbias [co_pad]).
+    deterministic: the two-stage ordered reduction (a workspace of vdqn_conv2d_wgrad_workspace_bytes) instead of atomics."""
     lib = _lib.load()
     n, ho, wo, ldg = gy.shape
     _, hi, wi, cx = x.shape
@@ -70,6 +72,13 @@ def conv2d_wgrad(gy: torch.Tensor, x: torch.Tensor, *, co: int, r: int, s: int, 
     a.ho, a.wo, a.co, a.ldg = ho, wo, co, ldg
     a.r, a.s, a.stride, a.pad = r, s, stride, pad
     a.splitk, a.dtype = splitk, dtype_code(x)
+    ws = None
+    if deterministic:
+        nbytes = lib.vdqn_conv2d_wgrad_workspace_bytes(C.byref(a))
+        if nbytes < 0:
+            _lib.check(-1, "vdqn_conv2d_wgrad_workspace_bytes")
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        a.workspace, a.workspace_bytes = _ptr(ws), nbytes
     _lib.check(lib.vdqn_conv2d_wgrad(C.byref(a), _stream()), "vdqn_conv2d_wgrad")
     return (dw, db) if want_dbias else dw
 
@@ -99,8 +108,11 @@ def maxpool_bwd(gy: torch.Tensor, idx: torch.Tensor, x: torch.Tensor) -> torch.T
     return gx
 
 
+LOSS_KINDS = {"l2": 0, "huber": 1}  # vdqn_td_args.loss_kind
+
+
 def td_loss(q_before, q_after_online, q_after_target, act, rew, term, valid=None, *, n_cat=5, n_act=3, gamma=0.99,
-            inv_count=None, clip_rect=True, linear=False, out_dtype=torch.float32):
+            inv_count=None, clip_rect=True, linear=False, out_dtype=torch.float32, loss_kind="l2"):
     """q_*: f32 [B, ldq] (ldq >= n_cat*n_act).  Returns (loss[1], dq[B, ldq] out_dtype, dq_f32)."""
     lib = _lib.load()
     B, ldq = q_before.shape
@@ -116,6 +128,7 @@ def td_loss(q_before, q_after_online, q_after_target, act, rew, term, valid=None
     a.gamma = gamma
     a.inv_count = (1.0 / (B * n_cat)) if inv_count is None else inv_count
     a.clip_rect, a.linear, a.use_valid, a.dtype = int(clip_rect), int(linear), int(valid is not None), dtype_code(dq)
+    a.loss_kind = LOSS_KINDS[loss_kind]
     _lib.check(lib.vdqn_td_loss(C.byref(a), _stream()), "vdqn_td_loss")
     return loss, dq, dq32
 

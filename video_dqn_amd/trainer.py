@@ -18,7 +18,7 @@ import torch
 from torch.utils import data
 
 from .dataset import QLearningRealDataset, SyntheticTupleDataset
-from .dist import BucketAllReduce
+from .dist import BucketAllReduce, agree_all, broadcast_replica_state
 from .engine import TDStepper
 from .model import build_model
 from .shards import ShardDataset, is_shard_dir
@@ -155,6 +155,8 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                 n_frames = sum(np.load(p_, mmap_mode="r").shape[0] for p_ in dataset._paths)
                 free, _ = torch.cuda.mem_get_info(torch.device(config.device))
                 resident = n_frames * 224 * 224 * 3 + (32 << 30) < free
+                if world_size > 1:  # one decision for the whole job: a rank on the loader path would draw from a different
+                    resident = agree_all(resident, device=config.device)  # sharding of the epoch than the resident ones
             if resident:
                 from .shards import DeviceFrameStore
                 store = DeviceFrameStore(config.DATASET, config.device, **kw)
@@ -183,7 +185,7 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                         remove_before_reward=config.REMOVE_BEFORE_REWARD,
                         train_on_ground_truth=config.TRAIN_ON_GROUND_TRUTH, value_learning=config.VALUE_LEARNING,
                         target_update_interval=config.TARGET_UPDATE_INTERVAL, world_size=world_size,
-                        allreduce=(comm.launch if comm else None))
+                        allreduce=(comm.launch if comm else None), loss_kind=getattr(config, "LOSS_KIND", "l2"))
     if world_size > 1 and config.ARCHITECTURE != "extra_capacity" and getattr(config, "SYNC_BN", True):
         model.engine.set_bn_sync(world_size)  # train-mode BatchNorm over the global batch, as the single-GPU reference sees it
     if store is not None:  # minibatches are gathered on the device; no loader, no host copies
@@ -198,6 +200,24 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
         log(f"Loading model from: {model_loc}")
         model.load_state_dict(snapshot["model_state_dict"])
         load_optimizer_state_dict(stepper, snapshot["optimizer_state_dict"])
+    if config.BOOTSTRAP:  # :200-206 — start from a network trained on ground truth (model AND optimiser state)
+        log("\n\nBOOTSTRAP\n\n")
+        model_loc = getattr(config, "BOOTSTRAP_CHECKPOINT", "") or "logs/trained_gt_0.99/models/epoch99.torch"  # :202
+        snapshot = torch.load(model_loc, map_location=config.device)  # a missing file raises, as in the reference
+        log(f"Loading model from: {model_loc}")
+        model.load_state_dict(snapshot["model_state_dict"])
+        load_optimizer_state_dict(stepper, snapshot["optimizer_state_dict"])
+    if resume_from < 0 and not config.BOOTSTRAP and not getattr(model, "pretrained_loaded", False) and rank == 0:
+        log("WARNING: the ResNet-18 trunk starts from a RANDOM initialisation — the reference builds "
+            "models.resnet18(pretrained=True) (archs/HabitatDQNMultiAction.py:11); set PRETRAINED_WEIGHTS in config.yml "
+            "(a torchvision resnet18 state_dict file) to train on ImageNet features as the reference does")
+    if world_size > 1:  # replicas must start identical: rank 0's parameters, statistics and optimiser state everywhere
+        eng = model.engine
+        broadcast_replica_state([eng.params, eng.bnstats, eng.num_batches_tracked, stepper.exp_avg, stepper.exp_avg_sq])
+        steps = torch.tensor([stepper.adam_step], dtype=torch.int64, device=eng.device)
+        torch.distributed.broadcast(steps, src=0)
+        stepper.adam_step = int(steps.item())
+        eng.mark_dirty()
     stepper.sync_target()  # :208
     stepper.sample_number = sample_number
 
@@ -222,8 +242,16 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                             valid if config.REMOVE_BEFORE_REWARD else None,
                             gt if config.TRAIN_ON_GROUND_TRUTH else None,
                             finish_allreduce=(comm.finish if comm else None))
-        if world_size > 1:
-            torch.distributed.all_reduce(loss)  # per-rank partial sums of the global mean
+        # every rank's `loss` is its share of the global mean (the TD kernel divides by the global batch).  The sum over
+        # ranks is only needed where the reference reports the loss — the tensorboard scalar every 100 updates (:236-238)
+        # and the checkpoint step — so the collective runs at that cadence, not per update; in between rank 0's progress
+        # line shows its own share scaled by the world size (an unbiased estimate of the global mean)
+        report = world_size > 1 and (sample_number % 100 == 0 or sample_number % config.CHECKPOINT_INTERVAL == 0 or sample_number == num_steps)
+        if report:
+            loss = loss.clone()
+            torch.distributed.all_reduce(loss)
+        elif world_size > 1:
+            loss = loss * float(world_size)
         slot = sample_number & 1
         host_loss[slot:slot + 1].copy_(loss, non_blocking=True)
         ev = torch.cuda.Event()
