@@ -171,10 +171,12 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
         feats = _oracle_relu_outputs(m0, tup[0])
         flips = _count_relu_flips(net, out[0]["acts"], 2 * B, B, feats)
         total = sum(int(v.numel()) for v in feats.values())
-        print(f"ReLU sign disagreements: {flips} of {total}")
         assert flips <= 1e-5 * total
         if flips > 0:
             tol_l2, tol_max = 3e-3, 1.5e-2
+        import warnings  # the warnings summary is what a `pytest -q` log keeps: record which gate this run took
+        warnings.warn(f"f32 parity gate: {flips} ReLU sign disagreements of {total} -> gradient gate L2 <= {tol_l2:g}, max <= {tol_max:g} "
+                      f"({'strict north_star 1e-3' if flips == 0 else 'relaxed branch'})")
     all_g, all_ref = [], []
     for name, p in tr.model.named_parameters():
         if p.grad is None:

@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 from video_dqn_amd import synth  # noqa: E402
 
 DEV = "cuda"
-TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}  # bf16: results STORED as bf16 (one rounding of the output, 2^-8 relative)
+# f32 results of the bf16 kernels (want_f32 outputs, weight gradients): the operands are the same bf16 values the reference
+# sees and every kernel accumulates in f32, so only the summation order differs
+TOL_F32OUT = {torch.float32: 1e-3, torch.bfloat16: 2e-4}
 
 
 def rnd(seed, name, shape, lo=-1.0, hi=1.0):
@@ -84,7 +87,7 @@ def test_conv_forward(case, dtype):
     # no-epilogue variant + f32 copy
     ref2 = F.conv2d(x, w, None, stride, pad)
     out2, out2f = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=ho, wo=ho, co=co, r=k, s=k, stride=stride, pad=pad, want_f32=True)
-    assert relerr(out2f.cpu().permute(0, 3, 1, 2), ref2) < (1e-3 if dtype == torch.float32 else 5e-3)
+    assert relerr(out2f.cpu().permute(0, 3, 1, 2), ref2) < TOL_F32OUT[dtype]
     assert relerr(out2.float().cpu().permute(0, 3, 1, 2), ref2) < TOL[dtype]
 
 
@@ -108,6 +111,11 @@ def test_conv_dgrad(case, dtype):
     assert relerr(got.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
     # per-tile column sums of the stored values (feeds the bias / BatchNorm-shift gradients)
     assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
+    # the f32 copy of the plain data gradient (no residual, no mask): summation order only
+    ref0 = F.grad.conv2d_input((n, ci, h, h), w, gy, stride, pad)
+    _, got0 = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=h, co=ci, r=k, s=k, stride=stride, pad=pad, mode=1, want_f32=True)
+    torch.cuda.synchronize()
+    assert relerr(got0.cpu().permute(0, 3, 1, 2), ref0) < TOL_F32OUT[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -123,8 +131,8 @@ def test_conv_wgrad(case, dtype, splitk):
     dw, db = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), co=co, r=k, s=k, stride=stride, pad=pad, splitk=splitk)
     torch.cuda.synchronize()
     got = dw.cpu()[:co].permute(0, 3, 1, 2)
-    assert relerr(got, ref) < (1e-3 if dtype == torch.float32 else 5e-3)
-    assert relerr(db.cpu()[:co], gy.sum((0, 2, 3))) < 1e-3
+    assert relerr(got, ref) < TOL_F32OUT[dtype]
+    assert relerr(db.cpu()[:co], gy.sum((0, 2, 3))) < TOL_F32OUT[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -142,7 +150,7 @@ def test_linear_fwd_bwd(dtype):
     out, outf = ops.conv2d(xd, wp.view(64, 1, 1, fin).to(dtype).to(DEV), ho=1, wo=1, co=64, r=1, s=1, stride=1, pad=0,
                            bias=bp.to(DEV), want_f32=True)
     torch.cuda.synchronize()
-    assert relerr(outf.cpu().view(B, 64)[:, :fout], ref) < (1e-3 if dtype == torch.float32 else 5e-3)
+    assert relerr(outf.cpu().view(B, 64)[:, :fout], ref) < TOL_F32OUT[dtype]
     assert outf.cpu().view(B, 64)[:, fout:].abs().max().item() == 0.0
     # dgrad: gx = gy @ W   (gy padded to 64 columns)
     gy = q(rnd(5, "gy", (B, fout)), dtype)
@@ -153,7 +161,7 @@ def test_linear_fwd_bwd(dtype):
     dw, db = ops.conv2d_wgrad(gyp.view(B, 1, 1, 64).to(dtype).to(DEV), xd, co=fout, r=1, s=1, stride=1, pad=0)
     torch.cuda.synchronize()
     assert relerr(gx.float().cpu().view(B, fin), gy @ w) < TOL[dtype]
-    assert relerr(dw.cpu().view(64, fin)[:fout], gy.t() @ x) < (1e-3 if dtype == torch.float32 else 5e-3)
+    assert relerr(dw.cpu().view(64, fin)[:fout], gy.t() @ x) < TOL_F32OUT[dtype]
     assert relerr(db.cpu()[:fout], gy.sum(0)) < 1e-3
 
 
@@ -223,7 +231,7 @@ def test_stem_pack_conv1_maxpool(dtype, src_kind):
                     r7, s7 = 2 * a + bh - 1, 2 * j + bw - 1
                     if r7 >= 0 and s7 >= 0:
                         got[:, :, r7, s7] = dws[:, a, j, (bh * 2 + bw) * 3:(bh * 2 + bw) * 3 + 3]
-    assert relerr(got, wref) < (1e-3 if dtype == torch.float32 else 5e-3)
+    assert relerr(got, wref) < TOL_F32OUT[dtype]
 
 
 def test_td_loss_branches_vs_golden(golden):

@@ -46,12 +46,11 @@ def main(n=512):
         print(f"{name}: {grid} workgroups x {nk:.0f} K-steps, launch {us:.1f} us = {flops / us / 1e6:.0f} TFLOP/s (stamped build), "
               f"first-begin..last-end {span:.0f} cycles = {span / us / 1e3:.2f} GHz if one clock domain")
         print(f"   per workgroup (cycles): total {total.mean():.0f}  prologue+loop {loop.mean():.0f}  epilogue {epi.mean():.0f}")
-        for lbl, col in (("wait", 3), ("barrier", 4), ("issue", 5), ("compute", 6)):
-            print(f"   per K-step {lbl:8s} {b[:, col].mean().item() / nk:8.1f}   (min over workgroups {b[:, col].min().item() / nk:7.1f}, max {b[:, col].max().item() / nk:7.1f})")
+        cols = (("wait", 3), ("barrier", 4), ("issue", 5), ("compute", 6))
+        for lbl, col in cols:
+            print(f"   per K-step {lbl:12s} {b[:, col].mean().item() / nk:8.1f}   (min over workgroups {b[:, col].min().item() / nk:7.1f}, max {b[:, col].max().item() / nk:7.1f})")
         ghz = ((b[:, 2] - b[:, 0]) / ((b[:, 9] - b[:, 8]).clamp_min(1.0) * 10.0))  # cycles per ns: realtime ticks are 10 ns
-        slots = torch.bincount((buf[:, 10].cpu() & 15).long(), minlength=4)[:4].tolist()
-        print(f"   in-kernel shader clock (s_memtime / s_memrealtime): median {ghz.median().item():.3f} GHz, min {ghz.min().item():.3f}, max {ghz.max().item():.3f};"
-              f" wave slots of wave 0 (HW_ID.wave_id) {slots}")
+        print(f"   in-kernel shader clock (s_memtime / s_memrealtime): median {ghz.median().item():.3f} GHz, min {ghz.min().item():.3f}, max {ghz.max().item():.3f}")
         start = b[:, 0] - b[:, 0].min()
         order = torch.argsort(start)
         q = [start[order[int(f * (grid - 1))]].item() for f in (0.0, 0.25, 0.5, 0.75, 1.0)]

@@ -1,0 +1,194 @@
+// Shared pieces of the implicit-GEMM kernels (igemm.hip, win9.hip): launch parameters, the LDS-free epilogue, the
+// MFMA / VALU / LDS interleave pattern.  Included inside each file's anonymous namespace user — everything here is
+// `static`/template/inline device code.
+#pragma once
+#include "common.h"
+
+namespace {
+
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct IgemmParams {
+  const void* in;
+  const void* wt;
+  const float* bias;
+  const void* resid;
+  const void* mask;
+  void* out;
+  float* out_f32;
+  float* colsum_part;
+  void* pool_out;      // MODE 3 (stem): max-pooled output [n][56][56][64] and its argmax codes
+  uint8_t* pool_idx;
+  int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldo, r, s, stride, pad, relu;
+  int M, howo, ktot, nk, tiles_m, tiles_n;
+  int cls_tile0[5], cls_h[2], cls_w[2];  // MODE 2: first tile of each output-parity class; class heights / widths
+  long long in_bytes;
+  int wt_bytes;
+  int vec_ok;
+};
+
+constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (num_records <= 0x7fffffff)
+
+// ---- epilogue, straight from the accumulators (shared by the generic and the window kernel): lane (i16, g) owns channels
+// [ncol, ncol + CPL) of pixels f*16 + i16 of its wave's 64 rows ----
+template <typename T, int BM, int BN, int MODE, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[4][BN / (16 * WN)], unsigned char* smem, int m0, int n0, int tile_m,
+                                               int rows_total, int pix_per_img, int row_w, int cls_ph, int cls_pw, int tid_override = -1) {
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int NF = BN / (16 * WN);
+  constexpr int CPL = 4 * NF;
+  // tid_override: kernels whose workgroup holds two independent 4-wave groups pass the thread's index inside its group
+  // (smem is then that group's LDS region; the barriers below are workgroup-wide, which both groups reach equally often)
+  const int tid = tid_override >= 0 ? tid_override : (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int i16 = lane & 15, g = lane >> 4;
+  T* __restrict__ out = (T*)p.out;
+  const T* __restrict__ resid = (const T*)p.resid;
+  const T* __restrict__ mask = (const T*)p.mask;
+  constexpr int V16 = CPL * ESZ / 16;  // 16-byte vectors per lane and pixel
+  const int ncol = n0 + wc * (BN / WN) + g * CPL;
+  float cs[CPL];  // per-lane column sums of the values this tile stores (for the BN-shift / bias gradient)
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) cs[e] = 0.f;
+  if (ncol < p.co) {
+    const bool vec = p.vec_ok && (ncol + CPL <= p.co);
+    float bv[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) bv[e] = (p.bias && ncol + e < p.co) ? p.bias[ncol + e] : 0.f;
+    size_t o[4];
+    bool okr[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      int m = m0 + wr * 64 + f * 16 + i16;
+      okr[f] = m < rows_total;
+      if constexpr (MODE == 2) {  // class-local row -> output pixel
+        const int mm = okr[f] ? m : m0;
+        const int img = mm / pix_per_img;
+        const int rem = mm - img * pix_per_img;
+        const int ohc = rem / row_w;
+        m = (img * p.ho + 2 * ohc + cls_ph) * p.wo + 2 * (rem - ohc * row_w) + cls_pw;
+      }
+      o[f] = (size_t)m * p.ldo + ncol;
+    }
+    if (vec) {
+      uint4 rv[4][V16], mv[4][V16];
+      if (resid) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int q = 0; q < V16; ++q) rv[f][q] = okr[f] ? reinterpret_cast<const uint4*>(resid + o[f])[q] : make_uint4(0, 0, 0, 0);
+      }
+      if (mask) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int q = 0; q < V16; ++q) mv[f][q] = okr[f] ? reinterpret_cast<const uint4*>(mask + o[f])[q] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        float v[CPL];
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + bv[j * 4 + r];
+        if (resid) {
+          const T* pr = reinterpret_cast<const T*>(rv[f]);
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] += to_f32<T>(pr[e]);
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (mask) {
+          const T* pm = reinterpret_cast<const T*>(mv[f]);
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] = (to_f32<T>(pm[e]) > 0.f) ? v[e] : 0.f;
+        }
+        if (okr[f]) {
+          if (out) {
+            T ov[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+              ov[e] = from_f32<T>(v[e]);
+              cs[e] += to_f32<T>(ov[e]);
+            }
+#pragma unroll
+            for (int q = 0; q < V16; ++q) reinterpret_cast<uint4*>(out + o[f])[q] = reinterpret_cast<const uint4*>(ov)[q];
+          }
+          if (p.out_f32) {
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q)
+              *reinterpret_cast<float4*>(p.out_f32 + o[f] + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        if (!okr[f]) continue;
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = j * 4 + r;
+            if (ncol + e >= p.co) continue;
+            float x = acc[f][j][r] + bv[e];
+            if (resid) x += to_f32<T>(resid[o[f] + e]);
+            if (p.relu) x = fmaxf(x, 0.f);
+            if (mask) x = (to_f32<T>(mask[o[f] + e]) > 0.f) ? x : 0.f;
+            if (out) {
+              out[o[f] + e] = from_f32<T>(x);
+              cs[e] += to_f32<T>(from_f32<T>(x));
+            }
+            if (p.out_f32) p.out_f32[o[f] + e] = x;
+          }
+      }
+    }
+  }
+  if (p.colsum_part) {  // uniform branch: partial column sums of this tile -> colsum_part[tile_m][ldo]
+    // sum the 16 pixel-lanes of every channel group, then the BM/64 wave rows through LDS
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+      float t = cs[e];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      t += __shfl_xor(t, 8, 64);
+      cs[e] = t;
+    }
+    __syncthreads();  // every wave is past its last fragment read: LDS can be reused
+    float* sR = reinterpret_cast<float*>(smem);
+    if (i16 == 0) {
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) sR[wr * BN + wc * (BN / WN) + g * CPL + e] = cs[e];
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.co) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < BM / 64; ++r) t += sR[r * BN + tid];
+      if constexpr (BM == 256) {  // consumers sum ceil(M/128) entries: this tile covers two of them
+        p.colsum_part[(size_t)(2 * tile_m) * p.ldo + n0 + tid] = t;
+        if ((2 * tile_m + 1) * 128 < p.M) p.colsum_part[(size_t)(2 * tile_m + 1) * p.ldo + n0 + tid] = 0.f;
+      } else {
+        p.colsum_part[(size_t)tile_m * p.ldo + n0 + tid] = t;
+      }
+    }
+  }
+}
+
+
+#define VDQN_INTERLEAVE(N)                                  \
+  if constexpr (sizeof(T) == 2) {                           \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N); ++g_) {    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);    \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+    }                                                       \
+  }
+
+}  // namespace
