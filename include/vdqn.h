@@ -81,6 +81,19 @@ typedef struct vdqn_conv_args {
   int32_t ho, wo, co, ldo;
   int32_t r, s, stride, pad;
   int32_t mode, relu, dtype;
+  /* Optional sibling 1x1 / stride-2 / pad-0 convolution fused into a 3x3 / stride-2 / pad-1 call: the downsample branch of a
+   * ResNet BasicBlock (torchvision resnet.py `downsample`; archs/HabitatDQNMultiAction.py:30), whose input pixel is the 3x3's
+   * centre tap.  All NULL / 0 = no sibling.
+   *   mode 0: out2[m, :co2] = relu2?( sum_c in[pix(m, centre), c] * wt2[n][c] + bias2[n] ), wt2 = [co2_pad][1][1][ci];
+   *           one launch, the input rows are fetched once for both convolutions.
+   *   mode 1: out += dgrad_1x1_stride2(in2, wt2) before the epilogue (residual / mask / column sums then see the sum):
+   *           in2 = gradient of the sibling's output, [n_img][hi][wi] pixels of pix_stride elems holding ci2 channels,
+   *           wt2 = [co_pad][1][1][ci2] (the sibling's data-gradient operand); bias2 / out2 / relu2 unused. */
+  const void* in2;
+  const void* wt2;
+  const float* bias2;
+  void* out2;
+  int32_t co2, ldo2, relu2, ci2;
 } vdqn_conv_args;
 int vdqn_conv2d(const vdqn_conv_args* a, void* stream);
 

@@ -118,6 +118,60 @@ def test_conv_dgrad(case, dtype):
     assert relerr(got0.cpu().permute(0, 3, 1, 2), ref0) < TOL_F32OUT[dtype]
 
 
+FUSED_CASES = [  # n, ci, planes, h: the stride-2 BasicBlocks (layer2.0 / layer3.0 / layer4.0 geometry) and ragged sizes
+    (3, 64, 128, 14), (2, 128, 256, 10), (2, 256, 512, 7), (5, 64, 128, 9), (1, 128, 128, 28),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_conv_fused_downsample_forward(case, dtype):
+    """conv1 (3x3 / 2, ReLU) and the 1x1 / 2 downsample of a stride-2 BasicBlock in ONE launch: both outputs are bit-identical
+    to the two separate launches (same tiles, same K order) and match torch."""
+    from video_dqn_amd import ops
+    n, ci, co, h = case
+    ho = (h + 2 - 3) // 2 + 1
+    x = q(rnd(1, "x", (n, ci, h, h)), dtype)
+    w1 = q(rnd(2, "w1", (co, ci, 3, 3), -0.1, 0.1), dtype)
+    w2 = q(rnd(3, "w2", (co, ci, 1, 1), -0.2, 0.2), dtype)
+    b1, b2 = rnd(4, "b1", (co,)), rnd(5, "b2", (co,))
+    xd = nhwc(x, dtype)
+    kw = dict(ho=ho, wo=ho, co=co, r=3, s=3, stride=2, pad=1, bias=b1.to(DEV), relu=True)
+    out, out2 = ops.conv2d(xd, krsc(w1, dtype), wt2=krsc(w2, dtype), bias2=b2.to(DEV), co2=co, relu2=False, **kw)
+    sep1 = ops.conv2d(xd, krsc(w1, dtype), **kw)
+    sep2 = ops.conv2d(xd, krsc(w2, dtype), ho=ho, wo=ho, co=co, r=1, s=1, stride=2, pad=0, bias=b2.to(DEV), relu=False)
+    torch.cuda.synchronize()
+    assert torch.equal(out, sep1) and torch.equal(out2, sep2)
+    assert relerr(out.float().cpu().permute(0, 3, 1, 2), F.relu(F.conv2d(x, w1, b1, 2, 1))) < TOL[dtype]
+    assert relerr(out2.float().cpu().permute(0, 3, 1, 2), F.conv2d(x, w2, b2, 2, 0)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_conv_fused_downsample_dgrad(case, dtype):
+    """gx = mask(x > 0) * (dgrad_3x3s2(g_h) + dgrad_1x1s2(g_out)) in ONE launch (the shortcut gradient never exists as a tensor),
+    against torch and against the two-launch composition (which rounds the shortcut gradient to the storage type first)."""
+    from video_dqn_amd import ops
+    n, ci, co, h = case
+    ho = (h + 2 - 3) // 2 + 1
+    w1 = q(rnd(2, "w1", (co, ci, 3, 3), -0.1, 0.1), dtype)
+    w2 = q(rnd(3, "w2", (co, ci, 1, 1), -0.2, 0.2), dtype)
+    g_h = q(rnd(5, "gh", (n, co, ho, ho)), dtype)
+    g_o = q(rnd(6, "go", (n, co, ho, ho)), dtype)
+    xact = q(rnd(7, "xa", (n, ci, h, h)), dtype)
+    ref = (F.grad.conv2d_input((n, ci, h, h), w1, g_h, 2, 1) + F.grad.conv2d_input((n, ci, h, h), w2, g_o, 2, 0)) * (xact > 0)
+    wd1 = w1.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)  # [ci][3][3][co]
+    wd2 = w2.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)  # [ci][1][1][co]
+    kw = dict(ho=h, wo=h, co=ci, r=3, s=3, stride=2, pad=1, mode=1, mask=nhwc(xact, dtype), want_colsum=True)
+    got, part = ops.conv2d(nhwc(g_h, dtype), wd1, wt2=wd2, in2=nhwc(g_o, dtype), **kw)
+    dsg = ops.conv2d(nhwc(g_o, dtype), wd2, ho=h, wo=h, co=ci, r=1, s=1, stride=2, pad=0, mode=1)
+    two, _ = ops.conv2d(nhwc(g_h, dtype), wd1, resid=dsg, **kw)
+    torch.cuda.synchronize()
+    assert relerr(got.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    assert relerr(got, two) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONV_CASES + [(5, 64, 64, 20, 3, 1, 1)])
 @pytest.mark.parametrize("splitk", [0, 1, 3])

@@ -23,7 +23,9 @@ class ConvArgs(C.Structure):
                 ("n_img", c_i32), ("hi", c_i32), ("wi", c_i32), ("ci", c_i32), ("pix_stride", c_i32),
                 ("ho", c_i32), ("wo", c_i32), ("co", c_i32), ("ldo", c_i32),
                 ("r", c_i32), ("s", c_i32), ("stride", c_i32), ("pad", c_i32),
-                ("mode", c_i32), ("relu", c_i32), ("dtype", c_i32)]
+                ("mode", c_i32), ("relu", c_i32), ("dtype", c_i32),
+                ("in2", c_vp), ("wt2", c_vp), ("bias2", c_vp), ("out2", c_vp),
+                ("co2", c_i32), ("ldo2", c_i32), ("relu2", c_i32), ("ci2", c_i32)]
 
 
 class WgradArgs(C.Structure):

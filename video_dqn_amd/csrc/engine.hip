@@ -785,8 +785,19 @@ int64_t wgrad_max_imgs(const vdqn_net* net, const Layer& L) {
   return m;
 }
 
+// VDQN_FUSE_DS: the 1x1 downsample of a stride-2 BasicBlock rides in its sibling 3x3's launches.  Bit 0 (default on): backward —
+// extra K-steps of the 3x3's stride-2 data gradient, the shortcut gradient never exists (0.27 instead of 0.42 ms per update);
+// bit 1 (default off): forward — second output of one launch, three launches fewer per pass, bit-identical outputs, but the
+// short sibling tiles (1-4 K-steps) between the long ones cost 0.07 ms per update more than their own launch did.
+int fuse_ds_mask() {
+  static const int m = [] { const char* e = getenv("VDQN_FUSE_DS"); return e ? atoi(e) : 1; }();
+  return m;
+}
+bool fuse_ds() { return (fuse_ds_mask() & 1) != 0; }
+bool fuse_ds_fwd() { return (fuse_ds_mask() & 2) != 0; }
+
 int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* in, void* out, int n_units, const void* resid,
-             int relu, float* out_f32, hipStream_t st) {
+             int relu, float* out_f32, hipStream_t st, const Layer* sib = nullptr, void* sib_out = nullptr) {
   vdqn_conv_args a;
   memset(&a, 0, sizeof(a));
   a.in = in;
@@ -803,13 +814,20 @@ int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, c
   a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
   a.mode = 0; a.relu = relu; a.dtype = net->cfg.dtype;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
+  if (sib) {  // the block's 1x1 / stride-2 downsample (BatchNorm folded, no ReLU): second output of the same launch
+    a.wt2 = packed + sib->wf_off;
+    a.bias2 = reinterpret_cast<const float*>(packed + sib->bias_off);
+    a.out2 = sib_out;
+    a.co2 = sib->co_pad; a.ldo2 = sib->co_pad; a.relu2 = 0;
+    g_prof_alg_flops += 2.0 * n_units * sib->ho * sib->wo * (double)sib->co * sib->ci;
+  }
   prof_layer(L, n_units);
   return vdqn_conv2d(&a, st);
 }
 
 // data gradient: gx = (dgrad(gy) + resid) masked by (mask > 0)
 int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* gy, void* gx, int n_units, const void* resid,
-              const void* mask, hipStream_t st, void* colsum_part = nullptr) {
+              const void* mask, hipStream_t st, void* colsum_part = nullptr, const Layer* sib = nullptr, const void* sib_gy = nullptr) {
   vdqn_conv_args a;
   memset(&a, 0, sizeof(a));
   a.in = gy;
@@ -824,6 +842,12 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
   a.r = L.k_r; a.s = L.k_s; a.stride = L.stride; a.pad = L.pad;
   a.mode = 1; a.relu = 0; a.dtype = net->cfg.dtype;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
+  if (sib) {  // + the data gradient of the block's 1x1 / stride-2 downsample, accumulated in the same tiles
+    a.in2 = sib_gy;
+    a.wt2 = packed + sib->wd_off;
+    a.ci2 = sib->co_pad;
+    g_prof_alg_flops += 2.0 * n_units * sib->ho * sib->wo * (double)sib->co * sib->ci;
+  }
   prof_layer(L, n_units);
   return vdqn_conv2d(&a, st);
 }
@@ -886,11 +910,16 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
   for (int b = 0; b < 8; ++b) {
     const Layer& c1 = net->layers[net->l_b_conv1[b]];
     const Layer& c2 = net->layers[net->l_b_conv2[b]];
-    RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st));
     const void* identity = x;
-    if (net->l_b_ds[b] >= 0) {
-      RC(run_conv(net, net->layers[net->l_b_ds[b]], packed, x, acts + A.ds[b], n, nullptr, 0, nullptr, st));
+    if (net->l_b_ds[b] >= 0 && fuse_ds_fwd()) {  // stride-2 block: conv1 and the downsample read the same pixels — one launch
+      RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st, &net->layers[net->l_b_ds[b]], acts + A.ds[b]));
       identity = acts + A.ds[b];
+    } else {
+      RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st));
+      if (net->l_b_ds[b] >= 0) {
+        RC(run_conv(net, net->layers[net->l_b_ds[b]], packed, x, acts + A.ds[b], n, nullptr, 0, nullptr, st));
+        identity = acts + A.ds[b];
+      }
     }
     RC(run_conv(net, c2, packed, acts + A.h[b], acts + A.o[b], n, identity, 1, nullptr, st));
     x = acts + A.o[b];
@@ -1223,6 +1252,10 @@ int block_backward(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayou
   const void* resid = g_out;  // identity shortcut
   if (net->l_b_ds[b] >= 0) {
     const Layer& ds = net->layers[net->l_b_ds[b]];
+    if (fuse_ds()) {  // the shortcut's gradient is the downsample's data gradient: summed inside conv1's data-gradient launch
+      RC(run_dgrad(net, c1, pk, bw + W.g_h[b], gx, n, nullptr, x, st, b > 0 ? bw + W.p_o[b - 1] : bw + W.p_pool, &ds, g_out));
+      return VDQN_OK;
+    }
     RC(run_dgrad(net, ds, pk, g_out, bw + W.dsg[b], n, nullptr, nullptr, st));
     resid = bw + W.dsg[b];
   }

@@ -70,7 +70,10 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
   const int lane = tid & 63, wave = tid >> 6;
   const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = (int)(lb % (uint32_t)p.tiles_n), tile_m = (int)(lb / (uint32_t)p.tiles_n);
-  const int n0 = tile_n * BN;
+  // fused sibling 1x1 (forward): this tile belongs to the 1x1 convolution — its own column range, weights and epilogue; K walks the
+  // channel chunks of the centre tap only
+  const bool sib = MODE == 0 && tile_n >= p.tiles_n1;
+  const int n0 = (sib ? tile_n - p.tiles_n1 : tile_n) * BN;
   // MODE 2 (stride-2 data gradient): an output pixel (oh, ow) only receives the taps with kr = oh + pad (mod 2) and
   // ks = ow + pad (mod 2).  Rows are therefore enumerated parity class by parity class ((oh & 1, ow & 1): 4 classes
   // of Ho/2 x Wo/2 pixels, tiles never straddle classes) and each tile walks only ITS taps: 9 tap-classes in total
@@ -86,6 +89,14 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     const int nkr = p.r > kr0 ? (p.r - kr0 + 1) / 2 : 0, nks = p.s > ks0 ? (p.s - ks0 + 1) / 2 : 0;
     nk = nkr * nks * (p.ci / KC);
   }
+  if (sib) {
+    kr0 = p.r >> 1;  // centre tap
+    ks0 = p.s >> 1;
+    nk = p.ci / KC;
+  }
+  // fused sibling (stride-2 data gradient): class (0, 0) tiles run extra K-steps over the sibling's output gradient
+  const int nk2 = (MODE == 2 && p.in2 != nullptr && cls_ph == 0 && cls_pw == 0) ? p.ci2 / KC : 0;
+  const int nk_all = nk + nk2;
   constexpr bool FWD = (MODE == 0 || MODE == 3);
   const int st_img = MODE == 3 ? tile_m >> 6 : 0, st_ty = (tile_m >> 3) & 7, st_tx = tile_m & 7;  // MODE 3 tile coordinates
   const int row_w = MODE == 2 ? p.cls_w[cls_pw] : p.wo;
@@ -107,11 +118,18 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
   long long a_rem = p.in_bytes - a_base_off;
   if (a_rem > 0x7fffffffLL) a_rem = 0x7fffffffLL;
   const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.in + a_base_off);
-  const unsigned long long b_ptr = (unsigned long long)p.wt;
+  const unsigned long long b_ptr = (unsigned long long)(sib ? p.wt2 : p.wt);
   const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
                       __builtin_amdgcn_readfirstlane((int)a_rem), 0x00020000};
   const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
-                      __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
+                      __builtin_amdgcn_readfirstlane(sib ? p.wt2_bytes : p.wt_bytes), 0x00020000};
+  // second operand pair of the fused stride-2 data gradient (same image geometry as `in`)
+  const unsigned long long a2_ptr = (unsigned long long)((const unsigned char*)p.in2 + a_base_off);
+  const unsigned long long b2_ptr = (unsigned long long)p.wt2;
+  const i32x4 rs_a2 = {__builtin_amdgcn_readfirstlane((int)(unsigned)a2_ptr), __builtin_amdgcn_readfirstlane((int)((a2_ptr >> 32) & 0xffff)),
+                       __builtin_amdgcn_readfirstlane((int)a_rem), 0x00020000};
+  const i32x4 rs_b2 = {__builtin_amdgcn_readfirstlane((int)(unsigned)b2_ptr), __builtin_amdgcn_readfirstlane((int)((b2_ptr >> 32) & 0xffff)),
+                       __builtin_amdgcn_readfirstlane(p.wt2_bytes), 0x00020000};
 
   // ---- per-row gather state (AROWS A rows per thread) ----
   uint32_t a_off[AROWS];
@@ -153,8 +171,13 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     a_wb[i] = wb;
   }
   uint32_t b_off[BROWS];
+  const int ktot_b = sib ? p.ci : p.ktot;  // K length of a weight row
 #pragma unroll
-  for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + RPS * i) * (uint32_t)(p.ktot * ESZ) + (uint32_t)(lchunk_b * 16);
+  for (int i = 0; i < BROWS; ++i) b_off[i] = (uint32_t)(n0 + lrow + RPS * i) * (uint32_t)(ktot_b * ESZ) + (uint32_t)(lchunk_b * 16);
+
+  uint32_t b_off2[BROWS];  // rows of the fused sibling's data-gradient weights [ci][1][1][ci2]
+#pragma unroll
+  for (int i = 0; i < BROWS; ++i) b_off2[i] = (uint32_t)(n0 + lrow + RPS * i) * (uint32_t)(p.ci2 * ESZ) + (uint32_t)(lchunk_b * 16);
 
   // LDS byte addresses (wave-uniform) of this wave's DMA pieces: piece i of an operand covers tile rows RPS i + 8 wave .. +7
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
       "s_add_u32 m0, %4, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                                 \
       ::"v"(V0), "v"(V1), "v"(V2), "v"(V3), "s"(LDS), "s"(RSRC), "s"(SOFF), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
       : "memory", "scc")
-#define VDQN_ISSUE(BUF, KR, KS, C0, KSTEP)                                                                          \
+#define VDQN_ISSUE_X(BUF, KR, KS, C0, KSTEP, RSA, RSB, BOFF)                                                                       \
   {                                                                                                                 \
     const int delta_ = (FWD         ? (((KR)*p.wi + (KS)) * p.pix_stride + (C0))                                    \
                         : MODE == 1 ? ((C0) - ((KR)*p.wi + (KS)) * p.pix_stride)                                    \
@@ -190,27 +213,40 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     }                                                                                                               \
     const uint32_t la_ = lds_wave + (uint32_t)(BUF) * (BM * 128);                                                   \
     const int zero_ = 0;                                                                                            \
-    VDQN_DMA4(vo_[0], vo_[1], vo_[2], vo_[3], la_, rs_a, zero_);                                                    \
+    VDQN_DMA4(vo_[0], vo_[1], vo_[2], vo_[3], la_, RSA, zero_);                                                    \
     if constexpr (AROWS == 8) {                                                                                     \
       const uint32_t la2_ = la_ + 4 * PSTR;                                                                         \
-      VDQN_DMA4(vo_[AROWS - 4], vo_[AROWS - 3], vo_[AROWS - 2], vo_[AROWS - 1], la2_, rs_a, zero_);                 \
+      VDQN_DMA4(vo_[AROWS - 4], vo_[AROWS - 3], vo_[AROWS - 2], vo_[AROWS - 1], la2_, RSA, zero_);                 \
     }                                                                                                               \
     const uint32_t lb_ = lds_wave + (uint32_t)(NS * BM * 128) + (uint32_t)(BUF) * (BN * 128);                       \
     const int so_ = (KSTEP)*128;                                                                                    \
     if constexpr (BROWS == 4) {                                                                                     \
-      VDQN_DMA4(b_off[0], b_off[BROWS > 1 ? 1 : 0], b_off[BROWS > 2 ? 2 : 0], b_off[BROWS > 2 ? 3 : 0], lb_, rs_b, so_); \
+      VDQN_DMA4(BOFF[0], BOFF[BROWS > 1 ? 1 : 0], BOFF[BROWS > 2 ? 2 : 0], BOFF[BROWS > 2 ? 3 : 0], lb_, RSB, so_); \
     } else if constexpr (BROWS == 2) {                                                                              \
       asm volatile(                                                                                                 \
           "s_nop 4\n\t"                                                                                             \
           "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %4 offen lds\n\t"                            \
           "s_add_u32 m0, %2, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds"                             \
-          ::"v"(b_off[0]), "v"(b_off[BROWS > 1 ? 1 : 0]), "s"(lb_), "s"(rs_b), "s"(so_), "n"(PSTR)                  \
+          ::"v"(BOFF[0]), "v"(BOFF[BROWS > 1 ? 1 : 0]), "s"(lb_), "s"(RSB), "s"(so_), "n"(PSTR)                  \
           : "memory", "scc");                                                                                       \
     } else {                                                                                                        \
       asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"             \
-                   ::"v"(b_off[0]), "s"(lb_), "s"(rs_b), "s"(so_)                                                   \
+                   ::"v"(BOFF[0]), "s"(lb_), "s"(RSB), "s"(so_)                                                   \
                    : "memory");                                                                                     \
     }                                                                                                               \
+  }
+#define VDQN_ISSUE(BUF, KR, KS, C0, KSTEP) VDQN_ISSUE_X(BUF, KR, KS, C0, KSTEP, rs_a, rs_b, b_off)
+  // the next K-step of this tile: one of its own taps, or (fused stride-2 data gradient, behind them) a channel chunk of the
+  // sibling 1x1's output gradient at the centre tap
+#define VDQN_ISSUE_NEXT(BUF)                                                                      \
+  {                                                                                               \
+    if (MODE == 2 && nk2 > 0 && issued >= nk) {                                                   \
+      VDQN_ISSUE_X(BUF, kr0, ks0, (issued - nk) * KC, issued - nk, rs_a2, rs_b2, b_off2)          \
+    } else {                                                                                      \
+      VDQN_ISSUE(BUF, ikr, iks, ic0, VDQN_WSTEP())                                                \
+      VDQN_ADVANCE()                                                                              \
+    }                                                                                             \
+    ++issued;                                                                                     \
   }
 #define VDQN_ADVANCE()                 \
   {                                    \
@@ -287,11 +323,7 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
                       "+v"(fa[CUR][1][0]), "+v"(fa[CUR][1][1]), "+v"(fa[CUR][1][2]), "+v"(fa[CUR][1][3]));               \
     _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) asm volatile("" : "+v"(fb[CUR][0][j_]), "+v"(fb[CUR][1][j_]));     \
     __builtin_amdgcn_s_barrier();                                                                                        \
-    if (issued < nk) {                                                                                                   \
-      VDQN_ISSUE((K) & (NS - 1), ikr, iks, ic0, VDQN_WSTEP())                                                            \
-      VDQN_ADVANCE()                                                                                                     \
-      ++issued;                                                                                                          \
-    }                                                                                                                    \
+    if (issued < nk_all) VDQN_ISSUE_NEXT((K) & (NS - 1))                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     /* unconditional (the last step reads a stale buffer) so that the reads sit in ONE block with the MFMAs: every */    \
     /* fragment read then issues behind an MFMA instead of in front of all of them (tools/probes/mfma_peak.hip) */       \
@@ -362,20 +394,12 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     }
   } else {
     // prologue: tiles 0 and 1 in flight, wait for tile 0 only
-    VDQN_ISSUE(0, ikr, iks, ic0, VDQN_WSTEP())
-    VDQN_ADVANCE()
-    ++issued;
+    VDQN_ISSUE_NEXT(0)
     if constexpr (NS == 4) {
-      for (int b = 1; b < NS && issued < nk; ++b) {
-        VDQN_ISSUE(b, ikr, iks, ic0, VDQN_WSTEP())
-        VDQN_ADVANCE()
-        ++issued;
-      }
+      for (int b = 1; b < NS && issued < nk_all; ++b) VDQN_ISSUE_NEXT(b)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once per tile
-    } else if (issued < nk) {
-      VDQN_ISSUE(1, ikr, iks, ic0, VDQN_WSTEP())
-      VDQN_ADVANCE()
-      ++issued;
+    } else if (issued < nk_all) {
+      VDQN_ISSUE_NEXT(1)
       if constexpr (AROWS + BROWS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if constexpr (AROWS + BROWS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if constexpr (AROWS + BROWS == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -386,11 +410,13 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     }
     __builtin_amdgcn_s_barrier();  // tile 0 visible
     VDQN_LOAD_FRAGS(0, 0)
-    for (int k = 0; k < nk; k += 2) {
+    for (int k = 0; k < nk_all; k += 2) {
       VDQN_STEP(k, 0, 1)
-      if (k + 1 < nk) VDQN_STEP(k + 1, 1, 0)
+      if (k + 1 < nk_all) VDQN_STEP(k + 1, 1, 0)
     }
   }
+#undef VDQN_ISSUE_NEXT
+#undef VDQN_ISSUE_X
 #undef VDQN_LOAD_FRAGS
 #undef VDQN_MFMA_ALL
 #undef VDQN_STEP
@@ -502,6 +528,13 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
       if constexpr (E16 == 8) *reinterpret_cast<uint2*>(p.pool_idx + o) = *reinterpret_cast<const uint2*>(bi);
       else *reinterpret_cast<uint32_t*>(p.pool_idx + o) = *reinterpret_cast<const uint32_t*>(bi);
     }
+    return;
+  }
+  if (sib) {  // the sibling's own epilogue: its bias, ReLU flag and output tensor; no residual, mask or column sums
+    IgemmParams q = p;
+    q.bias = p.bias2; q.out = p.out2; q.relu = p.relu2; q.co = p.co2; q.ldo = p.ldo2;
+    q.resid = nullptr; q.mask = nullptr; q.out_f32 = nullptr; q.colsum_part = nullptr;
+    igemm_epilogue<T, BM, BN, MODE, WN>(q, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw);
     return;
   }
   igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw);
@@ -1373,6 +1406,8 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   IgemmParams p;
   p.in = a->in; p.wt = a->wt; p.bias = a->bias; p.resid = a->resid; p.mask = a->mask; p.out = a->out; p.out_f32 = a->out_f32; p.colsum_part = a->colsum_part;
   p.pool_out = nullptr; p.pool_idx = nullptr;
+  p.in2 = nullptr; p.wt2 = nullptr; p.bias2 = nullptr; p.out2 = nullptr;
+  p.co2 = p.ldo2 = p.relu2 = p.ci2 = p.wt2_bytes = 0;
   p.n_img = a->n_img; p.hi = a->hi; p.wi = a->wi; p.ci = a->ci; p.pix_stride = a->pix_stride;
   p.ho = a->ho; p.wo = a->wo; p.co = a->co; p.ldo = a->ldo; p.r = a->r; p.s = a->s; p.stride = a->stride; p.pad = a->pad;
   p.relu = a->relu;
@@ -1391,6 +1426,25 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
     p.tiles_m = p.cls_tile0[4];
   }
   p.tiles_n = (a->co + bn - 1) / bn;
+  p.tiles_n1 = p.tiles_n;  // no sibling tiles unless set below
+  const bool has_sib = a->wt2 != nullptr;
+  if (has_sib) {
+    VDQN_CHECK(a->r == 3 && a->s == 3 && a->stride == 2 && a->pad == 1, "vdqn_conv2d: a sibling 1x1 needs a 3x3 / stride-2 / pad-1 call");
+    VDQN_CHECK((((uintptr_t)a->wt2) & 15) == 0, "vdqn_conv2d: wt2 must be 16-byte aligned");
+    if (a->mode == 0) {
+      VDQN_CHECK(a->out2 && a->co2 > 0 && a->ldo2 >= a->co2 && a->co2 % bn == 0 && bn == 128 && !a->out_f32 && !a->colsum_part,
+                 "vdqn_conv2d: fused sibling (forward) needs out2, co2 a multiple of the 128-column tile, no f32 copy / column sums");
+      VDQN_CHECK(((a->ldo2 * esz) % 16 == 0) && ((((uintptr_t)a->out2) & 15) == 0) && (a->ldo2 % 8 == 0), "vdqn_conv2d: out2 must be 16-byte aligned rows");
+      p.wt2 = a->wt2; p.bias2 = a->bias2; p.out2 = a->out2; p.co2 = a->co2; p.ldo2 = a->ldo2; p.relu2 = a->relu2;
+      p.wt2_bytes = (int)((long long)a->co2 * a->ci * esz);
+      p.tiles_n = p.tiles_n1 + a->co2 / bn;
+    } else {
+      VDQN_CHECK(a->in2 && a->ci2 > 0 && a->ci2 % kc == 0 && a->ci2 <= a->pix_stride && (((uintptr_t)a->in2) & 15) == 0,
+                 "vdqn_conv2d: fused sibling (data gradient) needs in2 with ci2 (a multiple of %d) channels in pixels of pix_stride elems", kc);
+      p.in2 = a->in2; p.wt2 = a->wt2; p.ci2 = a->ci2;
+      p.wt2_bytes = (int)((long long)p.tiles_n * bn * a->ci2 * esz);
+    }
+  }
   p.in_bytes = (long long)a->n_img * a->hi * a->wi * a->pix_stride * esz;
   const long long wtb = (long long)p.tiles_n * bn * p.ktot * esz;
   VDQN_CHECK(wtb < 0x7fffffffLL, "vdqn_conv2d: weight tensor too large");
@@ -1429,7 +1483,7 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
     return mode == 0 ? launch_igemm_win<float, 64, 0>(p, st) : launch_igemm_win<float, 64, 1>(p, st);
   }
   static const long long min256 = [] { const char* e = getenv("VDQN_BM256_MIN_ROWS"); return e ? atoll(e) : 256ll * 1024; }();
-  if (bn == 64 && mode != 2 && p.M >= min256) {
+  if (bn == 64 && mode != 2 && p.M >= min256 && !has_sib) {
     p.tiles_m = (p.M + 255) / 256;
     return a->dtype == VDQN_BF16 ? launch_mode<bf16raw, 256, 64>(p, mode, st) : launch_mode<float, 256, 64>(p, mode, st);
   }

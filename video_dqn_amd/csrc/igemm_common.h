@@ -27,6 +27,16 @@ struct IgemmParams {
   long long in_bytes;
   int wt_bytes;
   int vec_ok;
+  // sibling 1x1 convolution fused into a 3x3 / stride-2 / pad-1 launch (ResNet downsample branch; generic kernel only).
+  // Forward (MODE 0): the column tiles tiles_n1 .. tiles_n - 1 compute out2 = conv1x1_stride2(in) with wt2 / bias2 / relu2 —
+  // the 1x1's input pixel is the 3x3's centre tap, so both read the same staged rows.  Stride-2 data gradient (MODE 2): the
+  // tiles of output-parity class (0, 0) run ci2 / 64 extra K-steps over in2 (the gradient of the 1x1's output, same geometry as
+  // `in`) and wt2, adding the 1x1's data gradient in the accumulators (no intermediate tensor).
+  const void* in2;
+  const void* wt2;
+  const float* bias2;
+  void* out2;
+  int co2, ldo2, relu2, ci2, wt2_bytes, tiles_n1;
 };
 
 constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (num_records <= 0x7fffffff)

@@ -25,8 +25,12 @@ def dtype_code(t: torch.Tensor) -> int:
 def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: int, s: int, stride: int, pad: int,
            bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
            relu: bool = False, mode: int = 0, pix_stride: Optional[int] = None, ci: Optional[int] = None,
-           want_f32: bool = False, ldo: Optional[int] = None, want_colsum: bool = False):
-    """x: [n, hi, wi, c] NHWC; wt: [co_pad, r, s, ci].  Returns out [n, ho, wo, ldo] (and the f32 copy)."""
+           want_f32: bool = False, ldo: Optional[int] = None, want_colsum: bool = False,
+           wt2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None, co2: int = 0, relu2: bool = False,
+           in2: Optional[torch.Tensor] = None):
+    """x: [n, hi, wi, c] NHWC; wt: [co_pad, r, s, ci].  Returns out [n, ho, wo, ldo] (and the f32 copy).
+    Fused sibling 1x1 / stride 2 (include/vdqn.h): forward — wt2 [co2, 1, 1, ci] (+ bias2, relu2) gives a second output
+    (returned after `out`); data gradient — in2 [n, hi, wi, ci2] and wt2 [co, 1, 1, ci2] add the sibling's gradient."""
     lib = _lib.load()
     require_gpu()
     n, hi, wi, cx = x.shape
@@ -47,7 +51,15 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
     a.ho, a.wo, a.co, a.ldo = ho, wo, co, ldo
     a.r, a.s, a.stride, a.pad = r, s, stride, pad
     a.mode, a.relu, a.dtype = mode, int(relu), dtype_code(x)
+    out2 = None
+    if wt2 is not None and mode == 0:
+        out2 = torch.empty((n, ho, wo, co2), dtype=x.dtype, device=x.device)
+        a.wt2, a.bias2, a.out2, a.co2, a.ldo2, a.relu2 = _ptr(wt2), _ptr(bias2), _ptr(out2), co2, co2, int(relu2)
+    elif wt2 is not None:
+        a.wt2, a.in2, a.ci2 = _ptr(wt2), _ptr(in2), in2.shape[-1]
     _lib.check(lib.vdqn_conv2d(C.byref(a), _stream()), "vdqn_conv2d")
+    if out2 is not None:
+        return out, out2
     if want_colsum:
         return out, part
     return (out, out_f32) if want_f32 else out
