@@ -116,6 +116,7 @@ struct vdqn_net {
   int overlap = 1;
   int bwd_samples = 0;  // batch of the update in flight (set by vdqn_net_td_forward; sizes the bwd workspace layout)
   hipStream_t side = nullptr;
+  hipStream_t side2 = nullptr;  // the second half of the online forward pass
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
 };
@@ -125,9 +126,11 @@ namespace {
 bool side_ready(vdqn_net* net) {
   if (!net->overlap) return false;
   if (!net->side) {
-    if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&net->side2, hipStreamNonBlocking) != hipSuccess) {
       net->overlap = 0;
       net->side = nullptr;
+      net->side2 = nullptr;
       return false;
     }
     net->events.resize(64);
@@ -157,6 +160,20 @@ void join_side(vdqn_net* net, hipStream_t main) {
   if (!net->overlap || !net->side) return;
   hipEvent_t e = next_event(net);
   (void)hipEventRecord(e, net->side);
+  (void)hipStreamWaitEvent(main, e, 0);
+}
+// the same pair for the second side stream
+hipStream_t fork_side2(vdqn_net* net, hipStream_t main) {
+  if (!side_ready(net)) return main;
+  hipEvent_t e = next_event(net);
+  (void)hipEventRecord(e, main);
+  (void)hipStreamWaitEvent(net->side2, e, 0);
+  return net->side2;
+}
+void join_side2(vdqn_net* net, hipStream_t main) {
+  if (!net->overlap || !net->side2) return;
+  hipEvent_t e = next_event(net);
+  (void)hipEventRecord(e, net->side2);
   (void)hipStreamWaitEvent(main, e, 0);
 }
 
@@ -686,6 +703,28 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
 vdqn_wgrad_args wgrad_shape_args(const vdqn_net* net, const Layer& L, int n_units);
 int64_t wgrad_max_imgs(const vdqn_net* net, const Layer& L);
 
+// the same layout seen from sample `first`: every tensor's offset advanced by `first` samples (extra_capacity tensors only) —
+// lets one half of a batch run through forward_impl on its own stream
+ActLayout shift_layout(const vdqn_net* net, ActLayout A, int first) {
+  const int64_t F = net->cfg.num_frames, e = net->esz, s = first;
+  A.t_in += s * F * 115 * 115 * 16 * e;
+  A.pool += s * F * 56 * 56 * 64 * e;
+  A.idx += s * F * 56 * 56 * 64;
+  for (int b = 0; b < 8; ++b) {
+    const int64_t planes = 64 << (b / 2), sp = 56 >> (b / 2);
+    const int64_t per = F * sp * sp * planes * e;
+    A.h[b] += s * per;
+    A.o[b] += s * per;
+    if (A.ds[b] >= 0) A.ds[b] += s * per;
+  }
+  A.f8 += s * F * 25 * 64 * e;
+  A.l0 += s * 512 * e;
+  A.l1 += s * 256 * e;
+  A.q += s * 64 * e;
+  A.qf += s * 64 * 4;
+  return A;
+}
+
 BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
   const int64_t F = net->cfg.num_frames, n = (int64_t)n_samples * F, e = net->esz;
   BwdLayout L;
@@ -1011,6 +1050,7 @@ extern "C" int vdqn_net_create(const vdqn_net_config* cfg, vdqn_net** out) {
 extern "C" int vdqn_net_set_overlap(vdqn_net* net, int on) {
   VDQN_CHECK(net, "vdqn_net_set_overlap: null net");
   if (net->side) (void)hipStreamSynchronize(net->side);
+  if (net->side2) (void)hipStreamSynchronize(net->side2);
   net->overlap = on ? 1 : 0;
   return VDQN_OK;
 }
@@ -1031,6 +1071,10 @@ extern "C" void vdqn_net_destroy(vdqn_net* net) {
     for (auto& e : net->events)
       if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(net->side);
+    if (net->side2) {
+      (void)hipStreamSynchronize(net->side2);
+      (void)hipStreamDestroy(net->side2);
+    }
   }
   delete net;
 }
@@ -1191,8 +1235,22 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   }
   if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
     RC(forward_train_impl(net, (const unsigned char*)a->packed_online, a->params, a->bnstats, ao + A.t_in, ns_online, gtb ? 1 : 2, ao, A, st));
-  else
-    RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st));
+  else {
+    // The online pass over [before; after] as two independent half-batch passes on two streams (BatchNorm in eval mode: samples
+    // are independent, each half is bit-identical to its part of the 2B pass).  With the target pass that makes three concurrent
+    // kernel chains walking the same layers: their tiles fill each other's tail rounds (a 256-frame launch of layer3 / layer4 is
+    // 1.5 / 0.77 rounds of workgroups on its own).  VDQN_SPLIT_ONLINE=0 keeps the single 2B pass.
+    static const bool split = [] { const char* e = getenv("VDQN_SPLIT_ONLINE"); return !(e && e[0] == '0'); }();
+    hipStream_t s2 = (split && !gtb) ? fork_side2(net, st) : st;
+    if (s2 != st) {
+      const ActLayout A2 = shift_layout(net, A, B);
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A2.t_in, B, ao, A2, s2));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, B, ao, A, st));
+      join_side2(net, st);
+    } else {
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st));
+    }
+  }
   if (tst != st) join_side(net, st);
 
   hipError_t e = hipMemsetAsync(bw + W.zero_begin, 0, (size_t)W.zero_bytes, st);

@@ -80,8 +80,10 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
   // instead of 4 x 9 with three quarters of the A rows zero.
   int m0 = tile_m * BM, nk = p.nk, kr0 = 0, ks0 = 0, cls_ph = 0, cls_pw = 0;
   if constexpr (MODE == 2) {
-    const int cls = (tile_m >= p.cls_tile0[1]) + (tile_m >= p.cls_tile0[2]) + (tile_m >= p.cls_tile0[3]);
-    m0 = (tile_m - p.cls_tile0[cls]) * BM;  // first row inside the class
+    // class-major tile order, or (all classes equally long: every even-sized image) the four classes of one row block in
+    // consecutive tiles — they read the same gy rows, which the XCD-contiguous tile order then finds in that XCD's L2
+    const int cls = p.cls_interleave ? (tile_m & 3) : (tile_m >= p.cls_tile0[1]) + (tile_m >= p.cls_tile0[2]) + (tile_m >= p.cls_tile0[3]);
+    m0 = (p.cls_interleave ? (tile_m >> 2) : (tile_m - p.cls_tile0[cls])) * BM;  // first row inside the class
     cls_ph = cls >> 1;
     cls_pw = cls & 1;
     kr0 = (cls_ph + p.pad) & 1;
@@ -1156,7 +1158,7 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int q = q0 + lrow + 32 * i;
-      vo[i] = ((unsigned)q < (unsigned)p.M) ? (uint32_t)q * 128u + (uint32_t)(lchunk * 16) : kOob;
+      vo[i] = (uint32_t)q * 128u + (uint32_t)(lchunk * 16);  // q < 0 wraps past, q >= M runs past the descriptor's range: zero-filled
     }
     const uint32_t l0 = lds_wave + (uint32_t)(buf * kC64WinBytes);
 #pragma unroll
@@ -1419,11 +1421,14 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   p.tiles_m = (p.M + 127) / 128;
   memset(p.cls_tile0, 0, sizeof(p.cls_tile0));
   p.cls_h[0] = p.cls_h[1] = p.cls_w[0] = p.cls_w[1] = 0;
+  p.cls_interleave = 0;
   if (a->mode == 1 && a->stride == 2) {  // tiles are laid out parity class by parity class (see the kernel)
     p.cls_h[0] = (a->ho + 1) / 2; p.cls_h[1] = a->ho / 2;
     p.cls_w[0] = (a->wo + 1) / 2; p.cls_w[1] = a->wo / 2;
     for (int c = 0; c < 4; ++c) p.cls_tile0[c + 1] = p.cls_tile0[c] + (a->n_img * p.cls_h[c >> 1] * p.cls_w[c & 1] + 127) / 128;
     p.tiles_m = p.cls_tile0[4];
+    static const int inter = [] { const char* e = getenv("VDQN_DGRAD_S2_INTERLEAVE"); return e ? atoi(e) : 1; }();
+    p.cls_interleave = inter && p.cls_h[0] == p.cls_h[1] && p.cls_w[0] == p.cls_w[1];
   }
   p.tiles_n = (a->co + bn - 1) / bn;
   p.tiles_n1 = p.tiles_n;  // no sibling tiles unless set below

@@ -24,6 +24,7 @@ struct IgemmParams {
   int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldo, r, s, stride, pad, relu;
   int M, howo, ktot, nk, tiles_m, tiles_n;
   int cls_tile0[5], cls_h[2], cls_w[2];  // MODE 2: first tile of each output-parity class; class heights / widths
+  int cls_interleave;                    // MODE 2: the four classes have equal tile counts and tile t belongs to class t & 3
   long long in_bytes;
   int wt_bytes;
   int vec_ok;

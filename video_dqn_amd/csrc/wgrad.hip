@@ -409,33 +409,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
   const uint32_t pix_b = (uint32_t)p.pix_stride * 2u;
   constexpr int X_TAIL_WAVES = (WR * CPRX - 256 * (NLX - 1)) / 64;  // waves that take part in the last window pass
 
+  // Staging addresses are LINEAR in the pixel index: gy row pm, and — stride 1, pad 1, same-size images laid end to end — the
+  // x pixel one kernel-row offset away is pixel pm + (kr - 1) W of the flat tensor.  A pixel index below 0 or past the tensor
+  // wraps / runs out of the buffer descriptor's range and is zero-filled by the hardware; pixels that are in range but belong to
+  // another image row (top / bottom / left / right border of the OUTPUT pixel) are handled where the fragments are read (zero
+  // row).  So a K-step's address arithmetic is one add per DMA piece (it was ~25 VALU per piece with two divisions).
+  // slot q = tid + 256 i of a staged tile is row q / CPR + (256 / CPR) i with the SAME source chunk for every i (the swizzle keys
+  // repeat every 8 rows), so one per-lane offset per operand serves all pieces and the piece's row block is a scalar
+  const uint32_t g_lane = (uint32_t)(tid / CPRG) * ldg_b + (uint32_t)((co0 + ((tid % CPRG) ^ wg_swz<T, BCO>(tid / CPRG)) * E16) * 2);
+  const uint32_t x_lane = (uint32_t)(tid / CPRX) * pix_b + (uint32_t)((ci0 + ((tid % CPRX) ^ wg_swz<T, BCI>(tid / CPRX)) * E16) * 2);
+  static_assert((256 / CPRG) % 8 == 0 && (256 / CPRX) % 8 == 0, "swizzle keys repeat over the pieces of one thread");
+  const int x_shift = (kr - 1) * p.wo - 1;  // window row j = pixel kb + j + x_shift
+
   auto issue_tile = [&](int kb, int buf) {
 #pragma unroll
     for (int i = 0; i < NLG; ++i) {
-      const int q = tid + 256 * i, lr = q / CPRG;
-      const int ch = (q % CPRG) ^ wg_swz<T, BCO>(lr);
-      const int pm = kb + lr;
-      const uint32_t vg = pm < kend ? (uint32_t)pm * ldg_b + (uint32_t)((co0 + ch * E16) * 2) : kOobW;
+      const uint32_t vg = g_lane + (uint32_t)(kb + (256 / CPRG) * i) * ldg_b;
       const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RBG) + i * 4096);
-      asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vg), "s"(la), "s"(rs_g) : "memory");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vg), "s"(la), "s"(rs_g) : "memory");
     }
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
       if (i == NLX - 1 && wave_u >= X_TAIL_WAVES) break;
-      const int q = tid + 256 * i, lr = q / CPRX;
-      const int ch = (q % CPRX) ^ wg_swz<T, BCI>(lr);
-      const int pm = kb - 1 + lr;
-      const bool ok = pm >= 0 && pm < p.M;
-      const uint32_t pmu = ok ? (uint32_t)pm : 0u;
-      const uint32_t img = fastdiv(pmu, p.d_howo);
-      const uint32_t rem = pmu - img * p.d_howo.div;
-      const uint32_t oh = fastdiv(rem, p.d_wo);
-      const uint32_t ow = rem - oh * p.d_wo.div;
-      const int h = (int)oh + kr - 1;
-      const bool okx = ok && ((unsigned)h < (unsigned)p.hi);
-      const uint32_t vx = okx ? ((img * (uint32_t)p.hi + (uint32_t)h) * (uint32_t)p.wi + ow) * pix_b + (uint32_t)((ci0 + ch * E16) * 2) : kOobW;
+      const uint32_t vx = x_lane + (uint32_t)(kb + x_shift + (256 / CPRX) * i) * pix_b;  // may wrap below zero: out of range, zero-filled
       const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RBG + buf * (WR * RBX) + i * 4096);
-      asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vx), "s"(lx), "s"(rs_x) : "memory");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vx), "s"(lx), "s"(rs_x) : "memory");
     }
   };
 
@@ -460,15 +458,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
       const int sub = WSPLIT ? wave : sub0;
       const unsigned char* a = sA + buf * (KP * RBG) + sub * (32 * RBG);
       const unsigned char* xw = sX + buf * (WR * RBX);
-      // image column of this lane's two pixels (rows `row` and `row + 16` of the sub-step)
-      bool e_l[2], e_r[2];
+      // border flags of this lane's two output pixels (rows `row` and `row + 16` of the sub-step): the taps that leave the image
+      // on that side read the zero row.  e_v: the whole kernel row kr is outside (top row with kr = 0, bottom row with kr = 2).
+      bool e_l[2], e_r[2], e_v[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const uint32_t pm = (uint32_t)(kb + sub * 32 + row + 16 * hh);
         const uint32_t rem = pm - fastdiv(pm, p.d_howo) * p.d_howo.div;
-        const uint32_t ow = rem - fastdiv(rem, p.d_wo) * p.d_wo.div;
+        const uint32_t oh = fastdiv(rem, p.d_wo);
+        const uint32_t ow = rem - oh * p.d_wo.div;
         e_l[hh] = ow == 0;
         e_r[hh] = ow == (uint32_t)p.wo - 1;
+        e_v[hh] = (kr == 0 && oh == 0) || (kr == 2 && oh == (uint32_t)p.ho - 1);
       }
       s16x8 af[NFA];
 #pragma unroll
@@ -483,8 +484,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
       for (int ks = 0; ks < 3; ++ks) {
         const int jr = sub * 32 + row + ks;  // window row of the low half; high half: + 16 (same swizzle key for both)
         const int szX = wg_swz<T, BCI>(jr);
-        const bool z0 = (ks == 0 && e_l[0]) || (ks == 2 && e_r[0]);
-        const bool z1 = (ks == 0 && e_l[1]) || (ks == 2 && e_r[1]);
+        const bool z0 = e_v[0] || (ks == 0 && e_l[0]) || (ks == 2 && e_r[0]);
+        const bool z1 = e_v[1] || (ks == 0 && e_l[1]) || (ks == 2 && e_r[1]);
 #pragma unroll
         for (int j = 0; j < NFB; ++j) {  // one x fragment live at a time (register budget)
           const int cb = wc * (BCI / 2) + j * 16;
