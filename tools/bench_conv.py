@@ -51,4 +51,4 @@ def main(n_fwd=512, n_bwd=256, reps=20, dtype=torch.bfloat16):
 
 
 if __name__ == "__main__":
-    main(reps=int(os.environ.get("REPS", "20")))
+    main(n_fwd=int(os.environ.get("N_FWD", "512")), n_bwd=int(os.environ.get("N_BWD", "256")), reps=int(os.environ.get("REPS", "20")))

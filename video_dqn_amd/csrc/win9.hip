@@ -26,19 +26,35 @@
 
 namespace {
 
-constexpr int kU_WinStride = 192 * 128;             // bytes between the two window buffers (largest window: W = 28)
-constexpr int kU_WtTile = 128 * 128;                // one staged weight tile
-constexpr int kU_WinBase = 2 * kU_WtTile;           // LDS: [2 weight tiles][2 windows]
-constexpr int kU_Smem = kU_WinBase + 2 * kU_WinStride;
+constexpr int kU_WtTile = 128 * 128;       // one staged weight tile
+constexpr int kU_WinBase = 2 * kU_WtTile;  // LDS: [2 weight tiles][2 windows]
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void win9u_kernel(const IgemmParams p, const int wrows, const FastDiv d_wo, const FastDiv d_howo, void* stamps) {
+// BM = 128: 4 waves, two workgroups per CU.  BM = 256: 8 waves (4 x 2 of 64 x 64), one workgroup per CU — the two co-resident
+// 128-row tiles of a CU made one, so that the weight tile (16 of the 18.7 KB a 128-row tile stages per K-step) is staged once for
+// both halves: 21.4 KB per K-step and CU instead of 37.4 KB.
+template <int BM>
+struct Win9Geom {
+  static constexpr int NT = 2 * BM;                     // threads
+  static constexpr int RPP = NT / 8;                    // rows one staging pass of the workgroup covers (8 lanes x 16 B per row)
+  static constexpr int PSTR = RPP * 128;                // LDS distance between a thread's consecutive DMA pieces
+  static constexpr int WinRows = BM == 128 ? 192 : 320;  // >= BM + 2 * 28 + 3, a multiple of RPP
+  static constexpr int WinStride = WinRows * 128;       // bytes between the two window buffers
+  static constexpr int WPass = WinRows / RPP;           // 6 / 5 staging passes per window
+  static constexpr int BPass = 128 / RPP;               // 4 / 2 per weight tile
+  static constexpr int Smem = kU_WinBase + 2 * WinStride;
+};
+
+template <int MODE, int BM>
+__global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, const int wrows, const FastDiv d_wo, const FastDiv d_howo, void* stamps) {
   static_assert(MODE == 0 || MODE == 1, "window kernel: forward or stride-1 data gradient");
+  static_assert(BM == 128 || BM == 256, "tile rows");
   using T = bf16raw;  // (VDQN_INTERLEAVE keys on sizeof(T))
-  constexpr int BM = 128, BN = 128, WN = 2;
+  using G = Win9Geom<BM>;
+  constexpr int BN = 128, WN = 2;
   constexpr int NF = BN / (16 * WN);  // 4
   constexpr int CPL = 4 * NF;         // 16
-  constexpr int PSTR = 32 * 128;      // LDS distance between a thread's consecutive DMA pieces
+  constexpr int PSTR = G::PSTR;
+  constexpr int kU_WinStride = G::WinStride;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -58,17 +74,17 @@ __global__ __launch_bounds__(256, 2) void win9u_kernel(const IgemmParams p, cons
   const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
                       __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
 
-  // ---- window rows staged by this thread: j = lrow + 32 i; rows past 128 + 2 W + 2 (and pixels outside the tensor) are zero.
-  // The six offsets are rebuilt from (q0, lchunk) at every window issue (once per nine K-steps) instead of held in registers:
+  // ---- window rows staged by this thread: j = lrow + RPP i; rows past BM + 2 W + 2 (and pixels outside the tensor) are zero.
+  // The offsets are rebuilt from (q0, lchunk) at every window issue (once per nine K-steps) instead of held in registers:
   // the K loop needs the VGPRs for two fragment sets and the per-tap addresses ----
   const int pixB = p.pix_stride * 2;
   const int need = BM + 2 * W + 2;
   const int q0 = m0 - W - 1 + lrow;  // input pixel of window row lrow
   const uint32_t a_lane = (uint32_t)(lchunk_a * 16);
-  // weight rows lrow + 32 i: one per-lane offset, the row stride goes into the DMA's scalar offset (the weight tensor holds all
+  // weight rows lrow + RPP i: one per-lane offset, the row stride goes into the DMA's scalar offset (the weight tensor holds all
   // 128 rows of the column tile, so no range check is involved)
   const uint32_t b_off0 = (uint32_t)(n0 + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
-  const int b_row32 = 32 * p.ktot * 2;
+  const int b_row32 = G::RPP * p.ktot * 2;
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -84,38 +100,52 @@ __global__ __launch_bounds__(256, 2) void win9u_kernel(const IgemmParams p, cons
       "s_add_u32 m0, %4, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                                 \
       ::"v"(V0), "v"(V1), "v"(V2), "v"(V3), "s"(LDS), "s"(RSRC), "s"(SOFF), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
       : "memory", "scc")
-  // activation window of channel chunk CC -> window buffer WBUF: six passes of 32 rows (a window buffer is 192 rows whatever W
-  // is; rows past 128 + 2 W + 2 get an out-of-range offset and are zero-filled, the last of them is the zero row)
+  // activation window of channel chunk CC -> window buffer WBUF: WPass passes of RPP rows (a window buffer has WinRows rows whatever
+  // W is; rows past BM + 2 W + 2 get an out-of-range offset and are zero-filled, the last of them is the zero row)
 #define VDQN_ISSUE_AW(WBUF, CC)                                                                                     \
   {                                                                                                                 \
     const uint32_t la_ = lds_wave + (uint32_t)(kU_WinBase + (WBUF)*kU_WinStride);                                   \
     const int so_a_ = (CC)*128;                                                                                     \
     int q_ = q0;                                                                                                    \
-    asm volatile("" : "+v"(q_)); /* rebuilt here, not hoisted into six loop-carried registers */                     \
-    uint32_t a_off[6];                                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                              \
-      const int qi_ = q_ + 32 * i_;                                                                                 \
-      a_off[i_] = (lrow + 32 * i_ < need && (unsigned)qi_ < (unsigned)rows_total) ? (uint32_t)qi_ * (uint32_t)pixB + a_lane : kOob; \
+    asm volatile("" : "+v"(q_)); /* rebuilt here, not hoisted into loop-carried registers */                         \
+    uint32_t a_off[G::WPass];                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < G::WPass; ++i_) {                                                       \
+      const int qi_ = q_ + G::RPP * i_;                                                                             \
+      a_off[i_] = (lrow + G::RPP * i_ < need && (unsigned)qi_ < (unsigned)rows_total) ? (uint32_t)qi_ * (uint32_t)pixB + a_lane : kOob; \
     }                                                                                                               \
     VDQN_DMA4(a_off[0], a_off[1], a_off[2], a_off[3], la_, rs_a, so_a_);                                            \
     const uint32_t l4_ = la_ + 4 * PSTR;                                                                            \
-    asm volatile(                                                                                                   \
-        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %4 offen lds\n\t"                              \
-        "s_add_u32 m0, %2, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds"                               \
-        ::"v"(a_off[4]), "v"(a_off[5]), "s"(l4_), "s"(rs_a), "s"(so_a_), "n"(PSTR)                                  \
-        : "memory", "scc");                                                                                         \
+    if constexpr (G::WPass == 6) {                                                                                  \
+      asm volatile(                                                                                                 \
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %4 offen lds\n\t"                            \
+          "s_add_u32 m0, %2, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds"                             \
+          ::"v"(a_off[4]), "v"(a_off[G::WPass - 1]), "s"(l4_), "s"(rs_a), "s"(so_a_), "n"(PSTR)                     \
+          : "memory", "scc");                                                                                       \
+    } else {                                                                                                        \
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"                       \
+                   ::"v"(a_off[4]), "s"(l4_), "s"(rs_a), "s"(so_a_) : "memory");                                    \
+    }                                                                                                               \
   }
 #define VDQN_ISSUE_B(BUF, SOFF)                                                                                     \
   {                                                                                                                 \
     const uint32_t lb_ = lds_wave + (uint32_t)((BUF)*kU_WtTile);                                                    \
-    const int so0_ = (SOFF), so1_ = so0_ + b_row32, so2_ = so1_ + b_row32, so3_ = so2_ + b_row32;                    \
-    asm volatile(                                                                                                   \
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds\n\t"                              \
-        "s_add_u32 m0, %1, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds\n\t"                          \
-        "s_add_u32 m0, %1, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %5 offen lds\n\t"                          \
-        "s_add_u32 m0, %1, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %6 offen lds"                               \
-        ::"v"(b_off0), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "s"(so2_), "s"(so3_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
-        : "memory", "scc");                                                                                         \
+    const int so0_ = (SOFF), so1_ = so0_ + b_row32;                                                                 \
+    if constexpr (G::BPass == 4) {                                                                                  \
+      const int so2_ = so1_ + b_row32, so3_ = so2_ + b_row32;                                                       \
+      asm volatile(                                                                                                 \
+          "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds\n\t"                            \
+          "s_add_u32 m0, %1, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds\n\t"                        \
+          "s_add_u32 m0, %1, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %5 offen lds\n\t"                        \
+          "s_add_u32 m0, %1, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %6 offen lds"                             \
+          ::"v"(b_off0), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "s"(so2_), "s"(so3_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
+          : "memory", "scc");                                                                                       \
+    } else {                                                                                                        \
+      asm volatile(                                                                                                 \
+          "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds\n\t"                            \
+          "s_add_u32 m0, %1, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds"                             \
+          ::"v"(b_off0), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "n"(PSTR)                                       \
+          : "memory", "scc");                                                                                       \
+    }                                                                                                               \
   }
 
   f32x4 acc[4][NF];
@@ -284,10 +314,22 @@ extern void* g_stamp_buffer;
 #endif
 
 // entry used by vdqn_conv2d (igemm.hip): returns VDQN_OK or an error code
+template <int MODE, int BM>
+static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps) {
+  using G = Win9Geom<BM>;
+  const int wrows = (BM + 2 * p.wo + 2 + 1 + 7) & ~7;  // <= G::WinRows for W <= 28
+  const unsigned grid = (unsigned)(((p.M + BM - 1) / BM) * p.tiles_n);
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM>), (size_t)G::Smem);
+  hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
+                     make_fastdiv((uint32_t)p.howo), stamps);
+}
+
 int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
   const IgemmParams& p = *reinterpret_cast<const IgemmParams*>(pv);
-  const int wrows = (128 + 2 * p.wo + 2 + 1 + 7) & ~7;  // <= 192 for W <= 28
-  const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+  // VDQN_WIN9_BM256: 1 = 256-row tiles wherever the launch has more 128-row tiles than the chip holds at once (two per CU),
+  // 2 = always, 0 = never
+  static const int bm256 = [] { const char* e = getenv("VDQN_WIN9_BM256"); return e ? atoi(e) : 0; }();
+  const bool big = bm256 == 2 || (bm256 == 1 && (long long)p.tiles_m * p.tiles_n > 2ll * vdqn_num_cus());
   void* stamps = nullptr;
 #ifdef VDQN_STAMP
   stamps = g_stamp_buffer;
@@ -295,11 +337,9 @@ int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
   vdqn_prof_begin(mode == 0 ? "igemm_win<bf16,128,fwd>" : "igemm_win<bf16,128,dgrad>", 2.0 * p.M * p.co * p.ktot,
                   2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
   if (mode == 0) {
-    vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<0>), (size_t)kU_Smem);
-    hipLaunchKernelGGL((win9u_kernel<0>), dim3(grid), dim3(256), kU_Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), stamps);
+    if (big) launch_win9u<0, 256>(p, stream, stamps); else launch_win9u<0, 128>(p, stream, stamps);
   } else {
-    vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<1>), (size_t)kU_Smem);
-    hipLaunchKernelGGL((win9u_kernel<1>), dim3(grid), dim3(256), kU_Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), stamps);
+    if (big) launch_win9u<1, 256>(p, stream, stamps); else launch_win9u<1, 128>(p, stream, stamps);
   }
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
