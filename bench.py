@@ -26,6 +26,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises: see video_dqn_amd/__init__.py
+
 import torch  # noqa: E402
 
 GFLOP_PER_TUPLE_F1 = 17.982854656  # 3 fwd + 1 bwd, SURVEY.md §8(d) (8,991,427,328 MAC)

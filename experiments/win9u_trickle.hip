@@ -1,0 +1,424 @@
+// Nine-tap window kernel, unrolled: the 3x3 / stride 1 / pad 1 convolutions with 128+ channels (ResNet layer2 - layer4, bf16;
+// MODE 0 forward, MODE 1 data gradient) — the dominant kernel of a TD update.
+//
+// Same tiling and staging as igemm_win9_kernel (igemm.hip): 128 x 128 tiles, 4 waves of 64 x 64, ONE staged window of
+// 128 + 2 W + 2 consecutive input pixels per 64-channel chunk serving all nine taps, weight tiles streamed per K-step, two LDS
+// buffers and two register sets of fragments, one barrier per K-step, two workgroups per CU.  What changed is the instruction
+// stream of the K loop.  Counters and K-step stamps of the round-1 kernel (profiles/r02a_pmc_mfma.json,
+// profiles/r02b_win9_kstep_stamps_clock.txt) showed a K-step issuing ~170 instructions per wave for its 32 MFMAs — ~85 scalar
+// (tap decoding, the issue / load state machines, LDS-DMA address set-up with wait states), ~31 vector (swizzle keys, zero-row
+// selects, address adds) — and a wave issues at most one instruction per 4 cycles: two waves per SIMD need ~1360 issue cycles
+// for 1024 cycles of matrix work, which is the ~1500 cycles a K-step of the pair takes.  Here the K loop is unrolled over the
+// 18 K-steps of a chunk pair, so every step knows its tap, its LDS buffers and its register set at compile time:
+//   * per-lane fragment addresses of the nine taps (row offset W ky + kx and the XOR swizzle key of that row) are computed once
+//     per workgroup (18 VGPRs); the window buffer, the fragment row f and the weight-ring slot are ds_read immediates;
+//   * the zero row of an edge lane is selected with one v_cndmask per fragment read from a per-(f, K-half) address that already
+//     has the immediate subtracted; the centre tap and taps that cannot leave the image on a side skip the test;
+//   * scalar work per step: the weight tile's K offset (one add), M0 for the LDS-DMA pieces.
+// ~85 instructions per wave and K-step instead of ~170.
+//
+// Serves the same reference call sites as igemm.hip: torch conv2d (+ folded BatchNorm, ReLU, residual) of
+// archs/HabitatDQNMultiAction.py:30,49-51 (torchvision BasicBlock conv1 / conv2) and their data gradient
+// (train_q_network.py:226).
+#include <stdlib.h>
+
+#include "igemm_common.h"
+
+namespace {
+
+constexpr int kU_WtTile = 128 * 128;       // one staged weight tile
+constexpr int kU_WinBase = 2 * kU_WtTile;  // LDS: [2 weight tiles][2 windows]
+
+// BM = 128: 4 waves, two workgroups per CU.  BM = 256: 8 waves (4 x 2 of 64 x 64), one workgroup per CU — the two co-resident
+// 128-row tiles of a CU made one, so that the weight tile (16 of the 18.7 KB a 128-row tile stages per K-step) is staged once for
+// both halves: 21.4 KB per K-step and CU instead of 37.4 KB.
+template <int BM>
+struct Win9Geom {
+  static constexpr int NT = 2 * BM;                     // threads
+  static constexpr int RPP = NT / 8;                    // rows one staging pass of the workgroup covers (8 lanes x 16 B per row)
+  static constexpr int PSTR = RPP * 128;                // LDS distance between a thread's consecutive DMA pieces
+  static constexpr int WinRows = BM == 128 ? 192 : 320;  // >= BM + 2 * 28 + 3, a multiple of RPP
+  static constexpr int WinStride = WinRows * 128;       // bytes between the two window buffers
+  static constexpr int WPass = WinRows / RPP;           // 6 / 5 staging passes per window
+  static constexpr int BPass = 128 / RPP;               // 4 / 2 per weight tile
+  static constexpr int Smem = kU_WinBase + 2 * WinStride;
+};
+
+template <int MODE, int BM>
+__global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, const int wrows, const FastDiv d_wo, const FastDiv d_howo, void* stamps) {
+  static_assert(MODE == 0 || MODE == 1, "window kernel: forward or stride-1 data gradient");
+  static_assert(BM == 128 || BM == 256, "tile rows");
+  using T = bf16raw;  // (VDQN_INTERLEAVE keys on sizeof(T))
+  using G = Win9Geom<BM>;
+  constexpr int BN = 128, WN = 2;
+  constexpr int NF = BN / (16 * WN);  // 4
+  constexpr int CPL = 4 * NF;         // 16
+  constexpr int PSTR = G::PSTR;
+  constexpr int kU_WinStride = G::WinStride;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = (int)(lb % (uint32_t)p.tiles_n), tile_m = (int)(lb / (uint32_t)p.tiles_n);
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  const int W = p.wo, H = p.ho, rows_total = p.M;
+  const int lrow = tid >> 3;
+  const int lchunk_a = (tid & 7) ^ (lrow & 7);
+  const int lchunk_b = (tid & 7) ^ ((((lrow / CPL) & 1) << 2) | (lrow & 3));
+
+  const unsigned long long a_ptr = (unsigned long long)p.in;
+  const unsigned long long b_ptr = (unsigned long long)p.wt;
+  const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane((int)p.in_bytes), 0x00020000};
+  const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
+                      __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
+
+  // ---- window rows staged by this thread: j = lrow + RPP i; rows past BM + 2 W + 2 (and pixels outside the tensor) are zero.
+  // The offsets are rebuilt from (q0, lchunk) at every window issue (once per nine K-steps) instead of held in registers:
+  // the K loop needs the VGPRs for two fragment sets and the per-tap addresses ----
+  const int pixB = p.pix_stride * 2;
+  const int need = BM + 2 * W + 2;
+  const int q0 = m0 - W - 1 + lrow;  // input pixel of window row lrow
+  const uint32_t a_lane = (uint32_t)(lchunk_a * 16);
+  // weight rows lrow + RPP i: one per-lane offset, the row stride goes into the DMA's scalar offset (the weight tensor holds all
+  // 128 rows of the column tile, so no range check is involved)
+  const uint32_t b_off0 = (uint32_t)(n0 + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
+  const int b_row32 = G::RPP * p.ktot * 2;
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t lds_wave = lds_base + (uint32_t)wave_u * (8 * 128);
+
+  // LDS-DMA from inline asm (hipcc would wait vmcnt(0) before the first ds_read behind a pending LDS-DMA); M0 = LDS address of
+  // the wave's piece, one wait state between the M0 write and the DMA that reads it
+#define VDQN_DMA4(V0, V1, V2, V3, LDS, RSRC, SOFF)                                                                  \
+  asm volatile(                                                                                                     \
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, %6 offen lds\n\t"                                \
+      "s_add_u32 m0, %4, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"                            \
+      "s_add_u32 m0, %4, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"                            \
+      "s_add_u32 m0, %4, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds"                                 \
+      ::"v"(V0), "v"(V1), "v"(V2), "v"(V3), "s"(LDS), "s"(RSRC), "s"(SOFF), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
+      : "memory", "scc")
+  // activation window of channel chunk CC -> window buffer WBUF: WPass passes of RPP rows (a window buffer has WinRows rows whatever
+  // W is; rows past BM + 2 W + 2 get an out-of-range offset and are zero-filled, the last of them is the zero row)
+#define VDQN_ISSUE_AW(WBUF, CC)                                                                                     \
+  {                                                                                                                 \
+    const uint32_t la_ = lds_wave + (uint32_t)(kU_WinBase + (WBUF)*kU_WinStride);                                   \
+    const int so_a_ = (CC)*128;                                                                                     \
+    int q_ = q0;                                                                                                    \
+    asm volatile("" : "+v"(q_)); /* rebuilt here, not hoisted into loop-carried registers */                         \
+    uint32_t a_off[G::WPass];                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < G::WPass; ++i_) {                                                       \
+      const int qi_ = q_ + G::RPP * i_;                                                                             \
+      a_off[i_] = (lrow + G::RPP * i_ < need && (unsigned)qi_ < (unsigned)rows_total) ? (uint32_t)qi_ * (uint32_t)pixB + a_lane : kOob; \
+    }                                                                                                               \
+    VDQN_DMA4(a_off[0], a_off[1], a_off[2], a_off[3], la_, rs_a, so_a_);                                            \
+    const uint32_t l4_ = la_ + 4 * PSTR;                                                                            \
+    if constexpr (G::WPass == 6) {                                                                                  \
+      asm volatile(                                                                                                 \
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %4 offen lds\n\t"                            \
+          "s_add_u32 m0, %2, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds"                             \
+          ::"v"(a_off[4]), "v"(a_off[G::WPass - 1]), "s"(l4_), "s"(rs_a), "s"(so_a_), "n"(PSTR)                     \
+          : "memory", "scc");                                                                                       \
+    } else {                                                                                                        \
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"                       \
+                   ::"v"(a_off[4]), "s"(l4_), "s"(rs_a), "s"(so_a_) : "memory");                                    \
+    }                                                                                                               \
+  }
+#define VDQN_ISSUE_B(BUF, SOFF)                                                                                     \
+  {                                                                                                                 \
+    const uint32_t lb_ = lds_wave + (uint32_t)((BUF)*kU_WtTile);                                                    \
+    const int so0_ = (SOFF), so1_ = so0_ + b_row32;                                                                 \
+    if constexpr (G::BPass == 4) {                                                                                  \
+      const int so2_ = so1_ + b_row32, so3_ = so2_ + b_row32;                                                       \
+      asm volatile(                                                                                                 \
+          "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds\n\t"                            \
+          "s_add_u32 m0, %1, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds\n\t"                        \
+          "s_add_u32 m0, %1, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %5 offen lds\n\t"                        \
+          "s_add_u32 m0, %1, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %6 offen lds"                             \
+          ::"v"(b_off0), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "s"(so2_), "s"(so3_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
+          : "memory", "scc");                                                                                       \
+    } else {                                                                                                        \
+      asm volatile(                                                                                                 \
+          "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds\n\t"                            \
+          "s_add_u32 m0, %1, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds"                             \
+          ::"v"(b_off0), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "n"(PSTR)                                       \
+          : "memory", "scc");                                                                                       \
+    }                                                                                                               \
+  }
+
+  f32x4 acc[4][NF];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wr = wave / WN, wc = wave % WN;
+  const int i16 = lane & 15, g = lane >> 4;
+  // edge bits of this lane's four pixels, 4 bits per fragment f: 1 top row, 2 bottom row, 4 left column, 8 right column
+  uint32_t edge16 = 0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const uint32_t m = (uint32_t)(m0 + wr * 64 + f * 16 + i16);
+    const uint32_t rem = m - fastdiv(m, d_howo) * d_howo.div;
+    const uint32_t oh = fastdiv(rem, d_wo), ow = rem - oh * d_wo.div;
+    const uint32_t e = (oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u);
+    edge16 |= e << (4 * f);
+  }
+
+  // ---- per-lane LDS byte offsets, constant over the K loop ----
+  // ab[tap][h]: fragment row f = 0 of tap (kr, ks), K half h, relative to a window buffer: tile row wr*64 + i16 reads window row
+  // r + W ky + kx (forward: (ky, kx) = (kr, ks); data gradient: (2 - kr, 2 - ks)); the 16-byte chunk g + 4 h sits at the position
+  // XOR-ed with that window row's key (row & 7)
+  // (K half 1 is the same address with bit 6 flipped: chunk (g + 4) ^ key = (g ^ key) ^ 4)
+  uint32_t ab[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int kr = t / 3, ks = t % 3;
+    const int ky = MODE == 0 ? kr : 2 - kr, kx = MODE == 0 ? ks : 2 - ks;
+    const int row = wr * 64 + i16 + W * ky + kx;
+    const int key = (i16 + W * ky + kx) & 7;  // (wr * 64 is a multiple of 8)
+    ab[t] = (uint32_t)(row * 128 + ((g ^ key) << 4));
+  }
+  // zs[f]: the zero row (last row of a window buffer), minus the f * 16 rows the read's immediate adds
+  uint32_t zs[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) zs[f] = (uint32_t)((wrows - 1) * 128 + (g << 4) - f * 16 * 128);
+  // bb[h]: weight fragment j = 0, relative to a weight tile (rows read in the permuted order the epilogue expects)
+  const uint32_t bb0 = (uint32_t)((wc * (BN / WN) + (i16 >> 2) * CPL + (i16 & 3)) * 128 + ((g ^ (i16 & 7)) << 4));
+  const uint32_t bb1 = (uint32_t)((wc * (BN / WN) + (i16 >> 2) * CPL + (i16 & 3)) * 128 + (((g + 4) ^ (i16 & 7)) << 4));
+
+  const int cpk = p.ci / 64;   // channel chunks (even: ci is a multiple of 128); K order (chunk, tap), tap fastest
+  const int n_it = cpk >> 1;   // iterations of the 18-step body
+  const int tap_k = cpk * 128;  // byte distance between the weight K offsets of consecutive taps of one chunk
+
+  u32x4 fa[2][2][4], fb[2][2][NF];  // [register set][K half][fragment]
+
+  // fragments of the K-step with tap TAP_ in window buffer WBUF_ / weight buffer BBUF_ -> register set SET
+#define VDQN_LOAD_FRAGS(SET, TAP_, WBUF_, BBUF_)                                                                         \
+  {                                                                                                                      \
+    constexpr int kr_ = (TAP_) / 3, ks_ = (TAP_) % 3;                                                                    \
+    constexpr int ky_ = MODE == 0 ? kr_ : 2 - kr_, kx_ = MODE == 0 ? ks_ : 2 - ks_;                                      \
+    constexpr uint32_t tb_ = (ky_ == 0 ? 1u : 0u) | (ky_ == 2 ? 2u : 0u) | (kx_ == 0 ? 4u : 0u) | (kx_ == 2 ? 8u : 0u);   \
+    const unsigned char* wb_ = smem + kU_WinBase + (WBUF_)*kU_WinStride;                                                 \
+    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                                                   \
+      uint32_t a0_ = ab[TAP_];                                                                                           \
+      if constexpr (tb_ != 0u) { /* an edge lane's tap leaves the image: read the zero row */                            \
+        const bool z_ = (edge16 & (tb_ << (4 * f_))) != 0u;                                                              \
+        a0_ = z_ ? zs[f_] : a0_;                                                                                         \
+      }                                                                                                                  \
+      const uint32_t a1_ = a0_ ^ 64u;                                                                                    \
+      fa[SET][0][f_] = *reinterpret_cast<const u32x4*>(wb_ + f_ * 16 * 128 + a0_);                                       \
+      fa[SET][1][f_] = *reinterpret_cast<const u32x4*>(wb_ + f_ * 16 * 128 + a1_);                                       \
+    }                                                                                                                    \
+    const unsigned char* bt_ = smem + (BBUF_)*kU_WtTile;                                                                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) {                                                                  \
+      fb[SET][0][j_] = *reinterpret_cast<const u32x4*>(bt_ + j_ * 4 * 128 + bb0);                                        \
+      fb[SET][1][j_] = *reinterpret_cast<const u32x4*>(bt_ + j_ * 4 * 128 + bb1);                                        \
+    }                                                                                                                    \
+  }
+#define VDQN_MFMA_ALL(SET)                                                                                               \
+  _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_)                     \
+      _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) {                                                                \
+    acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[SET][h_][j_]),                   \
+                                                          __builtin_bit_cast(bf16x8, fa[SET][h_][f_]), acc[f_][j_], 0, 0, 0); \
+  }
+#ifdef VDQN_STAMP
+  // diagnostic build only (tools/stamp_win9.py): s_memtime around the phases of every K-step, summed per workgroup by wave 0
+  unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_comp = 0, st_t = 0;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_rt_begin = __builtin_amdgcn_s_memrealtime();
+#define VDQN_ST(ACC)                                                     \
+  {                                                                      \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();          \
+    ACC += n_ - st_t;                                                    \
+    st_t = n_;                                                           \
+  }
+#else
+#define VDQN_ST(ACC)
+#endif
+#ifndef VDQN_WIN9_TRICKLE
+#define VDQN_WIN9_TRICKLE 1
+#endif
+#if VDQN_WIN9_TRICKLE
+  // K-step U (0..17) of the iteration over chunks 2 it, 2 it + 1: tap U % 9 of chunk 2 it + U / 9.  Its fragments are in register
+  // set U & 1 (read one step ago).  The step runs as eight parts of four MFMAs; parts 0-3 read the A fragments, parts 4-7 the
+  // weight fragments of step U + 1 (two ds_read_b128 per part).  The staging is NOT a phase of its own: one LDS-DMA piece at the
+  // head of a part — the BPass pieces of step U + 2's weight tile (buffer U & 1, released by this step's barrier) in parts
+  // 0 .. BPass-1, and in part BPass piece U % 9 of the NEXT chunk's window (its buffer has been free since the previous chunk's
+  // last fragment read; WPass <= 6 pieces over a chunk's nine steps).  Issued as a burst behind the barrier, the pieces of all
+  // eight waves of a CU queue up at the texture-address unit and every wave sits in its issue phase (~330 cycles of a ~1450-cycle
+  // step, K-step stamps in profiles/) while the matrix pipe idles.
+#define VDQN_PIECE(VOFF, LDSADDR, RSRC, SOFF)                                                                            \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" ::"v"(VOFF), "s"(LDSADDR), "s"(RSRC), "s"(SOFF) : "memory")
+#define VDQN_UPART(U, P)                                                                                                 \
+  {                                                                                                                      \
+    constexpr int h_ = (P) / 4, f_ = (P) % 4;                                                                            \
+    if constexpr ((P) < G::BPass) {                                                                                      \
+      VDQN_PIECE(b_off0, lds_wave + (uint32_t)(cur_ * kU_WtTile + (P)*PSTR), rs_b, so_b_ + (P)*b_row32);                 \
+    } else if constexpr ((P) == G::BPass && tw_ < G::WPass) {                                                            \
+      int q_ = q0;                                                                                                       \
+      asm volatile("" : "+v"(q_));                                                                                       \
+      const int qi_ = q_ + G::RPP * tw_;                                                                                 \
+      const uint32_t ao_ = (lrow + G::RPP * tw_ < need && (unsigned)qi_ < (unsigned)rows_total) ? (uint32_t)qi_ * (uint32_t)pixB + a_lane : kOob; \
+      VDQN_PIECE(ao_, lds_wave + (uint32_t)(kU_WinBase + wn_ * kU_WinStride + tw_ * PSTR), rs_a, (cc2 + cw_) * 128);      \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    if constexpr ((P) < 4) {                                                                                             \
+      constexpr int kr_ = tl_ / 3, ks_ = tl_ % 3;                                                                        \
+      constexpr int ky_ = MODE == 0 ? kr_ : 2 - kr_, kx_ = MODE == 0 ? ks_ : 2 - ks_;                                    \
+      constexpr uint32_t tb_ = (ky_ == 0 ? 1u : 0u) | (ky_ == 2 ? 2u : 0u) | (kx_ == 0 ? 4u : 0u) | (kx_ == 2 ? 8u : 0u); \
+      const unsigned char* wb_ = smem + kU_WinBase + (cl_ & 1) * kU_WinStride;                                           \
+      uint32_t a0_ = ab[tl_];                                                                                            \
+      if constexpr (tb_ != 0u) a0_ = (edge16 & (tb_ << (4 * (P)))) != 0u ? zs[P] : a0_;                                  \
+      fa[nxt_][0][P] = *reinterpret_cast<const u32x4*>(wb_ + (P)*16 * 128 + a0_);                                        \
+      fa[nxt_][1][P] = *reinterpret_cast<const u32x4*>(wb_ + (P)*16 * 128 + (a0_ ^ 64u));                                \
+    } else {                                                                                                             \
+      const unsigned char* bt_ = smem + nxt_ * kU_WtTile;                                                                \
+      fb[nxt_][0][(P)-4] = *reinterpret_cast<const u32x4*>(bt_ + ((P)-4) * 4 * 128 + bb0);                               \
+      fb[nxt_][1][(P)-4] = *reinterpret_cast<const u32x4*>(bt_ + ((P)-4) * 4 * 128 + bb1);                               \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_)                                                                    \
+        acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[cur_][h_][j_]),              \
+                                                              __builtin_bit_cast(bf16x8, fa[cur_][h_][f_]), acc[f_][j_], 0, 0, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+#define VDQN_USTEP(U)                                                                                                    \
+  {                                                                                                                      \
+    constexpr int cur_ = (U)&1, nxt_ = cur_ ^ 1;                                                                         \
+    constexpr int ti_ = ((U) + 2) % 9, ci_ = ((U) + 2) / 9; /* tap and chunk (relative to 2 it) of the weight tile staged now */ \
+    constexpr int tl_ = ((U) + 1) % 9, cl_ = ((U) + 1) / 9; /* ... of the step whose fragments are read now */            \
+    constexpr int tw_ = (U) % 9, cw_ = (U) / 9 + 1, wn_ = cw_ & 1; /* window piece, its chunk (relative) and buffer */     \
+    const int so_b_ = ti_ * tap_k + (cc2 + ci_) * 128;                                                                   \
+    VDQN_ST(st_comp)                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
+    asm volatile("" : "+v"(edge16)); /* keeps the (loop-invariant) zero-row selects of this step inside this step */       \
+    VDQN_ST(st_wait)                                                                                                     \
+    asm volatile("" : "+v"(fa[cur_][0][0]), "+v"(fa[cur_][0][1]), "+v"(fa[cur_][0][2]), "+v"(fa[cur_][0][3]),            \
+                      "+v"(fa[cur_][1][0]), "+v"(fa[cur_][1][1]), "+v"(fa[cur_][1][2]), "+v"(fa[cur_][1][3]));           \
+    _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) asm volatile("" : "+v"(fb[cur_][0][j_]), "+v"(fb[cur_][1][j_]));   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    VDQN_ST(st_bar)                                                                                                      \
+    /* no branch: behind the last step this stages tiles nobody reads (out-of-range reads are zero-filled) */          \
+    VDQN_UPART(U, 0) VDQN_UPART(U, 1) VDQN_UPART(U, 2) VDQN_UPART(U, 3)                                                   \
+    VDQN_UPART(U, 4) VDQN_UPART(U, 5) VDQN_UPART(U, 6) VDQN_UPART(U, 7)                                                   \
+  }
+#else
+  // K-step U (0..17) of the iteration over chunks 2 it, 2 it + 1: tap U % 9 of chunk 2 it + U / 9.  Its fragments are in register
+  // set U & 1 (read one step ago); it issues the staging of step U + 2 (weight buffer U & 1, just released; at tap 0 also that
+  // chunk's window) and reads the fragments of step U + 1 underneath its own MFMAs.
+#define VDQN_USTEP(U)                                                                                                    \
+  {                                                                                                                      \
+    constexpr int cur_ = (U)&1, nxt_ = cur_ ^ 1;                                                                         \
+    constexpr int ti_ = ((U) + 2) % 9, ci_ = ((U) + 2) / 9; /* tap and chunk (relative to 2 it) of the step staged now */  \
+    constexpr int tl_ = ((U) + 1) % 9, cl_ = ((U) + 1) / 9; /* ... of the step whose fragments are read now */            \
+    VDQN_ST(st_comp)                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
+    asm volatile("" : "+v"(edge16)); /* keeps the (loop-invariant) zero-row selects of this step inside this step */       \
+    VDQN_ST(st_wait)                                                                                                     \
+    asm volatile("" : "+v"(fa[cur_][0][0]), "+v"(fa[cur_][0][1]), "+v"(fa[cur_][0][2]), "+v"(fa[cur_][0][3]),            \
+                      "+v"(fa[cur_][1][0]), "+v"(fa[cur_][1][1]), "+v"(fa[cur_][1][2]), "+v"(fa[cur_][1][3]));           \
+    _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) asm volatile("" : "+v"(fb[cur_][0][j_]), "+v"(fb[cur_][1][j_]));   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    VDQN_ST(st_bar)                                                                                                      \
+    /* no branch: behind the last step this stages two tiles nobody reads (out-of-range reads are zero-filled) */      \
+    VDQN_ISSUE_B(cur_, ti_ * tap_k + (cc2 + ci_) * 128)                                                                  \
+    if constexpr (ti_ == 0) VDQN_ISSUE_AW(ci_ & 1, cc2 + ci_)                                                            \
+    VDQN_ST(st_issue)                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    VDQN_LOAD_FRAGS(nxt_, tl_, cl_ & 1, nxt_) /* unconditional: the step behind the last one re-reads buffers that still exist */ \
+    VDQN_MFMA_ALL(cur_)                                                                                                  \
+    VDQN_INTERLEAVE(8 + 2 * NF)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+
+#endif
+
+  // prologue: K-steps 0 and 1 (window of chunk 0, weight tiles of taps 0 and 1), then the fragments of step 0
+  VDQN_ISSUE_B(0, 0)
+  VDQN_ISSUE_AW(0, 0)
+  VDQN_ISSUE_B(1, tap_k)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  VDQN_LOAD_FRAGS(0, 0, 0, 0)
+#ifdef VDQN_STAMP
+  st_t = __builtin_amdgcn_s_memtime();
+#endif
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < n_it; ++it) {
+    const int cc2 = 2 * it;            // first chunk of this iteration
+    VDQN_USTEP(0) VDQN_USTEP(1) VDQN_USTEP(2) VDQN_USTEP(3) VDQN_USTEP(4) VDQN_USTEP(5) VDQN_USTEP(6) VDQN_USTEP(7) VDQN_USTEP(8)
+    VDQN_USTEP(9) VDQN_USTEP(10) VDQN_USTEP(11) VDQN_USTEP(12) VDQN_USTEP(13) VDQN_USTEP(14) VDQN_USTEP(15) VDQN_USTEP(16) VDQN_USTEP(17)
+  }
+  VDQN_ST(st_comp)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two tiles staged behind the last step have landed:
+  __builtin_amdgcn_s_barrier();                     // the epilogue may reuse LDS
+#undef VDQN_USTEP
+#undef VDQN_UPART
+#undef VDQN_PIECE
+#undef VDQN_LOAD_FRAGS
+#undef VDQN_MFMA_ALL
+#undef VDQN_ISSUE_AW
+#undef VDQN_ISSUE_B
+#undef VDQN_DMA4
+#ifdef VDQN_STAMP
+  const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, p.howo, W, 0, 0);
+#ifdef VDQN_STAMP
+  if (stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(stamps) + (size_t)blockIdx.x * 16;
+    o[0] = st_begin; o[1] = st_loop_end; o[2] = __builtin_amdgcn_s_memtime();
+    o[3] = st_wait; o[4] = st_bar; o[5] = st_issue; o[6] = st_comp; o[7] = (unsigned long long)p.nk;
+    o[8] = st_rt_begin; o[9] = __builtin_amdgcn_s_memrealtime();  // 100 MHz reference clock
+  }
+#endif
+#undef VDQN_ST
+}
+
+}  // namespace
+
+#ifdef VDQN_STAMP
+extern void* g_stamp_buffer;
+#endif
+
+// entry used by vdqn_conv2d (igemm.hip): returns VDQN_OK or an error code
+template <int MODE, int BM>
+static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps) {
+  using G = Win9Geom<BM>;
+  const int wrows = (BM + 2 * p.wo + 2 + 1 + 7) & ~7;  // <= G::WinRows for W <= 28
+  const unsigned grid = (unsigned)(((p.M + BM - 1) / BM) * p.tiles_n);
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM>), (size_t)G::Smem);
+  hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
+                     make_fastdiv((uint32_t)p.howo), stamps);
+}
+
+int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
+  const IgemmParams& p = *reinterpret_cast<const IgemmParams*>(pv);
+  // VDQN_WIN9_BM256: 1 = 256-row tiles wherever the launch has more 128-row tiles than the chip holds at once (two per CU),
+  // 2 = always, 0 = never
+  static const int bm256 = [] { const char* e = getenv("VDQN_WIN9_BM256"); return e ? atoi(e) : 0; }();
+  const bool big = bm256 == 2 || (bm256 == 1 && (long long)p.tiles_m * p.tiles_n > 2ll * vdqn_num_cus());
+  void* stamps = nullptr;
+#ifdef VDQN_STAMP
+  stamps = g_stamp_buffer;
+#endif
+  vdqn_prof_begin(mode == 0 ? "igemm_win<bf16,128,fwd>" : "igemm_win<bf16,128,dgrad>", 2.0 * p.M * p.co * p.ktot,
+                  2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
+  if (mode == 0) {
+    if (big) launch_win9u<0, 256>(p, stream, stamps); else launch_win9u<0, 128>(p, stream, stamps);
+  } else {
+    if (big) launch_win9u<1, 256>(p, stream, stamps); else launch_win9u<1, 128>(p, stream, stamps);
+  }
+  vdqn_prof_end(stream);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}

@@ -11,6 +11,8 @@ import argparse
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises: see video_dqn_amd/__init__.py
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
