@@ -349,7 +349,15 @@ typedef struct vdqn_step_args {
   int32_t loss_kind;          /* vdqn_td_args.loss_kind (TD branch only) */
 } vdqn_step_args;
 int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream);
+/* Stage s of the backward pass (0: head + layer4, 1: layer3, 2: layer2, layer1, stem).  With the overlap on, the stage's weight
+ * gradients and the kernel that writes its range of `grads` run on the engine's side stream: after the call returns that range is
+ * complete on vdqn_net_grad_stream(net), NOT on `stream`, which goes straight on to the next stage's data gradients.  The call
+ * for stage 2 makes `stream` wait for the side stream, so vdqn_adam on `stream` sees every gradient.  A consumer of one stage's
+ * gradients (the data-parallel all-reduce) orders itself behind vdqn_net_grad_stream. */
 int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream);
+/* The HIP stream (hipStream_t) on which a stage's gradients become complete; NULL when the overlap is off (then it is the
+ * stream passed to vdqn_net_backward_stage). */
+void* vdqn_net_grad_stream(vdqn_net* net);
 
 #ifdef __cplusplus
 }

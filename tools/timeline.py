@@ -22,7 +22,8 @@ def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-    a, b = adam[-3], adam[-2]  # one full update between two Adam launches
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) // 2  # which update (default: the middle one: inside bench.py's timed region,
+    a, b = adam[k - 1], adam[k]                                   # not its serialised per-kernel profiling leg at the end)
     seg = rows[a + 1:b + 1]
     t0, t1 = int(rows[a]["End_Timestamp"]), int(rows[b]["End_Timestamp"])
     ev = []

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", f"libvdqn{'_' + os.environ['VDQN_LIB'] if os.environ.get('VDQN_LIB') else ''}.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -95,6 +95,7 @@ _SIGS = {
     "vdqn_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(c_vp)]),
     "vdqn_net_destroy": (None, [c_vp]),
     "vdqn_net_set_overlap": (C.c_int, [c_vp, C.c_int]),
+    "vdqn_net_grad_stream": (c_vp, [c_vp]),
     "vdqn_net_set_bn_sync": (C.c_int, [c_vp, c_vp, c_vp, c_i32]),
     "vdqn_net_num_params": (C.c_int, [c_vp]),
     "vdqn_net_param_info": (C.c_int, [c_vp, C.c_int, C.POINTER(ParamInfo)]),

@@ -29,7 +29,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 7; }
+extern "C" int vdqn_abi_version(void) { return 8; }
 
 namespace {
 
@@ -1365,6 +1365,11 @@ int block_backward_train(vdqn_net* net, const vdqn_step_args* a, int b, const Ac
 
 }  // namespace
 
+extern "C" void* vdqn_net_grad_stream(vdqn_net* net) {
+  if (!net || !side_ready(net)) return nullptr;
+  return (void*)net->side;
+}
+
 extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream) {
   VDQN_CHECK(net && a && a->grads, "vdqn_net_backward_stage: null arg");
   VDQN_CHECK(stage >= 0 && stage < 3, "vdqn_net_backward_stage: stage %d", stage);
@@ -1415,19 +1420,13 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     RC(block_backward(net, a, 4, A, W, n, st));
   } else {
     for (int b = 3; b >= 0; --b) RC(block_backward(net, a, b, A, W, n, st));
-    // g_pool is already masked by (pool > 0) in block 0's dgrad epilogue and c1[argmax] == pool, so the ReLU mask of c1 is implied
-    RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
-    // bn1's shift gradient = column sums of g_c1 = column sums of g_pool (max-pool routes every pooled gradient element
-    // to exactly one input position), which block 0's dgrad epilogue already produced as partials
+    // conv1's weight gradient is the last link of the chain (max-pool backward -> wgrad): the other layers of the stage are
+    // unfolded ahead of it
     split_conv1 = net->overlap && net->side && net->l_conv1 == net->layer_stage_first[2] && net->layer_stage_count[2] > 1;
-    if (split_conv1) join_side(net, st);  // the other layers' weight gradients: unfolded while conv1's (the last, 0.25 ms) still runs
-    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
   }
-  if (!split_conv1) join_side(net, st);  // every weight gradient of this stage is complete before it is unfolded
   int max_co = 0;
   for (int i = net->layer_stage_first[stage]; i < net->layer_stage_first[stage] + net->layer_stage_count[stage]; ++i)
     max_co = net->layers[i].co > max_co ? net->layers[i].co : max_co;
-  ProfScope ps_("unfold_grads", 0.0, (double)(net->stage_end[stage] - net->stage_begin[stage]) * 12.0, st);
   PartTable pt;
   memset(&pt, 0, sizeof(pt));
   if (!net->basic()) {
@@ -1452,16 +1451,38 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
       set(net->l_b_conv1[b], W.p_h[b], (int64_t)n * sp * sp, planes, 1, 0);
     }
   }
+  const bool stem_tail = stage == 2 && !net->basic();
+  auto conv1_chain = [&]() -> int {  // max-pool backward on the caller's stream, conv1's weight gradient behind it on the side stream
+    // g_pool is already masked by (pool > 0) in block 0's dgrad epilogue and c1[argmax] == pool, so the ReLU mask of c1 is implied
+    RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
+    // bn1's shift gradient = column sums of g_c1 = column sums of g_pool (max-pool routes every pooled gradient element
+    // to exactly one input position), which block 0's dgrad epilogue already produced as partials
+    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
+    return VDQN_OK;
+  };
+  if (stem_tail && !split_conv1) RC(conv1_chain());
+  // The unfold runs BEHIND the stage's weight gradients on the side stream (which first waits for the caller's stream: the
+  // column-sum partials come from the data-gradient epilogues there), so the caller's stream goes straight on to the next stage's
+  // data gradients; only stage 2 joins the side stream back (before Adam).  vdqn_net_grad_stream() is where a stage's range of
+  // `grads` is complete.
+  hipStream_t us = fork_side(net, st);  // == st when the overlap is off
+  const double unfold_bytes = (double)(net->stage_end[stage] - net->stage_begin[stage]) * 12.0;
   if (split_conv1) {
-    hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage] - 1), dim3(256), 0, st, net->fold, pt, net->layer_stage_first[stage] + 1,
-                       a->params, a->bnstats, (const unsigned char*)bw, a->grads, 0);
-    join_side(net, st);
-    hipLaunchKernelGGL(unfold_kernel, dim3(net->layers[net->l_conv1].co, 1), dim3(256), 0, st, net->fold, pt, net->l_conv1, a->params, a->bnstats,
+    {
+      ProfScope ps_("unfold_grads", 0.0, unfold_bytes, us);
+      hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage] - 1), dim3(256), 0, us, net->fold, pt, net->layer_stage_first[stage] + 1,
+                         a->params, a->bnstats, (const unsigned char*)bw, a->grads, 0);
+    }
+    RC(conv1_chain());
+    ProfScope ps_("unfold_grads", 0.0, 0.0, net->side);
+    hipLaunchKernelGGL(unfold_kernel, dim3(net->layers[net->l_conv1].co, 1), dim3(256), 0, net->side, net->fold, pt, net->l_conv1, a->params, a->bnstats,
                        (const unsigned char*)bw, a->grads, 0);
   } else {
-    hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, st, net->fold, pt, net->layer_stage_first[stage],
+    ProfScope ps_("unfold_grads", 0.0, unfold_bytes, us);
+    hipLaunchKernelGGL(unfold_kernel, dim3(max_co, net->layer_stage_count[stage]), dim3(256), 0, us, net->fold, pt, net->layer_stage_first[stage],
                        a->params, a->bnstats, (const unsigned char*)bw, a->grads, net->basic() ? 1 : 0);
   }
+  if (stage == 2) join_side(net, st);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
 }

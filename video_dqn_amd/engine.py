@@ -8,6 +8,7 @@ Mirrors the pieces of ``train_q_network.py`` that touch the device:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from collections import OrderedDict
@@ -265,6 +266,7 @@ class TDStepper:
             self._ones = torch.ones((batch, net.num_classes), dtype=torch.float32, device=dev)
         self.adam_step = 0
         self.sample_number = 0
+        self._grad_stream = None  # torch view of the engine's side stream (vdqn_net_grad_stream)
         self.stage_ranges = [net.stage_range(s) for s in range(3)]
         self.sync_target()
 
@@ -304,9 +306,20 @@ class TDStepper:
             for stage in range(3):
                 _lib.check(self.lib.vdqn_net_backward_stage(n.handle, C.byref(a), stage, st), "vdqn_net_backward_stage")
                 if self.allreduce is not None:
+                    # the stage's gradients are complete on the engine's gradient stream, not on `st` (which is already
+                    # running the next stage's data gradients): the collective is ordered behind that stream
                     b, e = self.stage_ranges[stage]
-                    self.allreduce(self.grads[b:e], stage)
+                    with self._grad_stream_ctx():
+                        self.allreduce(self.grads[b:e], stage)
         del keep
+
+    def _grad_stream_ctx(self):
+        ptr = self.lib.vdqn_net_grad_stream(self.net.handle)
+        if not ptr:
+            return contextlib.nullcontext()
+        if self._grad_stream is None or self._grad_stream.cuda_stream != ptr:
+            self._grad_stream = torch.cuda.ExternalStream(ptr, device=self.net.device)
+        return torch.cuda.stream(self._grad_stream)
 
     def optimizer_step(self):
         n = self.net
