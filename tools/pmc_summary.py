@@ -26,7 +26,7 @@ def tag_of(kernel_name: str):
             return f"stem_conv_pool<{dt}>"
         size = "256x64" if bm == 256 else str(bn)
         return f"igemm<{dt},{size},{('fwd', 'dgrad', 'dgrad_s2')[mode]}>"
-    m = re.search(r"win9u_kernel<(\d+)>", kernel_name)
+    m = re.search(r"win9u_kernel<(\d+)(?:, \d+)?>", kernel_name)
     if m:  # the unrolled nine-tap kernel (bf16 only), same tag
         return f"igemm_win<bf16,128,{('fwd', 'dgrad')[int(m[1])]}>"
     m = re.search(r"igemm_win9_kernel<(unsigned short|float), (\d+)>", kernel_name)
