@@ -181,6 +181,17 @@ int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, flo
 int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img,
                         int32_t dtype, void* stream);
 
+/* conv1's weight gradient straight from the POOLED gradient (the extra_capacity stem in bf16): what vdqn_maxpool_bwd(g_pool, idx)
+ * followed by vdqn_conv2d_wgrad on the packed stem geometry computes, without the 112 x 112 x 64 gradient of conv1's output
+ * ever being stored (autograd's max_pool2d backward + conv1 weight gradient behind loss.backward(), train_q_network.py:226;
+ * torchvision resnet stem reached from archs/HabitatDQNMultiAction.py:30).  g_pool [n][56][56][64] bf16, idx as written by
+ * vdqn_stem_conv_pool / vdqn_maxpool_fwd, t_in the packed frames of vdqn_pack_input; dw [64][4][64] f32 is ACCUMULATED into
+ * (f32 atomics; with a workspace of vdqn_stem_wgrad_pool_workspace_bytes(n_img) bytes: per-block partial copies summed in
+ * block order = deterministic).  The gradient tiles the kernel builds in LDS are bit-identical to vdqn_maxpool_bwd's output. */
+int vdqn_stem_wgrad_pool(const void* g_pool, const uint8_t* idx, const void* t_in, float* dw, int32_t n_img, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+int64_t vdqn_stem_wgrad_pool_workspace_bytes(int32_t n_img);
+
 /* Row-wise softmax over the first n_valid columns of x[rows][ld] (f32), written to y[rows][ld] (other columns 0):
  * `torch.softmax(x, dim=1)` of the inverse-action model's 3-way output (archs/inverse_action2.py:95). n_valid <= 64. */
 int vdqn_softmax_rows(const float* x, float* y, int32_t rows, int32_t ld, int32_t n_valid, void* stream);

@@ -288,6 +288,30 @@ def test_stem_pack_conv1_maxpool(dtype, src_kind):
     assert relerr(got, wref) < TOL_F32OUT[dtype]
 
 
+@pytest.mark.parametrize("n", [2, 5])
+def test_stem_wgrad_from_pooled_gradient(n):
+    """vdqn_stem_wgrad_pool (max-pool backward fused into conv1's weight gradient) == vdqn_maxpool_bwd + vdqn_conv2d_wgrad."""
+    from video_dqn_amd import ops
+    dtype = torch.bfloat16
+    frames = synth.make_frames_uint8(5, "f", n, 1, structured=True)
+    packed = ops.pack_input(torch.from_numpy(frames[:, 0]).to(DEV), 0, n, dtype)
+    w7 = q(rnd(2, "w7", (64, 3, 7, 7), -0.2, 0.2), dtype)
+    pool, idx = ops.stem_conv_pool(packed, s2d_weights(w7, dtype), rnd(3, "b", (64,)).to(DEV))
+    g_pool = nhwc(q(rnd(11, "gp", (n, 64, 56, 56), -1, 1), dtype), dtype)
+    g_pool = torch.where(pool > 0, g_pool, torch.zeros_like(g_pool))  # as block 0's data gradient leaves it
+    g_c1 = ops.maxpool_bwd(g_pool, idx, None, (112, 112))
+    ref = ops.conv2d_wgrad(g_c1, packed, co=64, r=4, s=1, stride=1, pad=0, ci=64, pix_stride=16, want_dbias=False)
+    got = ops.stem_wgrad_pool(g_pool, idx, packed)
+    det1 = ops.stem_wgrad_pool(g_pool, idx, packed, deterministic=True)
+    det2 = ops.stem_wgrad_pool(g_pool, idx, packed, deterministic=True)
+    torch.cuda.synchronize()
+    assert float(ref.abs().max()) > 0
+    # same products, same bf16 gradient tiles: only the f32 summation order differs
+    assert relerr(got.cpu().view(-1), ref.cpu().view(-1)) < 1e-5
+    assert relerr(det1.cpu().view(-1), ref.cpu().view(-1)) < 1e-5
+    assert torch.equal(det1, det2)
+
+
 def test_td_loss_branches_vs_golden(golden):
     """The fused TD kernel against the goldens produced by the reference's own process_batch statements."""
     from video_dqn_amd import ops

@@ -41,6 +41,8 @@ def tag_of(kernel_name: str):
     m = re.search(r"wgrad_kernel<(unsigned short|float), (\d+)>", kernel_name)
     if m:
         return f"wgrad<{'bf16' if m[1] == 'unsigned short' else 'f32'},{m[2]}>"
+    if "stem_wgrad_pool_kernel" in kernel_name:
+        return "wgrad_stem_pool<bf16>"
     if "stem_wgrad_kernel" in kernel_name:
         return "wgrad_stem<bf16>"
     if "pack_input" in kernel_name:

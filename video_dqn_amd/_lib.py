@@ -94,6 +94,8 @@ _SIGS = {
     "vdqn_avgpool_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(c_vp)]),
     "vdqn_net_destroy": (None, [c_vp]),
+    "vdqn_stem_wgrad_pool": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "vdqn_stem_wgrad_pool_workspace_bytes": (c_i64, [c_i32]),
     "vdqn_net_set_overlap": (C.c_int, [c_vp, C.c_int]),
     "vdqn_net_grad_stream": (c_vp, [c_vp]),
     "vdqn_net_set_bn_sync": (C.c_int, [c_vp, c_vp, c_vp, c_i32]),

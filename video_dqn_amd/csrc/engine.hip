@@ -1452,12 +1452,22 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     }
   }
   const bool stem_tail = stage == 2 && !net->basic();
-  auto conv1_chain = [&]() -> int {  // max-pool backward on the caller's stream, conv1's weight gradient behind it on the side stream
-    // g_pool is already masked by (pool > 0) in block 0's dgrad epilogue and c1[argmax] == pool, so the ReLU mask of c1 is implied
-    RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
+  auto conv1_chain = [&]() -> int {  // conv1's weight gradient from the pooled gradient g_pool
+    // g_pool is already masked by (pool > 0) in block 0's dgrad epilogue and c1[argmax] == pool, so the ReLU mask of c1 is implied.
     // bn1's shift gradient = column sums of g_c1 = column sums of g_pool (max-pool routes every pooled gradient element
-    // to exactly one input position), which block 0's dgrad epilogue already produced as partials
-    RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
+    // to exactly one input position), which block 0's dgrad epilogue already produced as partials.
+    const Layer& L1 = net->layers[net->l_conv1];
+    // bf16: ONE kernel on the side stream builds the max-pool backward tiles in LDS (VDQN_FUSE_POOL_BWD=0: the two launches below)
+    static const bool fuse_pool = [] { const char* e = getenv("VDQN_FUSE_POOL_BWD"); return !(e && e[0] == '0'); }();
+    const int64_t det_need = net->cfg.deterministic ? vdqn_stem_wgrad_pool_workspace_bytes(n) : 0;
+    if (fuse_pool && dt == VDQN_BF16 && (int64_t)n * 115 * 115 * 32 < (1ll << 31) && det_need <= W.det_ws_bytes) {
+      prof_layer(L1, n);
+      return vdqn_stem_wgrad_pool(bw + W.g_pool, ao + A.idx, ao + A.t_in, reinterpret_cast<float*>(bw + L1.dw_off), n,
+                                  net->cfg.deterministic ? bw + W.det_ws : nullptr, W.det_ws_bytes, fork_side(net, st));
+    }
+    // max-pool backward on the caller's stream, the weight gradient behind it on the side stream
+    RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
+    RC(run_wgrad(net, L1, bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
     return VDQN_OK;
   };
   if (stem_tail && !split_conv1) RC(conv1_chain());

@@ -726,6 +726,212 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16raw* __res
         wg_emit((ws ? ws + (size_t)blockIdx.x * (64 * 256) : dw) + (size_t)(f * 16 + grp * 4 + reg) * 256 + ky * 64 + kx * 16 + i16, ws != nullptr, acc[f][kx][reg]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The stem's weight gradient straight from the POOLED gradient (bf16): max-pool backward fused into the staging of
+// stem_wgrad_kernel's gradient operand.  Unfused, the 112 x 112 x 64 gradient of conv1's output — three quarters of it zeros —
+// is written by vdqn_maxpool_bwd (411 MB at batch 256) and read back by the weight-gradient kernel: the two HBM-bound launches
+// at the very end of an update's backward chain.  Here a workgroup walks pooled rows k of one image: conv rows 2k and 2k + 1
+// receive gradient only from pooled rows k and k + 1 (3 x 3 / stride 2 / pad 1 windows), which sit in LDS (gradient + arg-max
+// codes, one new row per step by LDS-DMA); the two 112 x 64 gradient tiles are built from them with the arithmetic of
+// maxpool_bwd_rows_kernel (f32 sum of the <= 4 windows whose arg-max is the pixel, one rounding: the tiles are bit-identical to
+// the unfused tensor) and consumed by the MFMA loop of stem_wgrad_kernel (wave ky, packed input rows 2k + hr + ky, kx shifts).
+// Per step and workgroup: [A] barrier | packed-row DMA issued, tiles built (VALU) | [B] barrier | next pooled row's DMA issued,
+// 128 MFMAs per wave.  Two workgroups per CU: one's VALU phase runs beside the other's MFMA phase.
+// HBM per update: pooled gradient + codes + packed frames = 231 MB instead of 1.27 GB for the two launches.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSpPoolG = 56 * 128;                 // a pooled gradient row: 56 pixels x 64 channels bf16 (7 DMA pieces)
+constexpr int kSpPoolI = 4096;                     // its arg-max codes, 56 x 64 bytes, staged as 4 pieces (the last one half used)
+constexpr int kSpPoolRow = kSpPoolG + kSpPoolI;
+constexpr int kSpGy = 2 * kSwGyBytes;              // gradient tiles of conv rows 2k, 2k + 1
+constexpr int kSpX = 5 * kSwXRow;                  // packed input rows 2k .. 2k + 4
+constexpr int kSpSmem = 2 * kSpPoolRow + kSpGy + kSpX;  // 76416 bytes: two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_pool_kernel(const bf16raw* __restrict__ g_pool, const uint8_t* __restrict__ idx,
+                                                                 const bf16raw* __restrict__ x, float* __restrict__ dw, int pairs_per_block,
+                                                                 int blocks_per_img, int gp_bytes, int idx_bytes, int x_bytes, float* __restrict__ ws) {
+  using T = bf16raw;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sPool = smem;                       // [2][kSpPoolRow]: pooled row r lives in slot r & 1
+  unsigned char* sGy = smem + 2 * kSpPoolRow;        // [2][kSwGyBytes]
+  unsigned char* sX = sGy + kSpGy;                   // [5][kSwXRow]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ky = __builtin_amdgcn_readfirstlane(wave);  // wave = kernel row in the MFMA phase
+  const int img = blockIdx.x / blocks_per_img;
+  const int k0 = (blockIdx.x - img * blocks_per_img) * pairs_per_block;
+  const int k1 = min(56, k0 + pairs_per_block);
+  if (k0 >= k1) return;
+  // what the DMA / the builder never write: gradient rows 112..127 of both tiles, the tail of every packed row; and the pooled-row
+  // slots, so that a slot no row was ever staged into (pooled row 56) holds arg-max codes of 0, not whatever LDS held
+  for (int i = tid; i < 2 * 128 + 5 * 8; i += 256) {
+    unsigned char* d = i < 256 ? sGy + (i >> 7) * kSwGyBytes + 112 * 128 + (i & 127) * 16 : sX + ((i - 256) >> 3) * kSwXRow + 4096 + ((i - 256) & 7) * 16;
+    *reinterpret_cast<uint4*>(d) = make_uint4(0, 0, 0, 0);
+  }
+  for (int i = tid; i < 2 * kSpPoolRow / 16; i += 256) reinterpret_cast<uint4*>(sPool)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();  // before the first LDS-DMA lands in a slot
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long g_ptr = (unsigned long long)g_pool, i_ptr = (unsigned long long)idx, x_ptr = (unsigned long long)x;
+  const i32x4 rs_g = {__builtin_amdgcn_readfirstlane((int)(unsigned)g_ptr), __builtin_amdgcn_readfirstlane((int)((g_ptr >> 32) & 0xffff)), gp_bytes, 0x00020000};
+  const i32x4 rs_i = {__builtin_amdgcn_readfirstlane((int)(unsigned)i_ptr), __builtin_amdgcn_readfirstlane((int)((i_ptr >> 32) & 0xffff)), idx_bytes, 0x00020000};
+  const i32x4 rs_x = {__builtin_amdgcn_readfirstlane((int)(unsigned)x_ptr), __builtin_amdgcn_readfirstlane((int)((x_ptr >> 32) & 0xffff)), x_bytes, 0x00020000};
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+#define VDQN_SP_DMA(VOFF, LDS, RSRC)                                                                                   \
+  {                                                                                                                    \
+    const uint32_t l_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(LDS));                                           \
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(VOFF), "s"(l_), "s"(RSRC) : "memory"); \
+  }
+  // pooled row r of this image -> slot r & 1: 7 gradient pieces + 4 code pieces of 1 KiB, piece p by wave p & 3
+  auto issue_pool = [&](int r) {
+    if (r >= 56) return;
+    const uint32_t px0 = (uint32_t)((img * 56 + r) * 56);
+    const uint32_t slot = lds_base + (uint32_t)((r & 1) * kSpPoolRow);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int pc = ky + 4 * i;  // wave-uniform
+      if (pc < 7) {
+        VDQN_SP_DMA(px0 * 128u + (uint32_t)(pc * 1024) + lane16, slot + (uint32_t)(pc * 1024), rs_g)
+      } else if (pc < 11) {
+        VDQN_SP_DMA(px0 * 64u + (uint32_t)((pc - 7) * 1024) + lane16, slot + (uint32_t)(kSpPoolG + (pc - 7) * 1024), rs_i)
+      }
+    }
+  };
+  // packed input rows 2k .. 2k + 4 (each 128 packed pixels x 32 B; 115 are real, the rest runs into the next row and meets
+  // gradient rows that are zero): 20 pieces, piece p by wave p & 3
+  auto issue_x = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int pc = ky + 4 * i;
+      const int row = pc >> 2, j = pc & 3;
+      VDQN_SP_DMA((uint32_t)((img * 115 + 2 * k + row) * 115) * 32u + (uint32_t)(j * 1024) + lane16, lds_base + (uint32_t)(2 * kSpPoolRow + kSpGy + row * kSwXRow + j * 1024), rs_x)
+    }
+  };
+#undef VDQN_SP_DMA
+  // gradient tiles of conv rows 2k (hr = 0) and 2k + 1 (hr = 1).  An item is (conv row, pixel w, 8-channel group); row 2k only
+  // receives from pooled row k (window row kh = 1), row 2k + 1 from pooled rows k (kh = 2) and k + 1 (kh = 0); an even pixel
+  // w = 2 j lies in window column j only (dx = 1), an odd one in columns j (dx = 2) and j + 1 (dx = 0).  The 4 x 448 items are
+  // dealt to the waves in runs of 64 of ONE (row, pixel parity) class, so the candidate windows of a run — 1, 2, 2 or 4, each with
+  // a constant arg-max code to match — are the same for every lane: 7 runs per wave and step.  Sums in f32 in the order of
+  // maxpool_bwd_rows_kernel (pooled row, then window column), one rounding.
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  auto add8 = [&](float (&sacc)[8], const unsigned char* slot, int ow, int cg, uint32_t tap) {
+    const uint4 gv = *reinterpret_cast<const uint4*>(slot + ow * 128 + cg * 16);
+    const uint2 iv = *reinterpret_cast<const uint2*>(slot + kSpPoolG + ow * 64 + cg * 8);
+    const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
+    const uint32_t xw[2] = {iv.x ^ (tap * 0x01010101u), iv.y ^ (tap * 0x01010101u)};  // a zero byte = a channel whose arg-max is this tap
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+      // the two code bytes of channels 2 pq, 2 pq + 1 spread to 16-bit halves; min(., 1) - 1 = 0xffff where the byte is zero
+      const uint32_t t = __builtin_amdgcn_perm(0u, xw[pq >> 1], (pq & 1) ? 0x0c030c02u : 0x0c010c00u);
+      const u16x2 m = __builtin_elementwise_min(__builtin_bit_cast(u16x2, t), (u16x2){1, 1}) - (u16x2){1, 1};
+      const uint32_t mg = gw[pq] & __builtin_bit_cast(uint32_t, m);
+      sacc[2 * pq] += __uint_as_float(mg << 16);
+      sacc[2 * pq + 1] += __uint_as_float(mg & 0xffff0000u);
+    }
+  };
+  auto build = [&](int k) {
+    const bool two = k + 1 < 56;
+    const unsigned char* s0 = sPool + (k & 1) * kSpPoolRow;        // pooled row k
+    const unsigned char* s1 = sPool + ((k + 1) & 1) * kSpPoolRow;  // pooled row k + 1
+#pragma unroll 1
+    for (int i = 0; i < 7; ++i) {
+      const int run = ky + 4 * i;   // wave-uniform, 0..27
+      const int cls = run / 7;      // 0: row 2k, even w | 1: row 2k, odd w | 2: row 2k + 1, even w | 3: row 2k + 1, odd w
+      const int j = (run - cls * 7) * 64 + lane;
+      const int cg = j & 7, jp = j >> 3;
+      // a window that does not exist (column 56, pooled row 56) is read at a clamped address against a code no arg-max has:
+      // no branches inside a run, so its LDS reads are all in flight before the first is used
+      const int jr = min(jp + 1, 55);
+      const uint32_t no = 0xffu;
+      const bool right = jp + 1 < 56;
+      float sacc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sacc[e] = 0.f;
+      if (cls == 0) {
+        add8(sacc, s0, jp, cg, 4);
+      } else if (cls == 1) {
+        add8(sacc, s0, jp, cg, 5);
+        add8(sacc, s0, jr, cg, right ? 3u : no);
+      } else if (cls == 2) {
+        add8(sacc, s0, jp, cg, 7);
+        add8(sacc, s1, jp, cg, two ? 1u : no);
+      } else {
+        add8(sacc, s0, jp, cg, 8);
+        add8(sacc, s0, jr, cg, right ? 6u : no);
+        add8(sacc, s1, jp, cg, two ? 2u : no);
+        add8(sacc, s1, jr, cg, (two && right) ? 0u : no);
+      }
+      const int w = 2 * jp + (cls & 1);
+      T ov[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(sacc[e]);
+      *reinterpret_cast<uint4*>(sGy + (cls >> 1) * kSwGyBytes + w * 128 + ((cg ^ wg_swz<T, 64>(w)) << 4)) = *reinterpret_cast<const uint4*>(ov);
+    }
+  };
+
+  f32x4 acc[4][4];  // [co fragment][kx]
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int grp = lane >> 4, i16 = lane & 15;
+  const int q = i16 >> 2, pp = i16 & 3;
+  const int row = 4 * grp + q;  // pixel row (of 32) this lane addresses in a transposing read; the high half is 16 rows on
+  const int sz = wg_swz<T, 64>(row);
+  int offa[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) offa[f] = row * 128 + (((((f * 16) >> 3) + (pp >> 1)) ^ sz) << 4) + ((pp & 1) << 3);
+  const int offb = row * 32 + pp * 8;
+
+  issue_pool(k0);
+  issue_pool(k0 + 1);
+  for (int k = k0; k < k1; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // [A] pooled rows k, k + 1 are in LDS; every wave is done with the tiles and the packed rows of step k - 1
+    issue_x(k);
+    build(k);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // [B] tiles built, packed rows landed; pooled row k is no longer read
+    if (k + 1 < k1) issue_pool(k + 2);
+#pragma unroll 1
+    for (int hr = 0; hr < 2; ++hr) {
+      const unsigned char* a = sGy + hr * kSwGyBytes;
+      const unsigned char* b = sX + (hr + ky) * kSwXRow;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        s16x8 af[4], bfr[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const unsigned char* pa = a + sub * (32 * 128) + offa[f];
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 16 * 128));
+          af[f] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const unsigned char* pb = b + (sub * 32 + kx) * 32 + offb;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pb);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + 16 * 32));
+          bfr[kx] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx)
+            acc[f][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bfr[kx]), acc[f][kx], 0, 0, 0);
+      }
+    }
+  }
+  // C layout: col (lane & 15) -> kx*16 + c, row ((lane >> 4) * 4 + reg) -> co
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        wg_emit((ws ? ws + (size_t)blockIdx.x * (64 * 256) : dw) + (size_t)(f * 16 + grp * 4 + reg) * 256 + ky * 64 + kx * 16 + i16, ws != nullptr, acc[f][kx][reg]);
+}
+
 // deterministic mode, second stage: dw[i] += ws[0][i] + ws[1][i] + ... in split order (one thread per 4 elements)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n4, int n_splits,
                                                            long long ws_stride) {
@@ -916,6 +1122,56 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
       hipLaunchKernelGGL((colsum_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)a->gy, a->dbias, p.M, co_pad, a->ldg, rpb);
     vdqn_prof_end(st);
     VDQN_LAUNCH_CHECK();
+  }
+  return VDQN_OK;
+}
+
+namespace {
+// blocks of stem_wgrad_pool_kernel: whole pooled-row ranges of ONE image each, about 512 blocks in all
+void stem_pool_grid(int n_img, int* pairs_per_block, int* blocks_per_img) {
+  int bpi = 512 / n_img;
+  bpi = bpi < 1 ? 1 : (bpi > 56 ? 56 : bpi);
+  *pairs_per_block = (56 + bpi - 1) / bpi;
+  *blocks_per_img = (56 + *pairs_per_block - 1) / *pairs_per_block;
+}
+}  // namespace
+
+extern "C" int64_t vdqn_stem_wgrad_pool_workspace_bytes(int32_t n_img) {
+  if (n_img <= 0) return 0;
+  int ppb, bpi;
+  stem_pool_grid(n_img, &ppb, &bpi);
+  return (int64_t)n_img * bpi * 64 * 256 * 4;
+}
+
+extern "C" int vdqn_stem_wgrad_pool(const void* g_pool, const uint8_t* idx, const void* t_in, float* dw, int32_t n_img, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  VDQN_CHECK(g_pool && idx && t_in && dw && n_img > 0, "vdqn_stem_wgrad_pool: bad args");
+  const int64_t gp_bytes = (int64_t)n_img * 56 * 56 * 64 * 2, idx_bytes = (int64_t)n_img * 56 * 56 * 64, x_bytes = (int64_t)n_img * 115 * 115 * 16 * 2;
+  VDQN_CHECK(x_bytes < (1ll << 31) && gp_bytes < (1ll << 31), "vdqn_stem_wgrad_pool: %d images exceed the 2 GiB operand range (split the batch)", n_img);
+  int ppb, bpi;
+  stem_pool_grid(n_img, &ppb, &bpi);
+  const int grid = n_img * bpi;
+  float* ws = nullptr;
+  if (workspace) {
+    VDQN_CHECK(workspace_bytes >= vdqn_stem_wgrad_pool_workspace_bytes(n_img), "vdqn_stem_wgrad_pool: workspace of %lld bytes, need %lld",
+               (long long)workspace_bytes, (long long)vdqn_stem_wgrad_pool_workspace_bytes(n_img));
+    ws = reinterpret_cast<float*>(workspace);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&stem_wgrad_pool_kernel), (size_t)kSpSmem);
+  const double M = (double)n_img * 112 * 112;
+  vdqn_prof_begin("wgrad_stem_pool<bf16>", 2.0 * M * 64 * 147, (double)gp_bytes + (double)idx_bytes + (double)x_bytes + 4.0 * 64 * 256, st);
+  hipLaunchKernelGGL(stem_wgrad_pool_kernel, dim3(grid), dim3(256), kSpSmem, st, (const bf16raw*)g_pool, idx, (const bf16raw*)t_in, dw, ppb, bpi, (int)gp_bytes,
+                     (int)idx_bytes, (int)x_bytes, ws);
+  vdqn_prof_end(st);
+  VDQN_LAUNCH_CHECK();
+  if (ws) {
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.ws = ws;
+    p.dw = dw;
+    p.ws_stride = 64 * 256;
+    return launch_wgrad_reduce(p, grid, 64 * 256, st);
   }
   return VDQN_OK;
 }

@@ -112,12 +112,32 @@ def maxpool_fwd(x: torch.Tensor):
     return out, idx
 
 
-def maxpool_bwd(gy: torch.Tensor, idx: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def maxpool_bwd(gy: torch.Tensor, idx: torch.Tensor, x: Optional[torch.Tensor] = None, out_hw=None) -> torch.Tensor:
+    """x given: the gradient is also masked by x > 0 (the ReLU in front of the pool); x None: plain unpooling into out_hw."""
     lib = _lib.load()
-    n, hi, wi, c = x.shape
-    gx = torch.empty_like(x)
-    _lib.check(lib.vdqn_maxpool_bwd(_ptr(gy), _ptr(idx), _ptr(x), _ptr(gx), n, hi, wi, c, dtype_code(x), _stream()), "vdqn_maxpool_bwd")
+    if x is not None:
+        n, hi, wi, c = x.shape
+        gx = torch.empty_like(x)
+    else:
+        n, _, _, c = gy.shape
+        hi, wi = out_hw
+        gx = torch.empty((n, hi, wi, c), dtype=gy.dtype, device=gy.device)
+    _lib.check(lib.vdqn_maxpool_bwd(_ptr(gy), _ptr(idx), _ptr(x), _ptr(gx), n, hi, wi, c, dtype_code(gy), _stream()), "vdqn_maxpool_bwd")
     return gx
+
+
+def stem_wgrad_pool(g_pool: torch.Tensor, idx: torch.Tensor, t_in: torch.Tensor, deterministic: bool = False) -> torch.Tensor:
+    """conv1's weight gradient from the pooled gradient: g_pool [n,56,56,64] bf16, idx uint8 (stem_conv_pool / maxpool_fwd),
+    t_in [n,115,115,16] (pack_input) -> dw f32 [64,4,1,64] == conv2d_wgrad(maxpool_bwd(g_pool, idx), t_in) on the stem geometry."""
+    lib = _lib.load()
+    n = g_pool.shape[0]
+    dw = torch.zeros((64, 4, 1, 64), dtype=torch.float32, device=g_pool.device)
+    ws, nbytes = None, 0
+    if deterministic:
+        nbytes = lib.vdqn_stem_wgrad_pool_workspace_bytes(n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=g_pool.device)
+    _lib.check(lib.vdqn_stem_wgrad_pool(_ptr(g_pool), _ptr(idx), _ptr(t_in), _ptr(dw), n, _ptr(ws), nbytes, _stream()), "vdqn_stem_wgrad_pool")
+    return dw
 
 
 LOSS_KINDS = {"l2": 0, "huber": 1}  # vdqn_td_args.loss_kind
