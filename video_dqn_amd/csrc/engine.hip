@@ -1236,11 +1236,12 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
     RC(forward_train_impl(net, (const unsigned char*)a->packed_online, a->params, a->bnstats, ao + A.t_in, ns_online, gtb ? 1 : 2, ao, A, st));
   else {
-    // The online pass over [before; after] as two independent half-batch passes on two streams (BatchNorm in eval mode: samples
-    // are independent, each half is bit-identical to its part of the 2B pass).  With the target pass that makes three concurrent
-    // kernel chains walking the same layers: their tiles fill each other's tail rounds (a 256-frame launch of layer3 / layer4 is
-    // 1.5 / 0.77 rounds of workgroups on its own).  VDQN_SPLIT_ONLINE=0 keeps the single 2B pass.
-    static const bool split = [] { const char* e = getenv("VDQN_SPLIT_ONLINE"); return !(e && e[0] == '0'); }();
+    // VDQN_SPLIT_ONLINE=1: the online pass over [before; after] as two independent half-batch passes on two streams (BatchNorm in
+    // eval mode: samples are independent, each half is bit-identical to its part of the 2B pass); with the target pass that
+    // makes three concurrent kernel chains walking the same layers, whose tiles fill each other's tail rounds.  Measured on
+    // alternating runs (profiles/r02n_split_online_ab.txt) it is 6.04-6.06 ms per update in some processes and 6.27-6.33 in others
+    // (the two equal chains either interleave or fall into step), against a steady 6.10-6.15 for the single 2B pass: off by default.
+    static const bool split = [] { const char* e = getenv("VDQN_SPLIT_ONLINE"); return e && e[0] == '1'; }();
     hipStream_t s2 = (split && !gtb) ? fork_side2(net, st) : st;
     if (s2 != st) {
       const ActLayout A2 = shift_layout(net, A, B);
