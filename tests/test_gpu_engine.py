@@ -3,6 +3,9 @@
 
 Tolerance: north_star's 1e-3 relative (fp32) — applied per tensor relative to the tensor's max |value|.
 The bf16 throughput mode is compared with the same fp32 oracle at a looser, stated tolerance."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -430,3 +433,20 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     d2 = ops.conv2d_wgrad(gy, t_in, deterministic=True, **kw)
     torch.cuda.synchronize()
     assert torch.equal(d1, d2) and relerr(d1, a) < 1e-5
+
+
+@pytest.mark.parametrize("env", [
+    {"VDQN_SPLIT_ONLINE": "1"},       # online forward as two half-batch passes on two streams
+    {"VDQN_FUSE_POOL_BWD": "0"},      # max-pool backward + stem weight gradient as two launches
+    {"VDQN_WIN9_BM256": "2"},         # 256-row tiles of the nine-tap window kernel
+    {"VDQN_FUSE_DS": "3"},            # 1x1 downsample fused into its sibling 3x3/2 in the forward pass too
+], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_non_default_kernel_selections(env):
+    """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and
+    determinism tests green: re-run them in a child process with the switch set."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_engine.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "td_step_matches_oracle_all_elements or side_stream_overlap or deterministic_mode_is_bit_identical"],
+                       env=dict(os.environ, **env), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
