@@ -462,6 +462,35 @@ def test_conv64_persistent_kernel_geometries(geom):
     assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
 
 
+def test_nine_tap_window_kernel_persistent_tiles():
+    """More than two rounds of resident workgroups (1176 tiles of 128 x 128 at 192 images of 28 x 28 x 128): the launch is
+    persistent — every workgroup walks several tiles, the next tile's first K-steps staged under the current tile's last steps and
+    epilogue (whose column-sum scratch then lives in the second window buffer).  Forward (residual + ReLU) and data gradient
+    (mask + column sums) against torch on the same bf16 operands."""
+    from video_dqn_amd import ops
+    n, h, ci, co = 192, 28, 128, 128
+    dtype = torch.bfloat16
+    x = q(rnd(31, "x", (n, ci, h, h)), dtype)
+    w = q(rnd(32, "w", (co, ci, 3, 3), -0.1, 0.1), dtype)
+    b = rnd(33, "b", (co,))
+    res = q(rnd(34, "r", (n, co, h, h)), dtype)
+    ref = F.relu(F.conv2d(x, w, b, 1, 1) + res)
+    out = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=h, wo=h, co=co, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
+    torch.cuda.synchronize()
+    assert relerr(out.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    gy = q(rnd(35, "gy", (n, co, h, h)), dtype)
+    xact = q(rnd(36, "xa", (n, ci, h, h)), dtype)
+    refg = F.grad.conv2d_input((n, ci, h, h), w, gy, 1, 1) * (xact > 0)
+    wd = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)
+    got, part = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=h, co=ci, r=3, s=3, stride=1, pad=1, mode=1, mask=nhwc(xact, dtype), want_colsum=True)
+    torch.cuda.synchronize()
+    assert relerr(got.float().cpu().permute(0, 3, 1, 2), refg) < TOL[dtype]
+    assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
+    _, got0 = ops.conv2d(nhwc(gy, dtype), wd, ho=h, wo=h, co=ci, r=3, s=3, stride=1, pad=1, mode=1, want_f32=True)
+    torch.cuda.synchronize()
+    assert relerr(got0.cpu().permute(0, 3, 1, 2), F.grad.conv2d_input((n, ci, h, h), w, gy, 1, 1)) < TOL_F32OUT[dtype]
+
+
 @pytest.mark.parametrize("geom", [(3, 10, 6), (2, 5, 17), (5, 28, 28)])
 def test_nine_tap_window_kernel_nonsquare(geom):
     """bf16 3x3 convs with 128-column tiles run igemm_win9 (one staged window per channel chunk for all nine taps): non-square

@@ -45,7 +45,7 @@ struct Win9Geom {
 };
 
 template <int MODE, int BM>
-__global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, const int wrows, const FastDiv d_wo, const FastDiv d_howo, void* stamps) {
+__global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, const int wrows, const FastDiv d_wo, const FastDiv d_howo, const uint32_t total_tiles, void* stamps) {
   static_assert(MODE == 0 || MODE == 1, "window kernel: forward or stride-1 data gradient");
   static_assert(BM == 128 || BM == 256, "tile rows");
   using T = bf16raw;  // (VDQN_INTERLEAVE keys on sizeof(T))
@@ -59,9 +59,18 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = (int)(lb % (uint32_t)p.tiles_n), tile_m = (int)(lb / (uint32_t)p.tiles_n);
-  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  // Tiles of this workgroup.  The launch has either one workgroup per tile or (VDQN_WIN9_PERSIST) as many as the chip holds at
+  // once, each walking several tiles: workgroups of XCD x = blockIdx & 7 own that XCD's contiguous range of logical tiles
+  // (xcd_remap's ranges), workgroup j of the XCD takes tiles j, j + nb_x, j + 2 nb_x, ... of the range.
+  const uint32_t xcd = blockIdx.x & 7u;
+  const uint32_t tq = total_tiles >> 3, tr = total_tiles & 7u;
+  const uint32_t x_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;  // first logical tile of this XCD
+  const uint32_t x_count = tq + (xcd < tr ? 1u : 0u);
+  const uint32_t x_blocks = (gridDim.x >> 3) + (xcd < (gridDim.x & 7u) ? 1u : 0u);       // workgroups on this XCD
+  uint32_t lt = blockIdx.x >> 3;                                                          // index inside the XCD's range
+  if (lt >= x_count) return;
+  int tile_n = (int)((x_first + lt) % (uint32_t)p.tiles_n), tile_m = (int)((x_first + lt) / (uint32_t)p.tiles_n);
+  int n0 = tile_n * BN, m0 = tile_m * BM;
   const int W = p.wo, H = p.ho, rows_total = p.M;
   const int lrow = tid >> 3;
   const int lchunk_a = (tid & 7) ^ (lrow & 7);
@@ -79,11 +88,11 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   // the K loop needs the VGPRs for two fragment sets and the per-tap addresses ----
   const int pixB = p.pix_stride * 2;
   const int need = BM + 2 * W + 2;
-  const int q0 = m0 - W - 1 + lrow;  // input pixel of window row lrow
+  int q0 = m0 - W - 1 + lrow;  // input pixel of window row lrow (of the current tile)
   const uint32_t a_lane = (uint32_t)(lchunk_a * 16);
   // weight rows lrow + RPP i: one per-lane offset, the row stride goes into the DMA's scalar offset (the weight tensor holds all
   // 128 rows of the column tile, so no range check is involved)
-  const uint32_t b_off0 = (uint32_t)(n0 + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
+  uint32_t b_off0 = (uint32_t)(n0 + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
   const int b_row32 = G::RPP * p.ktot * 2;
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -102,11 +111,11 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
       : "memory", "scc")
   // activation window of channel chunk CC -> window buffer WBUF: WPass passes of RPP rows (a window buffer has WinRows rows whatever
   // W is; rows past BM + 2 W + 2 get an out-of-range offset and are zero-filled, the last of them is the zero row)
-#define VDQN_ISSUE_AW(WBUF, CC)                                                                                     \
+#define VDQN_ISSUE_AW(WBUF, SO_A, Q0)                                                                                   \
   {                                                                                                                 \
     const uint32_t la_ = lds_wave + (uint32_t)(kU_WinBase + (WBUF)*kU_WinStride);                                   \
-    const int so_a_ = (CC)*128;                                                                                     \
-    int q_ = q0;                                                                                                    \
+    const int so_a_ = (SO_A);                                                                                       \
+    int q_ = (Q0);                                                                                                  \
     asm volatile("" : "+v"(q_)); /* rebuilt here, not hoisted into loop-carried registers */                         \
     uint32_t a_off[G::WPass];                                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < G::WPass; ++i_) {                                                       \
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
                    ::"v"(a_off[4]), "s"(l4_), "s"(rs_a), "s"(so_a_) : "memory");                                    \
     }                                                                                                               \
   }
-#define VDQN_ISSUE_B(BUF, SOFF)                                                                                     \
+#define VDQN_ISSUE_B(BUF, SOFF, BOFF)                                                                                   \
   {                                                                                                                 \
     const uint32_t lb_ = lds_wave + (uint32_t)((BUF)*kU_WtTile);                                                    \
     const int so0_ = (SOFF), so1_ = so0_ + b_row32;                                                                 \
@@ -137,35 +146,35 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
           "s_add_u32 m0, %1, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds\n\t"                        \
           "s_add_u32 m0, %1, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %5 offen lds\n\t"                        \
           "s_add_u32 m0, %1, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %6 offen lds"                             \
-          ::"v"(b_off0), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "s"(so2_), "s"(so3_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
+          ::"v"(BOFF), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "s"(so2_), "s"(so3_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
           : "memory", "scc");                                                                                       \
     } else {                                                                                                        \
       asm volatile(                                                                                                 \
           "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds\n\t"                            \
           "s_add_u32 m0, %1, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds"                             \
-          ::"v"(b_off0), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "n"(PSTR)                                       \
+          ::"v"(BOFF), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "n"(PSTR)                                         \
           : "memory", "scc");                                                                                       \
     }                                                                                                               \
   }
 
   f32x4 acc[4][NF];
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   const int wr = wave / WN, wc = wave % WN;
   const int i16 = lane & 15, g = lane >> 4;
-  // edge bits of this lane's four pixels, 4 bits per fragment f: 1 top row, 2 bottom row, 4 left column, 8 right column
-  uint32_t edge16 = 0;
+  // edge bits of this lane's four pixels (of the tile at m_base), 4 bits per fragment f: 1 top row, 2 bottom row, 4 left
+  // column, 8 right column
+  auto edge_bits = [&](int m_base) {
+    uint32_t eb = 0;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    const uint32_t m = (uint32_t)(m0 + wr * 64 + f * 16 + i16);
-    const uint32_t rem = m - fastdiv(m, d_howo) * d_howo.div;
-    const uint32_t oh = fastdiv(rem, d_wo), ow = rem - oh * d_wo.div;
-    const uint32_t e = (oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u);
-    edge16 |= e << (4 * f);
-  }
+    for (int f = 0; f < 4; ++f) {
+      const uint32_t m = (uint32_t)(m_base + wr * 64 + f * 16 + i16);
+      const uint32_t rem = m - fastdiv(m, d_howo) * d_howo.div;
+      const uint32_t oh = fastdiv(rem, d_wo), ow = rem - oh * d_wo.div;
+      const uint32_t e = (oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u);
+      eb |= e << (4 * f);
+    }
+    return eb;
+  };
+  uint32_t edge16 = edge_bits(m0);
 
   // ---- per-lane LDS byte offsets, constant over the K loop ----
   // ab[tap][h]: fragment row f = 0 of tap (kr, ks), K half h, relative to a window buffer: tile row wr*64 + i16 reads window row
@@ -256,8 +265,16 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     __builtin_amdgcn_s_barrier();                                                                                        \
     VDQN_ST(st_bar)                                                                                                      \
     /* no branch: behind the last step this stages two tiles nobody reads (out-of-range reads are zero-filled) */      \
-    VDQN_ISSUE_B(cur_, ti_ * tap_k + (cc2 + ci_) * 128)                                                                  \
-    if constexpr (ti_ == 0) VDQN_ISSUE_AW(ci_ & 1, cc2 + ci_)                                                            \
+    /* steps 16 and 17 stage the first two K-steps of what comes next: chunk 2 it + 2 of this tile, or — in the tile's last     \
+       iteration — chunk 0 of the workgroup's NEXT tile (so_nx / b_nx / q_nx), whose prologue thereby runs under this tile's   \
+       last steps and epilogue */                                                                                         \
+    if constexpr (ci_ == 2) {                                                                                            \
+      VDQN_ISSUE_B(cur_, ti_ * tap_k + so_nx, b_nx)                                                                      \
+      if constexpr (ti_ == 0) VDQN_ISSUE_AW(0, so_nx, q_nx)                                                              \
+    } else {                                                                                                             \
+      VDQN_ISSUE_B(cur_, ti_ * tap_k + (cc2 + ci_) * 128, b_off0)                                                        \
+      if constexpr (ti_ == 0) VDQN_ISSUE_AW(ci_ & 1, (cc2 + ci_) * 128, q0)                                              \
+    }                                                                                                                    \
     VDQN_ST(st_issue)                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     VDQN_LOAD_FRAGS(nxt_, tl_, cl_ & 1, nxt_) /* unconditional: the step behind the last one re-reads buffers that still exist */ \
@@ -266,35 +283,61 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
 
-  // prologue: K-steps 0 and 1 (window of chunk 0, weight tiles of taps 0 and 1), then the fragments of step 0
-  VDQN_ISSUE_B(0, 0)
-  VDQN_ISSUE_AW(0, 0)
-  VDQN_ISSUE_B(1, tap_k)
+  // prologue of the workgroup's FIRST tile: K-steps 0 and 1 (window of chunk 0, weight tiles of taps 0 and 1)
+  VDQN_ISSUE_B(0, 0, b_off0)
+  VDQN_ISSUE_AW(0, 0, q0)
+  VDQN_ISSUE_B(1, tap_k, b_off0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  VDQN_LOAD_FRAGS(0, 0, 0, 0)
 #ifdef VDQN_STAMP
   st_t = __builtin_amdgcn_s_memtime();
+  unsigned long long st_loop_end = 0;
 #endif
+  for (;;) {  // tiles of this workgroup
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    VDQN_LOAD_FRAGS(0, 0, 0, 0)  // the fragments of step 0
+    // the next tile of this workgroup (if any): where its first window and weight tiles come from
+    const uint32_t lt_nx = lt + x_blocks;
+    const bool has_nx = lt_nx < x_count;
+    const int tn_nx = has_nx ? (int)((x_first + lt_nx) % (uint32_t)p.tiles_n) : tile_n;
+    const int tm_nx = has_nx ? (int)((x_first + lt_nx) / (uint32_t)p.tiles_n) : tile_m;
+    const int q0_t = tm_nx * BM - W - 1 + lrow;
+    const uint32_t b_t = (uint32_t)(tn_nx * BN + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
 #pragma clang loop unroll(disable)
-  for (int it = 0; it < n_it; ++it) {
-    const int cc2 = 2 * it;            // first chunk of this iteration
-    VDQN_USTEP(0) VDQN_USTEP(1) VDQN_USTEP(2) VDQN_USTEP(3) VDQN_USTEP(4) VDQN_USTEP(5) VDQN_USTEP(6) VDQN_USTEP(7) VDQN_USTEP(8)
-    VDQN_USTEP(9) VDQN_USTEP(10) VDQN_USTEP(11) VDQN_USTEP(12) VDQN_USTEP(13) VDQN_USTEP(14) VDQN_USTEP(15) VDQN_USTEP(16) VDQN_USTEP(17)
+    for (int it = 0; it < n_it; ++it) {
+      const int cc2 = 2 * it;            // first chunk of this iteration
+      const bool last_it = has_nx && it == n_it - 1;  // (without a next tile the steps behind the end stage this tile's chunk 2 it + 2: nobody reads it)
+      const int so_nx = last_it ? 0 : (cc2 + 2) * 128;
+      const int q_nx = last_it ? q0_t : q0;
+      const uint32_t b_nx = last_it ? b_t : b_off0;
+      VDQN_USTEP(0) VDQN_USTEP(1) VDQN_USTEP(2) VDQN_USTEP(3) VDQN_USTEP(4) VDQN_USTEP(5) VDQN_USTEP(6) VDQN_USTEP(7) VDQN_USTEP(8)
+      VDQN_USTEP(9) VDQN_USTEP(10) VDQN_USTEP(11) VDQN_USTEP(12) VDQN_USTEP(13) VDQN_USTEP(14) VDQN_USTEP(15) VDQN_USTEP(16) VDQN_USTEP(17)
+    }
+    VDQN_ST(st_comp)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two tiles staged behind the last step have landed (the next tile's
+    __builtin_amdgcn_s_barrier();                     // K-steps 0 and 1: weight buffers 0, 1 and window buffer 0 stay untouched)
+#ifdef VDQN_STAMP
+    st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+    // the epilogue's scratch (column sums) is window buffer 1: its last reader was step 16
+    igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem + kU_WinBase + kU_WinStride, m0, n0, tile_m, rows_total, p.howo, W, 0, 0);
+    if (!has_nx) break;
+    lt = lt_nx;
+    tile_n = tn_nx; tile_m = tm_nx;
+    n0 = tile_n * BN; m0 = tile_m * BM;
+    q0 = q0_t;
+    b_off0 = b_t;
+    edge16 = edge_bits(m0);
   }
-  VDQN_ST(st_comp)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two tiles staged behind the last step have landed:
-  __builtin_amdgcn_s_barrier();                     // the epilogue may reuse LDS
 #undef VDQN_USTEP
 #undef VDQN_LOAD_FRAGS
 #undef VDQN_MFMA_ALL
 #undef VDQN_ISSUE_AW
 #undef VDQN_ISSUE_B
 #undef VDQN_DMA4
-#ifdef VDQN_STAMP
-  const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
-#endif
-  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, p.howo, W, 0, 0);
 #ifdef VDQN_STAMP
   if (stamps && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left
@@ -318,10 +361,17 @@ template <int MODE, int BM>
 static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps) {
   using G = Win9Geom<BM>;
   const int wrows = (BM + 2 * p.wo + 2 + 1 + 7) & ~7;  // <= G::WinRows for W <= 28
-  const unsigned grid = (unsigned)(((p.M + BM - 1) / BM) * p.tiles_n);
+  const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * p.tiles_n);
+  // VDQN_WIN9_PERSIST=1: at most as many workgroups as the chip holds at once, each walking its tiles with the next tile's first
+  // two K-steps staged under the current tile's last steps and epilogue; 0: one workgroup per tile
+  // (default: for launches of more than two rounds of resident workgroups — layer2 +5-7 %, layer3 at 512 frames +4 %; a launch of
+  // 1.5 rounds loses 2-3 % to the static tile assignment; 2: always; profiles/r02o_win9u_persistent.txt)
+  static const int persist = [] { const char* e = getenv("VDQN_WIN9_PERSIST"); return e ? atoi(e) : 1; }();
+  const unsigned resident = (unsigned)((BM == 128 ? 2 : 1) * vdqn_num_cus());
+  const unsigned grid = ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident)) ? resident : tiles;
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM>), (size_t)G::Smem);
   hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
-                     make_fastdiv((uint32_t)p.howo), stamps);
+                     make_fastdiv((uint32_t)p.howo), tiles, stamps);
 }
 
 int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
