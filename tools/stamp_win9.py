@@ -7,6 +7,8 @@ import ctypes as C
 import os
 import sys
 
+os.environ.setdefault("VDQN_WIN9_PERSIST", "0")  # the per-K-step averages assume one tile per workgroup
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
