@@ -1005,7 +1005,10 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
   VDQN_CHECK(a->ldg >= co_pad, "vdqn_conv2d_wgrad: gy rows (ldg=%d) must hold co padded to 64 (%d)", a->ldg, co_pad);
   const int M = (int)M64, taps = a->r * a->s;
   pl->copy_elems = (long long)co_pad * taps * a->ci;
-  const int bt = (co_pad % 128 == 0 && a->ci % 128 == 0) ? 128 : 64;
+  // 1 x 1 layers (the ResNet downsamples): with ONE tap the weight matrix is small, 128 x 128 tiles mean 2-8 tiles times ~200 splits,
+  // and the 512 blocks' f32 atomics (blocks x tile elements) outweigh the arithmetic: 64 x 64 tiles emit a quarter of them
+  static const int ds64 = [] { const char* e = getenv("VDQN_WGRAD_DS64"); return e ? atoi(e) : 1; }();
+  const int bt = (co_pad % 128 == 0 && a->ci % 128 == 0 && !(ds64 && taps == 1 && a->dtype == VDQN_BF16)) ? 128 : 64;
   pl->bt = bt;
   pl->ci_tiles = a->ci / bt;
   pl->tiles = (co_pad / bt) * taps * pl->ci_tiles;
