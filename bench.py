@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ramp-seconds", type=float, default=1.5,
+                    help="untimed updates run before the warm-up steps so that the device holds its steady clocks (0 = none)")
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
     ap.add_argument("--frames", type=int, default=1, help="views per sample (12 = BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -212,12 +214,31 @@ def main():
         pool_i["i"] += 1
         return stp.step(b_, a_, 0, act_, rew_, term_, finish_allreduce=(comm.finish if comm else None))
 
+    # device ramp (untimed, before the W warm-up steps): a box that sat idle takes longer than 20 updates (0.13 s) to reach the
+    # clocks it then holds; the same updates are repeated for --ramp-seconds so that short runs (--steps 20) are not timed on
+    # the ramp (profiles/r02p_warmup_ab.txt).  Every rank runs the same number of updates (they contain the collectives).
+    ramp_steps = 0
+    if args.ramp_seconds > 0:
+        t_r = time.perf_counter()
+        for _ in range(10):
+            one_step()
+        torch.cuda.synchronize()
+        per = max((time.perf_counter() - t_r) / 10, 1e-4)
+        ramp_steps = 10 + max(0, int(args.ramp_seconds / per) - 10)
+        if world > 1:
+            t = torch.tensor([ramp_steps], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ramp_steps = int(t.item())
+        for _ in range(ramp_steps - 10):
+            one_step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    sample0 = stp.sample_number
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
@@ -234,7 +255,7 @@ def main():
         per_rank_ms = [round(1e3 * x.item() / args.steps, 3) for x in allt]
         elapsed = max(x.item() for x in allt)  # MAX over ranks
     loss_val = float(loss.item())
-    refreshes = (stp.sample_number // args.target_update_interval) - (args.warmup // args.target_update_interval)
+    refreshes = (stp.sample_number // args.target_update_interval) - (sample0 // args.target_update_interval)
 
     # ---- live per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel ----
     roofline = None
@@ -287,7 +308,7 @@ def main():
         gflop_tuple = GFLOP_PER_TUPLE_F1 * F
         out = {
             "metric": "(s,a,r,s') TD-updates/sec, 224x224 frames, batch 256, 1/2/4/8 MI355X",
-            "value": round(value, 2), "unit": "tuples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "tuples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_steps": ramp_steps,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if args.h2d == "none" else f"synthetic, uint8 frames copied from pinned host memory every step ({args.h2d})",
             "config": {"workload": f"HabitatDQNMultiAction ResNet-18 {args.arch}, 5 categories x 3 actions, full TD update "

@@ -31,7 +31,7 @@ def _bench(args, **env):
     return json.loads(lines[0])
 
 
-SMALL = ["--batch", "8", "--steps", "3", "--warmup", "1", "--profile-steps", "1", "--no-cpu-baseline", "--pool", "2"]
+SMALL = ["--ramp-seconds", "0", "--batch", "8", "--steps", "3", "--warmup", "1", "--profile-steps", "1", "--no-cpu-baseline", "--pool", "2"]
 
 
 def test_bench_self_launches_two_ranks_without_torchrun():
