@@ -462,13 +462,15 @@ def test_conv64_persistent_kernel_geometries(geom):
     assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
 
 
-def test_nine_tap_window_kernel_persistent_tiles():
-    """More than two rounds of resident workgroups (1176 tiles of 128 x 128 at 192 images of 28 x 28 x 128): the launch is
+@pytest.mark.parametrize("n,co", [(192, 128), (96, 256)])
+def test_nine_tap_window_kernel_persistent_tiles(n, co):
+    """More than two rounds of resident workgroups (1176 tiles of 128 x 128: 192 images of 28 x 28 with one column tile, 96 with two — a
+    workgroup's consecutive tiles then differ in the column tile, i.e. in the weights it prefetches): the launch is
     persistent — every workgroup walks several tiles, the next tile's first K-steps staged under the current tile's last steps and
     epilogue (whose column-sum scratch then lives in the second window buffer).  Forward (residual + ReLU) and data gradient
     (mask + column sums) against torch on the same bf16 operands."""
     from video_dqn_amd import ops
-    n, h, ci, co = 192, 28, 128, 128
+    h, ci = 28, 128
     dtype = torch.bfloat16
     x = q(rnd(31, "x", (n, ci, h, h)), dtype)
     w = q(rnd(32, "w", (co, ci, 3, 3), -0.1, 0.1), dtype)
