@@ -9,7 +9,7 @@ O=$R/gpurun_out/pmc_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export VDQN_NO_OVERLAP=1
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-profile --pool 1"
+ARGS="--steps 2 --warmup 1 --ramp-seconds 0 --no-cpu-baseline --no-profile --pool 1"
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE \
   -d $O/p1 -o p --output-format csv -- python3 $R/bench.py $ARGS > /dev/null 2> $O/p1.err
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA \

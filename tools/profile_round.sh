@@ -11,6 +11,6 @@ python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/overlap -o k --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof_overlap.json 2>> $O/bench.err
 export VDQN_NO_OVERLAP=1
 rocprofv3 --kernel-trace --stats -d $O/serial -o k --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof_serial.json 2>> $O/bench.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>> $O/bench.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>> $O/bench.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --ramp-seconds 0 --no-cpu-baseline --no-profile > /dev/null 2>> $O/bench.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --ramp-seconds 0 --no-cpu-baseline --no-profile > /dev/null 2>> $O/bench.err
 find $O -name "*.csv" | head -20
