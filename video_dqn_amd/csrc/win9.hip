@@ -368,7 +368,7 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
   // 1.5 rounds loses 2-3 % to the static tile assignment; 2: always; profiles/r02o_win9u_persistent.txt)
   static const int persist = [] { const char* e = getenv("VDQN_WIN9_PERSIST"); return e ? atoi(e) : 1; }();
   const unsigned resident = (unsigned)((BM == 128 ? 2 : 1) * vdqn_num_cus());
-  const unsigned grid = ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident)) ? resident : tiles;
+  const unsigned grid = (BM == 128 && ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident))) ? resident : tiles;  // (256-row tiles: one workgroup per tile)
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM>), (size_t)G::Smem);
   hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
                      make_fastdiv((uint32_t)p.howo), tiles, stamps);
