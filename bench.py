@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--c4", action="store_true",
                     help="BASELINE config 4's timing window: at least 2200 timed steps so that two target refreshes "
                          "(every 1000 updates) fall inside it")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="DETERMINISTIC mode (ordered split-K sums, one-block loss): run-to-run bit-identical updates")
+    ap.add_argument("--params-digest", action="store_true",
+                    help="add `params_sha256` (SHA-256 of the master parameters after the last timed update, rank 0) to the line; "
+                         "with --deterministic and --pool 1 two runs from the same seed must agree bit for bit")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and issue the bucketed all-reduces even with one rank (RCCL and the "
                          "stream ordering of the exchange exercised on a single GPU)")
@@ -157,7 +162,7 @@ def main():
 
     B, F = args.batch, args.frames
     ec = args.arch == "extra_capacity"
-    net = NetEngine(3, 5, F, ec, args.dtype, 2 * B, device=dev)
+    net = NetEngine(3, 5, F, ec, args.dtype, 2 * B, device=dev, deterministic=(True if args.deterministic else None))
     net.load_tensors(synth.make_state_dict(4, extra_capacity=ec, num_frames=F))  # same seed on every rank: replicas start identical
     comm = BucketAllReduce(world, force=args.force_dist) if use_dist else None
     if world > 1 and not ec:
@@ -255,6 +260,10 @@ def main():
         per_rank_ms = [round(1e3 * x.item() / args.steps, 3) for x in allt]
         elapsed = max(x.item() for x in allt)  # MAX over ranks
     loss_val = float(loss.item())
+    params_sha = None
+    if args.params_digest and rank == 0:
+        import hashlib
+        params_sha = hashlib.sha256(net.params.detach().cpu().numpy().tobytes()).hexdigest()
     refreshes = (stp.sample_number // args.target_update_interval) - (sample0 // args.target_update_interval)
 
     # ---- live per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel ----
@@ -325,6 +334,8 @@ def main():
             "model_tflops": round(value * gflop_tuple / 1e3, 2),
             "model_frac_of_bf16_peak": round(value * gflop_tuple / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "loss": loss_val,
+            "deterministic": bool(net.deterministic),
+            "params_sha256": params_sha,
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -221,11 +221,16 @@ int vdqn_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t s
 int vdqn_bn_train_fwd(const void* y, const void* resid, void* z, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float* work, int32_t n_img, int32_t hw, int32_t c,
                       int32_t num_frames, int32_t imgs_per_half, int32_t relu, float momentum, float eps, int32_t dtype,
-                      void* stream);
+                      void* workspace, int64_t workspace_bytes, void* stream);
 /* dy = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) per group; dgamma/dbeta (may be NULL) = sums over all
  * groups of g*xhat / g.  dy may alias g.  `work` must be the array the forward of the same tensor filled. */
 int vdqn_bn_train_bwd(const void* g, const void* y, void* dy, float* work, float* dgamma, float* dbeta, int32_t n_img,
-                      int32_t hw, int32_t c, int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* stream);
+                      int32_t hw, int32_t c, int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+/* Deterministic mode of the two calls above (train_q_network.py:88-89 pins cudnn.deterministic): with `workspace` (>= this many
+ * bytes, 16-byte aligned; NULL = f32 atomics) every block stores its partial statistic sums and a second kernel adds them in
+ * block order — two runs are bit-identical.  -1 on invalid sizes. */
+int64_t vdqn_bn_train_workspace_bytes(int32_t n_img, int32_t hw, int32_t c, int32_t num_frames, int32_t imgs_per_half);
 /* AdaptiveAvgPool2d(1) of the ResNet (torchvision resnet.py avgpool) on NHWC x[n_img][hw][c] -> out[n_img][c], and its
  * backward fused with the mask of the ReLU that produced x: gx = (x > 0) * g / hw. */
 int vdqn_avgpool_fwd(const void* x, void* out, int32_t n_img, int32_t hw, int32_t c, int32_t dtype, void* stream);
@@ -245,8 +250,9 @@ typedef struct vdqn_net_config {
   int32_t max_batch;       /* largest per-call sample count B the workspaces are sized for */
   int32_t deterministic;   /* 1: run-to-run bit-identical updates (the reference's cudnn.deterministic = True,
                               train_q_network.py:88-89): weight gradients through the two-stage ordered reduction of
-                              vdqn_conv2d_wgrad (its workspace is part of `bwd`), the loss summed by one block.
-                              ARCHITECTURE='basic' keeps atomic sums in its train-mode BatchNorm statistics. */
+                              vdqn_conv2d_wgrad (its workspace is part of `bwd`), the loss summed by one block,
+                              ARCHITECTURE='basic': the train-mode BatchNorm statistics through the ordered two-stage sums
+                              of vdqn_bn_train_fwd/bwd (workspace inside `acts`). */
 } vdqn_net_config;
 
 typedef struct vdqn_net vdqn_net;
@@ -369,6 +375,30 @@ int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stag
 /* The HIP stream (hipStream_t) on which a stage's gradients become complete; NULL when the overlap is off (then it is the
  * stream passed to vdqn_net_backward_stage). */
 void* vdqn_net_grad_stream(vdqn_net* net);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel exchange: one process per GPU, the flat f32 gradient SUM-all-reduced over RCCL (xGMI)
+ * in the three stage buckets of vdqn_net_stage_range, each issued on vdqn_net_grad_stream(net) when its stage's
+ * vdqn_net_backward_stage call has returned; the caller's stream waits for the three collectives (hipStreamWaitEvent) before
+ * vdqn_adam.  The fused TD kernel already divides by the GLOBAL batch (vdqn_step_args.inv_count), so the sum is the gradient of
+ * the global-batch mean loss: N ranks == the reference's one big batch (the reference itself is single-GPU,
+ * train_q_network.py:255-259,275; no reference call site is replaced).
+ * RCCL is looked up at run time (an already-loaded librccl.so, e.g. PyTorch's, is reused; VDQN_RCCL_LIB names another):
+ * single-GPU users of this library do not need it.  The Python host uses torch.distributed's "nccl" backend — the same
+ * library — instead (video_dqn_amd/dist.py); these entries serve callers that bind this header directly.
+ * ------------------------------------------------------------------------------------------------ */
+#define VDQN_COMM_UID_BYTES 128
+typedef struct vdqn_comm vdqn_comm;
+/* Rank 0 creates the 128-byte rendezvous id (ncclGetUniqueId) and hands it to every rank by whatever channel the job has
+ * (file, environment, socket); uid_host is HOST memory. */
+int vdqn_comm_unique_id(void* uid_host);
+/* Collective over all ranks: joins the communicator on the calling thread's current HIP device (ncclCommInitRank). */
+int vdqn_comm_init(int32_t rank, int32_t nranks, const void* uid_host, vdqn_comm** out);
+/* In-place SUM all-reduce of `count` elements (dtype VDQN_F32 | VDQN_BF16) at device pointer `ptr`, asynchronous on `stream`. */
+int vdqn_allreduce_bucket(vdqn_comm* comm, void* ptr, int64_t count, int32_t dtype, void* stream);
+int vdqn_comm_rank(const vdqn_comm* comm);
+int vdqn_comm_size(const vdqn_comm* comm);
+int vdqn_comm_destroy(vdqn_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,7 @@
 """Rank program for tests/test_launch_cpu.py: joins a gloo group from the environment the launcher set, sums the ranks,
-rank 0 prints ONE JSON line.  `--fail-rank R` makes rank R exit 3 before the group forms."""
+rank 0 prints ONE JSON line.  `--fail-rank R` makes rank R exit 3 before the group forms; `--hang-rank R` makes rank R write
+its pid to `--pid-dir`/rank<R>.pid and sleep for ever (a peer stuck in a collective) while the others skip the group and
+exit 0 (`--others-exit`) or sleep too."""
 import json
 import os
 import sys
@@ -14,6 +16,15 @@ if __name__ == "__main__":
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if "--fail-rank" in sys.argv and rank == int(sys.argv[sys.argv.index("--fail-rank") + 1]):
         sys.exit(3)
+    if "--hang-rank" in sys.argv:
+        import time
+        pid_dir = sys.argv[sys.argv.index("--pid-dir") + 1]
+        with open(os.path.join(pid_dir, f"rank{rank}.pid"), "w") as f:
+            f.write(str(os.getpid()))
+        if rank == int(sys.argv[sys.argv.index("--hang-rank") + 1]) or "--others-exit" not in sys.argv:
+            while True:
+                time.sleep(1)
+        sys.exit(0)
     out_stream = launch.claim_stdout()
     import torch
     import torch.distributed as dist

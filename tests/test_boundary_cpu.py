@@ -84,6 +84,62 @@ def test_model_state_dict_matches_reference_layout(g1):
         HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False, device="cpu")(torch.zeros(2, 4, 3, 224, 224))
 
 
+def test_pretrained_weights_land_in_the_trunk(tmp_path):
+    """`models.resnet18(pretrained=True)` (archs/HabitatDQNMultiAction.py:11) served from a file: a torchvision-keyed ResNet-18
+    state_dict (the oracle's restated trunk has torchvision's module names) reaches EVERY trunk tensor — 20 convolutions, 20
+    BatchNorm layers with running statistics, the frozen fc — bit for bit, the head keeps its own initialisation, wrong shapes
+    and partial files are errors that leave the model untouched."""
+    from oracle import ref_cpu
+    from video_dqn_amd.model import HabitatDQNMultiAction, load_torchvision_resnet18
+    torch.manual_seed(3)
+    trunk = ref_cpu.HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False).resnet
+    with torch.no_grad():
+        for t in trunk.state_dict().values():  # distinct non-default values everywhere (fresh BatchNorm buffers are 0 / 1)
+            if t.dtype.is_floating_point:
+                t.copy_(torch.rand_like(t) + 0.5)
+    sd = trunk.state_dict()
+    assert "conv1.weight" in sd and "layer4.1.bn2.running_var" in sd and "fc.bias" in sd and "bn1.num_batches_tracked" in sd
+    path = tmp_path / "resnet18.pth"
+    torch.save(sd, path)
+    for ec in (True, False):
+        torch.manual_seed(11)
+        base = HabitatDQNMultiAction(3, 5, extra_capacity=ec, panorama=False, device="cpu")
+        torch.manual_seed(11)
+        m = HabitatDQNMultiAction(3, 5, extra_capacity=ec, panorama=False, device="cpu", pretrained_weights=str(path))
+        assert m.pretrained_loaded and not base.pretrained_loaded
+        got = m.state_dict()
+        n_trunk = 0
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            assert torch.equal(got["resnet." + k], v), k
+            n_trunk += 1
+        assert n_trunk == 20 + 20 * 4 + 2  # conv weights, BatchNorm (weight, bias, mean, var), fc
+        assert n_trunk == sum(1 for n in m.engine.slots if n.startswith("resnet."))
+        for k in got:  # the head: untouched by the file (same seeded initialisation as without it)
+            if k.startswith("top.") or (ec and k.startswith("features.8.")):
+                assert torch.equal(got[k], base.state_dict()[k]), k
+    m = HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False, device="cpu")
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    partial = {k: v for k, v in sd.items() if not k.startswith("layer4.")}
+    with pytest.raises(ValueError, match="trunk tensors missing"):
+        load_torchvision_resnet18(m.engine, partial)
+    wrong = dict(sd)
+    wrong["layer2.0.conv1.weight"] = torch.zeros(128, 64, 1, 1)
+    with pytest.raises(ValueError, match="wrong shapes"):
+        load_torchvision_resnet18(m.engine, wrong)
+    with pytest.raises(ValueError, match="unknown keys"):
+        load_torchvision_resnet18(m.engine, dict(sd, **{"layer5.0.conv1.weight": torch.zeros(1)}))
+    with pytest.raises(ValueError):
+        torch.save({"epoch": 3}, tmp_path / "junk.pth")
+        HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False, device="cpu", pretrained_weights=str(tmp_path / "junk.pth"))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    # wrapped forms: {'state_dict': ...} with DataParallel's 'module.' prefix (the Places365 release format)
+    assert load_torchvision_resnet18(m.engine, {"state_dict": {"module." + k: v for k, v in sd.items()}}) == 102
+    assert torch.equal(m.state_dict()["resnet.layer3.1.conv2.weight"], sd["layer3.1.conv2.weight"])
+
+
 def test_checkpoint_roundtrip_into_oracle_and_adam(tmp_path):
     """A checkpoint written from the flat engine state loads (strict) into the oracle restatement of the
     reference class and into torch.optim.Adam, and back into the product model bit-exactly."""

@@ -71,6 +71,57 @@ def test_bn_train_fwd_bwd_match_torch(dtype, tol, n, hw, c, F, halves):
     assert relerr(dbeta, bd.grad) < max(tol, 1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_train_deterministic_sums(dtype):
+    """vdqn_bn_train_fwd / _bwd with a workspace (per-block partial sums added in block order, the workspace handed over full of
+    NaN): bit-identical run to run where the atomic mode is not guaranteed to be, and equal to it to summation order.  Many
+    blocks per group (48 images of 56 x 56: 147 blocks) so that the order of the cross-block sum matters."""
+    from video_dqn_amd import ops
+    n, hw, c, F, iph = 48, 56, 64, 2, 24
+    y = torch.from_numpy(synth.uniform(9, "y", (n, hw, hw, c), -1.0, 2.0)).to(dtype).to(DEV)
+    g = torch.from_numpy(synth.uniform(9, "g", (n, hw, hw, c), -1.0, 1.0)).to(dtype).to(DEV)
+    gamma = torch.from_numpy(synth.uniform(9, "ga", (c,), 0.5, 1.5)).to(DEV)
+    beta = torch.from_numpy(synth.uniform(9, "be", (c,), -0.5, 0.5)).to(DEV)
+
+    def run(det):
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        z, work = ops.bn_train_fwd(y, gamma, beta, rm, rv, relu=True, num_frames=F, imgs_per_half=iph, deterministic=det)
+        w_fwd = work.clone()
+        dy, dgamma, dbeta = ops.bn_train_bwd(g, y, work, num_frames=F, imgs_per_half=iph, deterministic=det)
+        torch.cuda.synchronize()
+        return z, w_fwd, rm, rv, dy, dgamma, dbeta
+    a, b, ref = run(True), run(True), run(False)
+    for x, y_ in zip(a, b):
+        assert torch.isfinite(x.float()).all() and torch.equal(x, y_)
+    for x, r in zip(a, ref):
+        assert relerr(x, r) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+def test_basic_arch_deterministic_updates_are_bit_identical():
+    """DETERMINISTIC covers ARCHITECTURE='basic' (defaults.py:14; train_q_network.py:88-89 pins cudnn.deterministic): with the
+    train-mode BatchNorm statistics through the ordered sums, three updates from the same state leave the same bits in
+    parameters, running statistics and Adam state, and the first gradient equals the atomic mode's to summation order."""
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    B, F = 6, 1
+
+    def run(det):
+        net = NetEngine(3, 5, F, False, "f32", 2 * B, deterministic=det)
+        net.load_tensors(synth.make_state_dict(7, extra_capacity=False, num_frames=F))
+        stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=2)
+        g1 = None
+        for step in range(3):
+            (tup, raw) = synth.make_batch(720 + step, B, F, structured=True, reward_p=0.3)
+            stp.step(torch.from_numpy(raw[0]).to(DEV), torch.from_numpy(raw[1]).to(DEV), 0, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV))
+            torch.cuda.synchronize()
+            if step == 0:
+                g1 = stp.grads.clone()
+        return net.params.clone(), net.bnstats.clone(), stp.exp_avg_sq.clone(), g1
+    a, b, c = run(True), run(True), run(False)
+    for x, y_ in zip(a, b):
+        assert torch.equal(x, y_)
+    assert relerr(a[3], c[3]) < 1e-3  # batch statistics amplify summation-order differences of the first update
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
 def test_avgpool_fwd_bwd(dtype, tol):
     from video_dqn_amd import ops

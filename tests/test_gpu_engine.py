@@ -139,11 +139,50 @@ def cosine(a, b):
     return (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
 
 
+def _f64_yardstick(net, engine_grads, make_trainer, tup, what):
+    """The f32 gradient gate (north_star: 1e-3 relative, fp32): the oracle is run in float64 AND float32 on the same minibatch;
+    per gradient tensor the engine's distance to the float64 gradients must satisfy
+        L2:  err(engine, f64) <= max(1e-3, 1.5 * err(oracle_f32, f64))      max element:  <= max(5e-3, 1.5 * err_max(oracle_f32, f64))
+    (the rule of tests/test_gpu_basic.py: two fp32 implementations are both measured against the exact answer, neither against
+    the other).  Returns (bad, report): the tensors that fail and a line naming the worst tensor with its measured numbers —
+    emitted as a pytest warning so a `-q` log shows how far from 1e-3 the run was."""
+    from oracle import ref_cpu
+    grads = {}
+    for prec in (torch.float32, torch.float64):
+        tr = make_trainer()
+        tr.model.to(prec)
+        tr.target_net.to(prec)
+        tr.model.set_train()
+        tr.optimizer.zero_grad()
+        loss = ref_cpu.process_batch(tr.model, tr.target_net, tr.config, (tup[0].to(prec), tup[1].to(prec)) + tuple(tup[2:]))
+        loss.backward()
+        grads[prec] = {n: p.grad.double() for n, p in tr.model.named_parameters() if p.grad is not None}
+    bad, rows = [], []
+    for name, r in grads[torch.float64].items():
+        s = net.slots[name]
+        ge = engine_grads[s.offset:s.offset + s.numel].view(s.shape).double().cpu()
+        g32 = grads[torch.float32][name]
+        rn, rm = r.norm().clamp_min(1e-300), r.abs().max().clamp_min(1e-300)
+        e_l2, e_mx = ((ge - r).norm() / rn).item(), ((ge - r).abs().max() / rm).item()
+        o_l2, o_mx = ((g32 - r).norm() / rn).item(), ((g32 - r).abs().max() / rm).item()
+        rows.append((e_l2, e_mx, o_l2, o_mx, name))
+        if e_l2 > max(1e-3, 1.5 * o_l2) or e_mx > max(5e-3, 1.5 * o_mx):
+            bad.append((name, e_l2, e_mx, o_l2, o_mx))
+    w = max(rows)
+    wm = max(rows, key=lambda t: t[1])
+    report = (f"{what}: worst gradient tensor vs the float64 oracle: L2 {w[0]:.3g} ({w[4]}; fp32 oracle's own {w[2]:.3g}), "
+              f"max element {wm[1]:.3g} ({wm[4]}; fp32 oracle's own {wm[3]:.3g}); gate L2 <= max(1e-3, 1.5 x oracle), "
+              f"max <= max(5e-3, 1.5 x oracle); {len(bad)} of {len(rows)} tensors outside")
+    return bad, report
+
+
 @pytest.mark.parametrize("dtype,tol_q,tol_g", [("f32", 1e-3, 1e-3), ("bf16", 4e-2, None)])
 def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
     """One update compared over every gradient element with the oracle run on the GPU box's host.
-    f32: relative L2 error of every gradient tensor <= 1e-3 (north_star) and max error <= 5e-3 of the tensor's
-    max (the looser max bound absorbs isolated ReLU flips between two fp32 implementations).
+    f32: every gradient tensor is measured against the oracle run in float64; its relative L2 error must be <= 1e-3 (north_star)
+    and its max error <= 5e-3 of the tensor's max — or within 1.5x the distance of the fp32 oracle itself from float64
+    (`_f64_yardstick`; the measured worst tensor is emitted as a pytest warning).  ReLU sign disagreements between engine and
+    fp32 oracle are counted and reported as information; they do not change the tolerance.
     bf16 (throughput mode): the TD error Q_b - y is a difference of O(1) Q-values carrying ~1e-2 bf16 error and
     bf16 activations flip many ReLU masks, so element-wise agreement with an fp32 run is not defined; gate on
     direction and scale instead: the WHOLE gradient must agree with the oracle's to cosine >= 0.995 and 2 % in norm
@@ -155,19 +194,19 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
     torch.set_num_threads(max(1, torch.get_num_threads()))
     B = 8
     net, out = _run_steps(dtype, 1, B)
-    tr = ref_cpu.Trainer(ref_cpu.default_config(), synth.make_state_dict(7))
-    tr.target_net.load_state_dict(synth.make_state_dict(8))
+
+    def make_trainer():
+        t = ref_cpu.Trainer(ref_cpu.default_config(), synth.make_state_dict(7))
+        t.target_net.load_state_dict(synth.make_state_dict(8))
+        return t
+    tr = make_trainer()
     (tup, _) = synth.make_batch(101, B, 1, structured=True, reward_p=0.3)
     d = {}
     loss = tr.step(tup, d)
     assert abs(out[0]["loss"] - loss) <= tol_q * abs(loss) * 5
     assert relerr(out[0]["q_before"], d["before_values"].detach().reshape(B, 15)) < tol_q
     bad = []
-    tol_l2, tol_max = tol_g, 5e-3
     if dtype == "f32":
-        # ReLU sign disagreements between the two fp32 implementations (pre-activations that round to opposite sides of 0):
-        # none -> the strict 1e-3 gate; a few -> every tensor downstream of a flip moves by ~1e-3 of its max, so the gate
-        # is relaxed to 3e-3 (L2) / 1.5e-2 (max) and the number of flips itself is bounded
         m0 = ref_cpu.HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False)  # pre-update weights (tr.step ran Adam)
         m0.load_state_dict(synth.make_state_dict(7))
         m0.eval()
@@ -175,11 +214,9 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
         flips = _count_relu_flips(net, out[0]["acts"], 2 * B, B, feats)
         total = sum(int(v.numel()) for v in feats.values())
         assert flips <= 1e-5 * total
-        if flips > 0:
-            tol_l2, tol_max = 3e-3, 1.5e-2
-        import warnings  # the warnings summary is what a `pytest -q` log keeps: record which gate this run took
-        warnings.warn(f"f32 parity gate: {flips} ReLU sign disagreements of {total} -> gradient gate L2 <= {tol_l2:g}, max <= {tol_max:g} "
-                      f"({'strict north_star 1e-3' if flips == 0 else 'relaxed branch'})")
+        bad, report = _f64_yardstick(net, out[0]["grads"], make_trainer, tup, "f32 parity gate (B=8, F=1)")
+        import warnings  # the warnings summary is what a `pytest -q` log keeps
+        warnings.warn(report + f"; ReLU sign disagreements engine vs fp32 oracle: {flips} of {total} (information only)")
     all_g, all_ref = [], []
     for name, p in tr.model.named_parameters():
         if p.grad is None:
@@ -187,8 +224,7 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
         s = net.slots[name]
         g = out[0]["grads"][s.offset:s.offset + s.numel].view(s.shape)
         if dtype == "f32":
-            if l2err(g, p.grad) > tol_l2 or relerr(g, p.grad) > tol_max:
-                bad.append((name, l2err(g, p.grad), relerr(g, p.grad)))
+            continue  # gated above against float64
         else:
             c, ratio = cosine(g, p.grad), (g.double().norm() / p.grad.double().norm()).item()
             small = p.grad.dim() == 1  # per-channel vector
@@ -318,9 +354,8 @@ def _count_relu_flips(net, buf, layout_samples, n_frames, feats):
 
 def test_td_step_multi_frame_matches_oracle_f32():
     """PANORAMA / PREVIOUS_IMAGES geometry (F = 4 views per sample, top.0 takes 6400 features): one full update.
-    With only 12 frames a single ReLU whose pre-activation rounds to opposite sides of zero in the two fp32
-    implementations moves the 7x7-map gradients by > 1e-3, so the ReLU disagreements are counted explicitly:
-    none -> the strict 1e-3 gate; some -> the (stated) relaxed gate."""
+    Gradients are gated against the oracle run in float64 (`_f64_yardstick`: 1e-3 L2 / 5e-3 max, or 1.5x the fp32 oracle's own
+    distance from float64); ReLU sign disagreements with the fp32 oracle are counted and reported, not used as a tolerance."""
     from oracle import ref_cpu
     from video_dqn_amd.engine import NetEngine, TDStepper
     B, F = 3, 4
@@ -341,17 +376,11 @@ def test_td_step_multi_frame_matches_oracle_f32():
     assert relerr(stp.q_before, d["before_values"].detach().reshape(B, 15)) < 1e-3
     feats = _oracle_relu_outputs(tr.model, before.reshape(B * F, 3, 224, 224))
     flips = _count_relu_flips(net, stp.acts_online, 2 * B, B * F, feats)
-    tol_l2, tol_max = (1e-3, 5e-3) if flips == 0 else (1e-2, 5e-2)
-    print(f"ReLU sign disagreements: {flips}; gradient gate L2 {tol_l2} / max {tol_max}")
     assert flips <= 8
-    bad = []
-    for name, p in tr.model.named_parameters():
-        if p.grad is None:
-            continue
-        s = net.slots[name]
-        g = stp.grads[s.offset:s.offset + s.numel].view(s.shape)
-        if l2err(g, p.grad) > tol_l2 or relerr(g, p.grad) > tol_max:
-            bad.append((name, l2err(g, p.grad), relerr(g, p.grad)))
+    bad, report = _f64_yardstick(net, stp.grads, lambda: ref_cpu.Trainer(ref_cpu.default_config(), synth.make_state_dict(7, num_frames=F), num_frames=F),
+                                 tup, f"f32 parity gate (B={B}, F={F})")
+    import warnings
+    warnings.warn(report + f"; ReLU sign disagreements engine vs fp32 oracle: {flips} (information only)")
     assert not bad, bad
 
 

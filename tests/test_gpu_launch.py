@@ -46,14 +46,82 @@ def test_bench_self_launches_two_ranks_without_torchrun():
 
 
 def test_bench_single_rank_through_rccl():
-    """One rank, backend nccl (= RCCL): the three async all-reduces per update and their stream hand-off (the engine's
-    side stream joined into torch's stream before each bucket is launched) run on the GPU; the result must equal the
-    run without any collective."""
+    """One rank, backend nccl (= RCCL): the three async all-reduces per update run on the GPU, each issued with the engine's
+    gradient stream current (vdqn_net_grad_stream: where the stage's weight gradients and unfold kernel ran) and joined into the
+    caller's stream by BucketAllReduce.finish() before Adam.  A one-rank SUM all-reduce is the identity, so in DETERMINISTIC f32
+    mode the run with the collectives must leave the SAME BITS in the master parameters as the run without them: any
+    mis-ordering of side stream -> RCCL -> Adam (a bucket reduced before its unfold finished, Adam before a bucket landed)
+    changes them."""
+    det = ["--dtype", "f32", "--deterministic", "--params-digest", "--batch", "4", "--steps", "3", "--warmup", "0", "--ramp-seconds", "0",
+           "--profile-steps", "1", "--no-cpu-baseline", "--pool", "1"]
+    a = _bench(["--gpus", "1", "--force-dist"] + det)
+    b = _bench(["--gpus", "1"] + det)
+    assert a["allreduce"]["backend"].startswith("nccl") and len(a["allreduce"]["buckets_bytes"]) == 3
+    assert sum(a["allreduce"]["buckets_bytes"]) == 4 * 12426384
+    assert b["allreduce"] is None and a["deterministic"] and b["deterministic"]
+    assert a["params_sha256"] is not None and a["params_sha256"] == b["params_sha256"]
+    assert a["loss"] == b["loss"]
+    # and the throughput mode (bf16, atomic sums): same data, same updates, not bit-equal
     a = _bench(["--gpus", "1", "--force-dist"] + SMALL)
     b = _bench(["--gpus", "1"] + SMALL)
-    assert a["allreduce"]["backend"].startswith("nccl") and len(a["allreduce"]["buckets_bytes"]) == 3
-    assert b["allreduce"] is None
-    assert a["loss"] == pytest.approx(b["loss"], rel=2e-2)  # same data, same updates (bf16 + atomics: not bit-equal)
+    assert a["loss"] == pytest.approx(b["loss"], rel=2e-2)
+
+
+def test_bench_eight_ranks_on_one_device_gloo():
+    """BASELINE config 4's rank count, functionally: eight self-launched ranks at batch 2 share this box's GPU (gloo carries the
+    exchange); catches anything that depends on the number of ranks (bucket slicing, rank-strided seeds, the MAX over ranks)."""
+    out = _bench(["--gpus", "8", "--backend", "gloo", "--ramp-seconds", "0", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-profile",
+                  "--no-cpu-baseline", "--pool", "1"], VDQN_BENCH_SINGLE_DEVICE="1")
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp8"
+    assert len(out["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in out["per_rank_ms_per_step"])
+    assert out["ms_per_step"] == pytest.approx(max(out["per_rank_ms_per_step"]), rel=1e-3)
+    b = out["allreduce"]["buckets_bytes"]
+    assert len(b) == 3 and sum(b) == 4 * 12426384
+    assert out["loss"] == out["loss"] and out["value"] > 0
+
+
+def test_c_abi_comm_one_rank(tmp_path):
+    """include/vdqn.h's own exchange entries (vdqn_comm_unique_id / _init / vdqn_allreduce_bucket / _destroy) on RCCL with one
+    rank: the all-reduce is the identity for f32 and bf16 buffers, bad arguments are errors, and a deterministic f32 update
+    whose three stage buckets go through them (CAbiBucketAllReduce, each queued on vdqn_net_grad_stream) leaves the same bits as
+    an update without any exchange."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    from video_dqn_amd import _lib, synth
+    from video_dqn_amd.dist import CAbiBucketAllReduce
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    lib = _lib.load()
+    comm = CAbiBucketAllReduce(0, 1, str(tmp_path / "uid"), force=True)
+    assert lib.vdqn_comm_rank(comm.handle) == 0 and lib.vdqn_comm_size(comm.handle) == 1
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(1 << 20, device="cuda")
+    y = x.clone()
+    _lib.check(lib.vdqn_allreduce_bucket(comm.handle, x.data_ptr(), x.numel(), _lib.VDQN_F32, st), "allreduce f32")
+    xb = torch.randn(4096, device="cuda").to(torch.bfloat16)
+    yb = xb.clone()
+    _lib.check(lib.vdqn_allreduce_bucket(comm.handle, xb.data_ptr(), xb.numel(), _lib.VDQN_BF16, st), "allreduce bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(x, y) and torch.equal(xb, yb)
+    assert lib.vdqn_allreduce_bucket(comm.handle, x.data_ptr(), 16, 5, st) < 0 and b"dtype" in lib.vdqn_last_error()
+    assert lib.vdqn_allreduce_bucket(None, x.data_ptr(), 16, 0, st) < 0
+    h = C.c_void_p()
+    assert lib.vdqn_comm_init(2, 2, C.create_string_buffer(128), C.byref(h)) < 0  # rank out of range: refused before RCCL is asked
+
+    def run(with_comm):
+        B = 4
+        net = NetEngine(3, 5, 1, True, "f32", 2 * B, deterministic=True)
+        net.load_tensors(synth.make_state_dict(7))
+        stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, allreduce=(comm.launch if with_comm else None))
+        for step in (1, 2, 3):
+            (tup, _) = synth.make_batch(300 + step, B, 1, structured=True, reward_p=0.3)
+            stp.step(tup[0].contiguous().cuda(), tup[1].contiguous().cuda(), 1, tup[2].cuda(), tup[3].float().cuda(), tup[4].float().cuda(),
+                     finish_allreduce=(comm.finish if with_comm else None))
+        torch.cuda.synchronize()
+        return net.params.cpu().clone()
+    pa, pb = run(True), run(False)
+    assert comm.bucket_bytes and sum(comm.bucket_bytes) == 4 * 12426384
+    assert torch.equal(pa, pb)
+    comm.close()
 
 
 def test_bench_failed_rank_is_a_failed_job():
@@ -104,6 +172,51 @@ def _worker_nccl(rank, world, port, out_dir, arch_ec):
     torch.save({"params": net.params.cpu(), "bnstats": net.bnstats.cpu()}, os.path.join(out_dir, f"nccl{int(arch_ec)}_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _worker_cabi(rank, world, uid_path, out_dir):
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    from video_dqn_amd import synth
+    from video_dqn_amd.dist import CAbiBucketAllReduce
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    B = 4
+    comm = CAbiBucketAllReduce(rank, world, uid_path)
+    net = NetEngine(3, 5, 1, True, "f32", 2 * B, device=dev)
+    net.load_tensors(synth.make_state_dict(7))
+    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, world_size=world, allreduce=comm.launch)
+    for step in (1, 2):
+        (tup, _) = synth.make_batch(200 + step, 2 * B, 1, structured=True, reward_p=0.3)
+        lo, hi = rank * B, rank * B + B
+        stp.step(tup[0][lo:hi].contiguous().to(dev), tup[1][lo:hi].contiguous().to(dev), 1, tup[2][lo:hi].to(dev),
+                 tup[3][lo:hi].float().to(dev), tup[4][lo:hi].float().to(dev), finish_allreduce=comm.finish)
+    torch.cuda.synchronize()
+    torch.save({"params": net.params.cpu()}, os.path.join(out_dir, f"cabi_{rank}.pt"))
+    comm.close()
+
+
+def test_two_gpus_c_abi_comm_equal_one_big_batch(tmp_path):
+    """The exchange through include/vdqn.h's own RCCL entries (no torch.distributed) on two GPUs == one big batch."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    from video_dqn_amd import synth
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    mp.spawn(_worker_cabi, args=(2, str(tmp_path / "uid"), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "cabi_0.pt"), torch.load(tmp_path / "cabi_1.pt")
+    assert torch.equal(r0["params"], r1["params"])
+    B = 8
+    net = NetEngine(3, 5, 1, True, "f32", 2 * B)
+    net.load_tensors(synth.make_state_dict(7))
+    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True)
+    for step in (1, 2):
+        (tup, _) = synth.make_batch(200 + step, B, 1, structured=True, reward_p=0.3)
+        stp.step(tup[0].contiguous().cuda(), tup[1].contiguous().cuda(), 1, tup[2].cuda(), tup[3].float().cuda(), tup[4].float().cuda())
+    torch.cuda.synchronize()
+    nt = net.trainable_numel
+    d = (net.params.cpu()[:nt] - r0["params"][:nt]).abs()
+    assert d.max().item() <= 2.5e-4 and d.mean().item() < 2e-6
 
 
 @pytest.mark.parametrize("arch_ec", [True, False], ids=["extra_capacity", "basic_syncbn"])

@@ -190,6 +190,31 @@ def test_conv_wgrad(case, dtype, splitk):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(3, 64, 100, 9, 3, 1, 1), (2, 128, 15, 6, 1, 1, 0), (2, 128, 130, 8, 3, 2, 1)])
+def test_conv_wgrad_deterministic_with_ragged_co(case, dtype):
+    """Deterministic mode with co not a multiple of 64 and a workspace full of NaN: the padding rows co .. co_pad - 1 of dw stay
+    exactly zero (as in the atomic mode), every other element equals the atomic mode to summation order, two runs agree bit for bit."""
+    from video_dqn_amd import ops
+    n, ci, co, h, k, stride, pad = case
+    ho = (h + 2 * pad - k) // stride + 1
+    co_pad = (co + 63) // 64 * 64
+    x = q(rnd(1, "x", (n, ci, h, h)), dtype)
+    gy = torch.zeros((n, co_pad, ho, ho))
+    gy[:, :co] = q(rnd(5, "gy", (n, co, ho, ho)), dtype)
+    kw = dict(co=co, r=k, s=k, stride=stride, pad=pad)
+    dw_a, _ = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), **kw)
+    dw_d, _ = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), deterministic=True, poison_workspace=True, **kw)
+    dw_e, _ = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), deterministic=True, poison_workspace=True, **kw)
+    torch.cuda.synchronize()
+    assert dw_d.shape[0] == co_pad and torch.isfinite(dw_d).all()
+    assert dw_d[co:].abs().max().item() == 0.0 and dw_a[co:].abs().max().item() == 0.0
+    assert torch.equal(dw_d, dw_e)
+    assert relerr(dw_d, dw_a) < 1e-5
+    ref = F.grad.conv2d_weight(x, (co, ci, k, k), gy[:, :co], stride, pad)
+    assert relerr(dw_d.cpu()[:co].permute(0, 3, 1, 2), ref) < TOL_F32OUT[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_fwd_bwd(dtype):
     """Linear layers are 1x1 convolutions on a 1x1 image; out features padded to 64 columns (15 -> 64)."""
     from video_dqn_amd import ops
@@ -480,6 +505,11 @@ def test_nine_tap_window_kernel_persistent_tiles(n, co):
     out = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=h, wo=h, co=co, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
     torch.cuda.synchronize()
     assert relerr(out.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    # the f32 result of the same launch shape (no rounding of the output: only the summation order differs from torch)
+    _, out32 = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=h, wo=h, co=co, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True,
+                          want_f32=True)
+    torch.cuda.synchronize()
+    assert relerr(out32.cpu().permute(0, 3, 1, 2), ref) < TOL_F32OUT[dtype]
     gy = q(rnd(35, "gy", (n, co, h, h)), dtype)
     xact = q(rnd(36, "xa", (n, ci, h, h)), dtype)
     refg = F.grad.conv2d_input((n, ci, h, h), w, gy, 1, 1) * (xact > 0)

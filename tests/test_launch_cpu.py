@@ -34,6 +34,83 @@ def test_failed_rank_fails_the_job():
     assert r.stdout.strip() == ""
 
 
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    # a zombie still answers kill(0): read its state
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except FileNotFoundError:
+        return False
+
+
+def _wait_pids(pid_dir, n, timeout=60):
+    import time
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < timeout:
+        names = [f for f in os.listdir(pid_dir) if f.endswith(".pid")]
+        if len(names) >= n:
+            pids = []
+            for f in names:
+                txt = open(os.path.join(pid_dir, f)).read().strip()
+                if txt:
+                    pids.append(int(txt))
+            if len(pids) >= n:
+                return pids
+        time.sleep(0.1)
+    raise AssertionError("ranks did not start")
+
+
+def test_ranks_die_with_a_signalled_launcher(tmp_path):
+    """SIGTERM to the launcher (gpurun --timeout, a pytest timeout): every rank is stopped, the exit code is 128 + 15."""
+    import signal
+    import time
+    p = subprocess.Popen([sys.executable, SCRIPT, "--gpus", "2", "--hang-rank", "0", "--pid-dir", str(tmp_path)], env=_clean_env(),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    pids = _wait_pids(str(tmp_path), 2)
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    time.sleep(0.2)
+    assert not any(_alive(q) for q in pids)
+
+
+def test_ranks_die_with_a_killed_launcher(tmp_path):
+    """SIGKILL to the launcher: no handler runs; the ranks get SIGTERM from the kernel (PR_SET_PDEATHSIG)."""
+    import signal
+    import time
+    p = subprocess.Popen([sys.executable, SCRIPT, "--gpus", "2", "--hang-rank", "0", "--pid-dir", str(tmp_path)], env=_clean_env(),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    pids = _wait_pids(str(tmp_path), 2)
+    p.kill()
+    p.wait(timeout=60)
+    t0 = time.monotonic()
+    while any(_alive(q) for q in pids) and time.monotonic() - t0 < 30:
+        time.sleep(0.1)
+    assert not any(_alive(q) for q in pids)
+
+
+def test_straggler_behind_a_finished_rank_is_bounded(tmp_path):
+    """One rank exits 0 while its peer hangs (stuck in a collective): the job ends with 124 after the grace period."""
+    env = _clean_env()
+    env["VDQN_LAUNCH_STRAGGLER_GRACE"] = "1.5"
+    r = subprocess.run([sys.executable, SCRIPT, "--gpus", "2", "--hang-rank", "1", "--others-exit", "--pid-dir", str(tmp_path)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 124
+    assert not any(_alive(q) for q in _wait_pids(str(tmp_path), 2))
+
+
+def test_launch_timeout(tmp_path):
+    env = _clean_env()
+    env["VDQN_LAUNCH_TIMEOUT"] = "2"
+    r = subprocess.run([sys.executable, SCRIPT, "--gpus", "2", "--hang-rank", "0", "--pid-dir", str(tmp_path)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 124
+    assert not any(_alive(q) for q in _wait_pids(str(tmp_path), 2))
+
+
 def test_parent_of_bench_and_cli_never_imports_the_gpu_runtime_before_spawning():
     """The spawn decision sits above every GPU call in both entry points (static check: the launcher call precedes the
     first torch.cuda / _lib use in main)."""

@@ -1,0 +1,181 @@
+// Probe: is s_memtime a shader-clock counter on this MI355X, and what clock does the chip hold under an MFMA-dense load?
+//
+// A wave issues N dependency-free v_mfma_f32_16x16x32_bf16 (16 independent accumulators, operands in registers, one wave per
+// SIMD: 256-thread workgroups, one per CU).  Back to back such an MFMA occupies the SIMD's matrix pipe for exactly 16 shader
+// cycles (MI355X_MICROARCH.md, cycle constants), so the run costs 16 N shader cycles whatever the clock is.  Three independent
+// readings of the clock follow:
+//   (a) in-kernel:  ticks = delta s_memtime around the run;  ticks / (16 N) = s_memtime ticks per shader cycle (1.000 if s_memtime
+//       counts shader cycles);  delta s_memtime / delta s_memrealtime x 100 MHz = the clock in Hz, if it does;
+//   (b) wall:       16 N / (HIP-event duration of the dispatch) — needs no counter at all, only the 16-cycle issue rate;
+//   (c) profiler:   GRBM_GUI_ACTIVE / 8 / dispatch duration (run this binary under `rocprofv3 --pmc GRBM_GUI_ACTIVE
+//       --kernel-trace`; tools/pmc_mfma_summary.py prints the quotient) — the guide says it reads HIGH on dispatches shorter
+//       than ~0.3 ms and settles within 3 % of (a) at >= 10 ms.
+// The same run on zero operands and on random operands (full-range uniform bf16) shows the DVFS give-back: the chip holds a lower
+// clock when the MFMAs toggle real data.  A 32x32x16 variant (8 accumulators of 16 registers... same 64x64 output tile per wave,
+// 32 cycles per MFMA) reports the shape dependence of the held clock.
+//
+// Build: hipcc -O3 --offload-arch=gfx950 clock_calib.hip -o clock_calib ; run: ./clock_calib  (prints one table + one JSON line)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// SHAPE 0: 16x16x32 (16 accumulators f32x4 = a 64x64 tile), SHAPE 1: 32x32x16 (4 accumulators f32x16 = the same 64x64 tile)
+template <int SHAPE>
+__global__ __launch_bounds__(256, 1) void calib(const uint32_t* __restrict__ data, unsigned long long* __restrict__ stamps, float* sink, int iters) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  // operands: 4 A and 4 B fragments per lane, 16 bytes each, from the data buffer (zeros or random bf16 pairs)
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint4 va = reinterpret_cast<const uint4*>(data)[(blockIdx.x * 256 + tid) * 8 + i];
+    uint4 vb = reinterpret_cast<const uint4*>(data)[(blockIdx.x * 256 + tid) * 8 + 4 + i];
+    a[i] = __builtin_bit_cast(bf16x8, va);
+    b[i] = __builtin_bit_cast(bf16x8, vb);
+  }
+  f32x4 acc4[4][4];
+  f32x16 acc16[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc16[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a[i]), "+v"(b[i]));  // the operand loads have landed before the opening stamp
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int k = 0; k < iters; ++k) {
+    if (SHAPE == 0) {
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep)  // 32 MFMAs of 16 cycles per iteration = 512 cycles
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc4[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int rep = 0; rep < 4; ++rep)  // 16 MFMAs of 32 cycles per iteration = 512 cycles, the same FLOP
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i + 2 * (rep & 1)], b[j + 2 * (rep >> 1)], acc16[i][j], 0, 0, 0);
+    }
+  }
+  // the last MFMA's result must be there before the closing stamp: a dependent VALU read of every accumulator
+  float s = 0.f;
+  if (SHAPE == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc4[i][j][0] + acc4[i][j][3];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) s += acc16[i][j][0] + acc16[i][j][15];
+  }
+  asm volatile("" : "+v"(s));
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {  // one record per wave; the stamps never reach an output the arithmetic reads
+    unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 2;
+    o[0] = t1 - t0;
+    o[1] = r1 - r0;
+  }
+  if (s == 1.2345e33f) sink[blockIdx.x * 256 + tid] = s;
+}
+
+struct Result {
+  double ticks_per_mfma_cycle, memtime_ghz, wall_ghz, tflops, us;
+};
+
+template <int SHAPE>
+Result run(const uint32_t* d_data, unsigned long long* d_st, float* d_sink, int blocks, int iters, int heat_launches) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int i = 0; i < heat_launches; ++i) calib<SHAPE><<<blocks, 256>>>(d_data, d_st, d_sink, iters);  // bring the chip to the clock it holds
+  hipEventRecord(e0);
+  calib<SHAPE><<<blocks, 256>>>(d_data, d_st, d_sink, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> st((size_t)blocks * 8);
+  hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> tpc, ghz;
+  const double mfma_cycles = 512.0 * iters;  // per wave: 32 x 16 or 16 x 32 cycles per iteration
+  for (int w = 0; w < blocks * 4; ++w) {
+    tpc.push_back((double)st[2 * w] / mfma_cycles);
+    ghz.push_back((double)st[2 * w] / (double)st[2 * w + 1] * 0.1);  // s_memrealtime: 100 MHz
+  }
+  std::sort(tpc.begin(), tpc.end());
+  std::sort(ghz.begin(), ghz.end());
+  Result r;
+  r.ticks_per_mfma_cycle = tpc[tpc.size() / 2];
+  r.memtime_ghz = ghz[ghz.size() / 2];
+  r.us = ms * 1e3;
+  r.wall_ghz = mfma_cycles / (ms * 1e6);  // cycles / ns: a LOWER bound (the dispatch also holds launch ramp and drain)
+  r.tflops = (double)blocks * 4 * iters * 32 * (2.0 * 16 * 16 * 32) / ms / 1e9;
+  return r;
+}
+
+int main(int argc, char** argv) {
+  const int blocks = 256;
+  uint32_t* d_data;
+  unsigned long long* d_st;
+  float* d_sink;
+  const size_t words = (size_t)blocks * 256 * 8 * 4;
+  hipMalloc(&d_data, words * 4);
+  hipMalloc(&d_st, (size_t)blocks * 8 * 8);
+  hipMalloc(&d_sink, (size_t)blocks * 256 * 4);
+  std::vector<uint32_t> h(words);
+  printf("%-10s %-9s %9s %10s | %12s %12s %10s %9s\n", "operands", "mfma", "iters", "dispatch", "ticks/cycle", "memtime GHz", "wall GHz", "TFLOP/s");
+  std::string json = "{\"probe\": \"clock_calib\", \"rows\": [";
+  bool first = true;
+  for (int fill = 0; fill < 2; ++fill) {
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < words; ++i) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      // random: two bf16 in [-1, 1) per word: sign random, exponent 0x3f7f.. -> mantissa and low exponent bits random
+      const uint32_t lo = (uint32_t)(x & 0x807f) | (0x3f00 - (((uint32_t)(x >> 20) & 3) << 7));
+      const uint32_t hi = (uint32_t)((x >> 32) & 0x807f) | (0x3f00 - (((uint32_t)(x >> 52) & 3) << 7));
+      h[i] = fill == 0 ? 0u : (lo | (hi << 16));
+    }
+    hipMemcpy(d_data, h.data(), words * 4, hipMemcpyHostToDevice);
+    // short dispatches (~0.1 ms, the length of the update's convolution launches) and long ones (>= 10 ms), after 2 s of heat
+    for (int shape = 0; shape < 2; ++shape) {
+      for (int iters : {400, 60000}) {
+        const double est_ms = 512.0 * iters / 2.0e6;  // at ~2 GHz
+        const int heat = (int)std::min(20000.0, 2000.0 / est_ms);
+        Result r = shape == 0 ? run<0>(d_data, d_st, d_sink, blocks, iters, heat) : run<1>(d_data, d_st, d_sink, blocks, iters, heat);
+        printf("%-10s %-9s %9d %8.1f us | %12.4f %12.3f %10.3f %9.1f\n", fill == 0 ? "zeros" : "random", shape == 0 ? "16x16x32" : "32x32x16", iters, r.us,
+               r.ticks_per_mfma_cycle, r.memtime_ghz, r.wall_ghz, r.tflops);
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s{\"operands\": \"%s\", \"mfma\": \"%s\", \"iters\": %d, \"dispatch_us\": %.1f, \"memtime_ticks_per_mfma_cycle\": %.4f, "
+                 "\"memtime_over_realtime_ghz\": %.3f, \"wall_ghz_lower_bound\": %.3f, \"tflops\": %.1f}",
+                 first ? "" : ", ", fill == 0 ? "zeros" : "random", shape == 0 ? "16x16x32" : "32x32x16", iters, r.us, r.ticks_per_mfma_cycle, r.memtime_ghz,
+                 r.wall_ghz, r.tflops);
+        json += buf;
+        first = false;
+      }
+    }
+  }
+  json += "]}";
+  printf("%s\n", json.c_str());
+  return 0;
+}

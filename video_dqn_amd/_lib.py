@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", f"libvdqn{'_' + os.environ['VDQN_LIB'] if os.environ.get('VDQN_LIB') else ''}.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -88,8 +88,9 @@ _SIGS = {
     "vdqn_gt_loss": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
     "vdqn_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_vp]),
     "vdqn_bn_train_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                    c_f32, c_f32, c_i32, c_vp]),
-    "vdqn_bn_train_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+                                    c_f32, c_f32, c_i32, c_vp, c_i64, c_vp]),
+    "vdqn_bn_train_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "vdqn_bn_train_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "vdqn_avgpool_fwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_avgpool_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(c_vp)]),
@@ -120,7 +121,14 @@ _SIGS = {
     "vdqn_net_forward_train": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vdqn_net_td_forward": (C.c_int, [c_vp, C.POINTER(StepArgs), c_vp]),
     "vdqn_net_backward_stage": (C.c_int, [c_vp, C.POINTER(StepArgs), c_i32, c_vp]),
+    "vdqn_comm_unique_id": (C.c_int, [c_vp]),
+    "vdqn_comm_init": (C.c_int, [c_i32, c_i32, c_vp, C.POINTER(c_vp)]),
+    "vdqn_allreduce_bucket": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "vdqn_comm_rank": (C.c_int, [c_vp]),
+    "vdqn_comm_size": (C.c_int, [c_vp]),
+    "vdqn_comm_destroy": (C.c_int, [c_vp]),
 }
+COMM_UID_BYTES = 128
 EXPORTS = tuple(_SIGS)
 
 _lib = None

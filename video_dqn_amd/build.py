@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 _VARIANT = os.environ.get("VDQN_LIB_OUT", "")
 OBJ_DIR = os.path.join(LIB_DIR, "obj", _VARIANT or "main")
 LIB_PATH = os.path.join(LIB_DIR, f"libvdqn{'_' + _VARIANT if _VARIANT else ''}.so")
-SOURCES = ["igemm.hip", "win9.hip", "stem.hip", "wgrad.hip", "pointwise.hip", "bn_train.hip", "engine.hip", "profile.hip"]
+SOURCES = ["igemm.hip", "win9.hip", "stem.hip", "wgrad.hip", "pointwise.hip", "bn_train.hip", "engine.hip", "profile.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm_common.h"), os.path.join(os.path.dirname(HERE), "include", "vdqn.h")]
 CFLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
@@ -84,7 +84,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(out)
     with open(flag_stamp, "w") as f:
         f.write(flags_txt)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-ldl", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

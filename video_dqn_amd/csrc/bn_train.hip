@@ -30,7 +30,7 @@ struct BnGeom {
 // grid (blocks, G).  MODE 0: (sum y, sum y^2)   MODE 1: (sum g, sum g * xhat)
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ a, const T* __restrict__ y, float* __restrict__ work, BnGeom gm, int C,
-                                                      int rows_per_block) {
+                                                      int rows_per_block, float* __restrict__ det_part) {
   constexpr int E16 = 16 / (int)sizeof(T);
   __shared__ float red[2][256 * E16];
   const int grp = blockIdx.y;
@@ -98,9 +98,26 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ a, c
       t1 += red[0][(st * cg_n + g) * E16 + e];
       t2 += red[1][(st * cg_n + g) * E16 + e];
     }
-    atomicAdd(wk + 4 * C + c, t1);
-    atomicAdd(wk + 5 * C + c, t2);
+    if (det_part) {  // deterministic mode: this block's partial sums as plain stores, added up in block order by bn_sums_reduce_kernel
+      float* o = det_part + ((size_t)grp * gridDim.x + blockIdx.x) * 2 * C;
+      o[c] = t1;
+      o[C + c] = t2;
+    } else {
+      atomicAdd(wk + 4 * C + c, t1);
+      atomicAdd(wk + 5 * C + c, t2);
+    }
   }
+}
+
+// deterministic mode, second stage: work[g][4..5][c] = sum over the blocks of group g of their partial sums, in block order
+__global__ void bn_sums_reduce_kernel(const float* __restrict__ part, float* __restrict__ work, int blocks, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  const int grp = blockIdx.y;
+  const float* p = part + (size_t)grp * blocks * 2 * C + i;
+  float t = 0.f;
+  for (int b = 0; b < blocks; ++b) t += p[(size_t)b * 2 * C];
+  work[(size_t)grp * 6 * C + 4 * C + i] = t;
 }
 
 // one thread per channel; the groups are consumed in order so the running statistics see the reference's update order
@@ -280,6 +297,12 @@ inline int apply_chunks(int per_img) {
   return b < 1 ? 1 : b;
 }
 
+template <typename T, int MODE>
+void launch_bn_sums(const void* a, const void* y, float* work, const BnGeom& gm, int c, int blocks, int rpb, float* det_ws, hipStream_t st) {
+  hipLaunchKernelGGL((bn_sums_kernel<T, MODE>), dim3(blocks, gm.groups), dim3(256), 0, st, (const T*)a, (const T*)y, work, gm, c, rpb, det_ws);
+  if (det_ws) hipLaunchKernelGGL(bn_sums_reduce_kernel, dim3((2 * c + 255) / 256, gm.groups), dim3(256), 0, st, det_ws, work, blocks, c);
+}
+
 int make_geom(const char* who, int n_img, int hw, int c, int frames, int iph, int dtype, BnGeom* gm) {
   VDQN_CHECK(n_img > 0 && hw > 0 && c > 0 && frames > 0 && iph > 0, "%s: bad sizes", who);
   VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "%s: bad dtype", who);
@@ -296,7 +319,25 @@ int make_geom(const char* who, int n_img, int hw, int c, int frames, int iph, in
   return VDQN_OK;
 }
 
+// deterministic mode: the workspace that takes one partial sum pair per block (nullptr = atomics)
+int det_workspace(const char* who, const BnSync* sync, const BnGeom& gm, int blocks, int c, float** out) {
+  *out = nullptr;
+  if (!sync || !sync->det_ws) return VDQN_OK;
+  const int64_t need = (int64_t)gm.groups * blocks * 2 * c * 4;
+  VDQN_CHECK(sync->det_ws_bytes >= need, "%s: deterministic workspace of %lld bytes, %lld needed", who, (long long)sync->det_ws_bytes, (long long)need);
+  VDQN_CHECK(((uintptr_t)sync->det_ws & 15) == 0, "%s: workspace must be 16-byte aligned", who);
+  *out = sync->det_ws;
+  return VDQN_OK;
+}
+
 }  // namespace
+
+extern "C" int64_t vdqn_bn_train_workspace_bytes(int32_t n_img, int32_t hw, int32_t c, int32_t num_frames, int32_t imgs_per_half) {
+  BnGeom gm;
+  if (make_geom("vdqn_bn_train_workspace_bytes", n_img, hw, c, num_frames, imgs_per_half, VDQN_F32, &gm) != VDQN_OK) return -1;
+  int rpb;
+  return (int64_t)gm.groups * grid_rows(gm.grp_rows, &rpb) * 2 * c * 4;
+}
 
 // sync (may be null): all-reduce hook + scratch for SyncBN; the statistics then cover grp_rows * sync->world rows
 int vdqn_bn_train_fwd_impl(const void* y, const void* resid, void* z, const float* gamma, const float* beta, float* running_mean,
@@ -310,11 +351,13 @@ int vdqn_bn_train_fwd_impl(const void* y, const void* resid, void* z, const floa
   VDQN_CHECK(e == hipSuccess, "vdqn_bn_train_fwd: memset failed: %s", hipGetErrorString(e));
   int rpb;
   const int blocks = grid_rows(gm.grp_rows, &rpb);
+  float* det_ws = nullptr;
+  if (int rc = det_workspace("vdqn_bn_train_fwd", sync, gm, blocks, c, &det_ws)) return rc;
   const double esz = dtype == VDQN_BF16 ? 2 : 4, elems = (double)n_img * hw * c;
   {
     ProfScope ps("bn_stats", 0.0, elems * esz, st);
-    if (dtype == VDQN_BF16) hipLaunchKernelGGL((bn_sums_kernel<bf16raw, 0>), dim3(blocks, gm.groups), dim3(256), 0, st, (const bf16raw*)y, (const bf16raw*)nullptr, work, gm, c, rpb);
-    else hipLaunchKernelGGL((bn_sums_kernel<float, 0>), dim3(blocks, gm.groups), dim3(256), 0, st, (const float*)y, (const float*)nullptr, work, gm, c, rpb);
+    if (dtype == VDQN_BF16) launch_bn_sums<bf16raw, 0>(y, nullptr, work, gm, c, blocks, rpb, det_ws, st);
+    else launch_bn_sums<float, 0>(y, nullptr, work, gm, c, blocks, rpb, det_ws, st);
   }
   int total_rows = gm.grp_rows;
   if (sync && sync->fn && sync->world > 1) {
@@ -337,9 +380,11 @@ int vdqn_bn_train_fwd_impl(const void* y, const void* resid, void* z, const floa
 
 extern "C" int vdqn_bn_train_fwd(const void* y, const void* resid, void* z, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, float* work, int32_t n_img, int32_t hw, int32_t c, int32_t num_frames,
-                                 int32_t imgs_per_half, int32_t relu, float momentum, float eps, int32_t dtype, void* stream) {
+                                 int32_t imgs_per_half, int32_t relu, float momentum, float eps, int32_t dtype, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  BnSync sy = {nullptr, nullptr, nullptr, 1, reinterpret_cast<float*>(workspace), workspace_bytes};
   return vdqn_bn_train_fwd_impl(y, resid, z, gamma, beta, running_mean, running_var, work, n_img, hw, c, num_frames, imgs_per_half, relu, momentum,
-                                eps, dtype, stream, nullptr);
+                                eps, dtype, stream, workspace ? &sy : nullptr);
 }
 
 // dgamma / dbeta receive the LOCAL sums (the flat gradient is summed over the ranks later); dy uses the global ones
@@ -351,11 +396,13 @@ int vdqn_bn_train_bwd_impl(const void* g, const void* y, void* dy, float* work, 
   hipStream_t st = (hipStream_t)stream;
   int rpb;
   const int blocks = grid_rows(gm.grp_rows, &rpb);
+  float* det_ws = nullptr;
+  if (int rc = det_workspace("vdqn_bn_train_bwd", sync, gm, blocks, c, &det_ws)) return rc;
   const double esz = dtype == VDQN_BF16 ? 2 : 4, elems = (double)n_img * hw * c;
   {
     ProfScope ps("bn_bwd_sums", 0.0, 2.0 * elems * esz, st);
-    if (dtype == VDQN_BF16) hipLaunchKernelGGL((bn_sums_kernel<bf16raw, 1>), dim3(blocks, gm.groups), dim3(256), 0, st, (const bf16raw*)g, (const bf16raw*)y, work, gm, c, rpb);
-    else hipLaunchKernelGGL((bn_sums_kernel<float, 1>), dim3(blocks, gm.groups), dim3(256), 0, st, (const float*)g, (const float*)y, work, gm, c, rpb);
+    if (dtype == VDQN_BF16) launch_bn_sums<bf16raw, 1>(g, y, work, gm, c, blocks, rpb, det_ws, st);
+    else launch_bn_sums<float, 1>(g, y, work, gm, c, blocks, rpb, det_ws, st);
   }
   if (dgamma || dbeta) hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, st, work, dgamma, dbeta, gm.groups, c);
   int total_rows = gm.grp_rows;
@@ -377,8 +424,10 @@ int vdqn_bn_train_bwd_impl(const void* g, const void* y, void* dy, float* work, 
 }
 
 extern "C" int vdqn_bn_train_bwd(const void* g, const void* y, void* dy, float* work, float* dgamma, float* dbeta, int32_t n_img, int32_t hw,
-                                 int32_t c, int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* stream) {
-  return vdqn_bn_train_bwd_impl(g, y, dy, work, dgamma, dbeta, n_img, hw, c, num_frames, imgs_per_half, dtype, stream, nullptr);
+                                 int32_t c, int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+  BnSync sy = {nullptr, nullptr, nullptr, 1, reinterpret_cast<float*>(workspace), workspace_bytes};
+  return vdqn_bn_train_bwd_impl(g, y, dy, work, dgamma, dbeta, n_img, hw, c, num_frames, imgs_per_half, dtype, stream, workspace ? &sy : nullptr);
 }
 
 extern "C" int vdqn_avgpool_fwd(const void* x, void* out, int32_t n_img, int32_t hw, int32_t c, int32_t dtype, void* stream) {

@@ -81,6 +81,8 @@ struct BnSync {
   void* user;
   float* scratch;        // device buffer for the packed sums (>= groups * 2 * channels floats)
   int world;
+  float* det_ws = nullptr;       // deterministic mode: per-block partial sums (vdqn_bn_train_workspace_bytes), else f32 atomics
+  int64_t det_ws_bytes = 0;
 };
 int vdqn_bn_train_fwd_impl(const void* y, const void* resid, void* z, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float* work, int32_t n_img, int32_t hw, int32_t c, int32_t num_frames, int32_t imgs_per_half,

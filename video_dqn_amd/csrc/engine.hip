@@ -29,7 +29,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 8; }
+extern "C" int vdqn_abi_version(void) { return 9; }
 
 namespace {
 
@@ -80,6 +80,7 @@ struct ActLayout {
   int64_t f8, l0, l1, q, qf;
   // ARCHITECTURE='basic' only: pooled features, raw (pre-BatchNorm) conv outputs, per-layer BatchNorm work areas
   int64_t avg, r_c1, r_h[8], r_o[8], r_ds[8], bnw[kMaxLayers], bnw_begin, bnw_bytes, bn_sync;
+  int64_t bn_det = -1, bn_det_bytes = 0;  // deterministic mode ('basic'): per-block partial sums of the train-mode BatchNorm kernels
   int64_t total;
 };
 struct BwdLayout {
@@ -695,6 +696,16 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
       if (net->layers[i].has_bn) L.bnw[i] = take((int64_t)2 * F * 6 * net->layers[i].co * 4);
     L.bnw_bytes = off - L.bnw_begin;
     L.bn_sync = take((int64_t)2 * F * 2 * 512 * 4);  // packed sums of one layer (SyncBN scratch)
+    if (net->cfg.deterministic) {  // ordered two-stage statistic sums: the largest per-block partial array of any layer and call shape
+      for (const Layer& ly : net->layers) {
+        if (!ly.has_bn) continue;
+        for (int halves = 1; halves <= 2; ++halves) {
+          if (n % halves || (n / halves) % F) continue;
+          L.bn_det_bytes = std::max(L.bn_det_bytes, vdqn_bn_train_workspace_bytes((int32_t)n, ly.ho * ly.wo, ly.co, (int32_t)F, (int32_t)(n / halves)));
+        }
+      }
+      L.bn_det = take(L.bn_det_bytes);
+    }
   }
   L.total = off;
   return L;
@@ -982,6 +993,10 @@ int run_bn(const vdqn_net* net, int li, const float* params, float* bnstats, uns
   const Layer& L = net->layers[li];
   BnSync sy = net->bn_sync;
   sy.scratch = reinterpret_cast<float*>(acts + A.bn_sync);
+  if (A.bn_det >= 0) {
+    sy.det_ws = reinterpret_cast<float*>(acts + A.bn_det);
+    sy.det_ws_bytes = A.bn_det_bytes;
+  }
   return vdqn_bn_train_fwd_impl(y, resid, z, params + L.g_off, params + L.b_off, bnstats + L.mean_off, bnstats + L.var_off,
                                 reinterpret_cast<float*>(acts + A.bnw[li]), n_img, L.ho * L.wo, L.co, net->cfg.num_frames, iph, relu, kBnMomentum,
                                 kBnEps, net->cfg.dtype, st, &sy);
@@ -1328,6 +1343,10 @@ int run_bn_bwd(const vdqn_net* net, const vdqn_step_args* a, int li, const ActLa
   const Layer& L = net->layers[li];
   BnSync sy = net->bn_sync;
   sy.scratch = reinterpret_cast<float*>((unsigned char*)a->acts_online + A.bn_sync);
+  if (A.bn_det >= 0) {
+    sy.det_ws = reinterpret_cast<float*>((unsigned char*)a->acts_online + A.bn_det);
+    sy.det_ws_bytes = A.bn_det_bytes;
+  }
   return vdqn_bn_train_bwd_impl(g, y, dy, reinterpret_cast<float*>((unsigned char*)a->acts_online + A.bnw[li]), a->grads + L.g_off, a->grads + L.b_off,
                                 n, L.ho * L.wo, L.co, net->cfg.num_frames, n, net->cfg.dtype, st, &sy);
 }

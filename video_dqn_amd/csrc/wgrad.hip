@@ -1108,7 +1108,9 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   else rc = pl.bt == 128 ? launch_wgrad<float, 128>(p, pl.tiles, pl.splitk, st) : launch_wgrad<float, 64>(p, pl.tiles, pl.splitk, st);
   if (rc != VDQN_OK) return rc;
   if (p.ws && pl.variant != 0) {
-    rc = launch_wgrad_reduce(p, pl.copies, pl.copy_elems, st);
+    // only the rows below co: the kernels store nothing for the padding rows co .. co_pad - 1 of a copy (dw keeps its zeros there,
+    // as in the atomic mode), and the caller's workspace is not initialised
+    rc = launch_wgrad_reduce(p, pl.copies, (long long)a->co * p.taps * a->ci, st);
     if (rc != VDQN_OK) return rc;
   }
   if (a->dbias) {

@@ -61,19 +61,57 @@ def image_net_transform(img_u8):
     return x.permute(2, 0, 1).contiguous()
 
 
+def tuple_columns(samples, gamma, value_learning=False, confidence_reward=False, inverse_actions=False, one_action=False,
+                  slam_actions=False):
+    """The non-image part of every tuple of a feather table, computed once for the whole table (the reference derives it row by
+    row inside __getitem__, dataloaders/q_learning_real.py:72-98; shards.write_shards stores the same columns): returns
+    (reward [N,5], gt [N,5] or None, action [N]).
+
+      reward : detector_score > per-category threshold as int64 (:82), or the raw scores under CONFIDENCE_REWARD (:78-80)
+      gt     : gamma ** steps_to_reward with inf -> NaN under VALUE_LEARNING (:85-87), else the scalar NaN
+      action : the `inverse_actions` column (:89-90) or zeros under ONE_ACTION (:93-94); SLAM actions were never implemented"""
+    det = multi_get(samples, "detector_score")
+    reward = det if confidence_reward else (det > detection_thresholds).astype(np.int64)
+    gt = None
+    if value_learning:
+        steps = multi_get(samples, "steps_to_reward")
+        gt = np.power(np.full(steps.shape, gamma), steps)
+        gt[steps == np.inf] = np.nan
+    if inverse_actions:
+        action = samples["inverse_actions"].to_numpy()
+    elif slam_actions:
+        raise NotImplementedError("not implemented")  # :91-92
+    elif one_action:
+        action = np.zeros(len(samples), dtype=np.int64)
+    else:
+        raise Exception("not implemented")  # :95-96
+    return reward, gt, action
+
+
 class QLearningRealDataset(data.Dataset):
+    """Same constructor arguments and the same 7-tuple per index as dataloaders/q_learning_real.py:27-98.  The table columns are
+    turned into arrays once (``tuple_columns``); ``__getitem__`` only decodes the two frames (or 2 x 4 under PREVIOUS_IMAGES)
+    and indexes those arrays."""
+
+    _FRAME = re.compile(r"(.*?/)(\d+).jpg")
+
     def __init__(self, location=None, one_action=False, value_learning=False, inverse_actions=False,
                  previous_images=False, confidence_reward=False, slam_actions=False, gamma=0.99, as_uint8=False):
         import pandas as pd
         self.samples = pd.read_feather(location)  # :37
-        self.value_learning = value_learning
-        self.confidence_reward = confidence_reward
-        self.slam_actions = slam_actions
-        self.one_action = one_action
-        self.inverse_actions = inverse_actions
-        self.gamma = gamma
-        self.previous_images = previous_images
-        self.as_uint8 = as_uint8
+        self.gamma, self.as_uint8, self.previous_images = gamma, as_uint8, previous_images
+        self.value_learning, self.confidence_reward = value_learning, confidence_reward
+        self.slam_actions, self.one_action, self.inverse_actions = slam_actions, one_action, inverse_actions
+        self._mode_error = None
+        try:
+            self._reward, self._gt, self._action = tuple_columns(self.samples, gamma, value_learning, confidence_reward,
+                                                                 inverse_actions, one_action, slam_actions)
+        except Exception as e:  # the reference raises at the first __getitem__, not in the constructor
+            if len(e.args) != 1 or e.args[0] != "not implemented":
+                raise
+            self._mode_error = e
+        self._paths = (self.samples["before_image"].to_numpy(), self.samples["after_image"].to_numpy())
+        self._start = self.samples["im_start"].to_numpy() if previous_images else None
 
     def __len__(self):
         return len(self.samples)
@@ -87,42 +125,22 @@ class QLearningRealDataset(data.Dataset):
         u8 = resize_center_crop_u8(Image.open(path))
         return torch.from_numpy(u8.copy()) if self.as_uint8 else image_net_transform(u8)
 
+    def _frames(self, path, index):
+        if not self.previous_images:
+            return self._load(path)
+        # :60-67  frames id, id-1, id-2, id-3 of the same episode folder, clamped at the episode's first frame
+        m = self._FRAME.match(path)
+        first = self._start[index]
+        return torch.stack([self._load(m[1] + "%04d.jpg" % max(int(m[2]) - back, first)) for back in range(4)])
+
     def __getitem__(self, index):  # :55-98
-        sample = self.samples.loc[index]
-        if self.previous_images:
-            start = sample["im_start"]
-
-            def get_ims(path):  # :60-67  frames id, id-1, id-2, id-3 clamped at the episode start
-                m = re.match(r"(.*?/)(\d+).jpg", path)
-                prefix, im_id = m[1], int(m[2])
-                ids = [max(im_id - i, start) for i in range(4)]
-                return torch.stack([self._load(prefix + "%04d.jpg" % i) for i in ids])
-
-            bi = get_ims(sample["before_image"])
-            ai = get_ims(sample["after_image"])
-        else:
-            bi = self._load(sample["before_image"])
-            ai = self._load(sample["after_image"])
-        detections = multi_get(sample, "detector_score")
-        steps_to_reward = multi_get(sample, "steps_to_reward")
-        if self.confidence_reward:
-            reward = detections  # :78-80 (the reference's `termainl` typo leaves terminal = reward below)
-        else:
-            reward = (detections > detection_thresholds).astype(np.int64)  # :82
-        valid_mask = np.ones_like(reward)
-        gt = np.nan
-        if self.value_learning:
-            gt = np.power(np.ones((5,)) * self.gamma, steps_to_reward)
-            gt[steps_to_reward == np.inf] = np.nan
-        if self.inverse_actions:
-            action = sample["inverse_actions"]
-        elif self.slam_actions:
-            raise NotImplementedError("not implemented")
-        elif self.one_action:
-            action = 0
-        else:
-            raise Exception("not implemented")
-        return bi, ai, action, reward, reward, gt, valid_mask  # :98 (reward twice, as the reference)
+        if self._mode_error is not None:
+            raise self._mode_error
+        before, after = (self._frames(col[index], index) for col in self._paths)
+        reward = self._reward[index]
+        gt = self._gt[index] if self._gt is not None else np.nan
+        # (reward twice: the reference's `termainl` typo, :80, leaves terminal = reward in every mode; :98)
+        return before, after, self._action[index], reward, reward, gt, np.ones_like(reward)
 
 
 class SyntheticTupleDataset(data.Dataset):

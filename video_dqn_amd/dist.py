@@ -40,6 +40,65 @@ class BucketAllReduce:
         self._works.clear()
 
 
+class CAbiBucketAllReduce:
+    """The same exchange through the C ABI's own RCCL entries (include/vdqn.h: vdqn_comm_init / vdqn_allreduce_bucket) instead
+    of torch.distributed — what a caller that binds the header without PyTorch's process group does.  The 128-byte
+    rendezvous id travels through a file (`uid_path`: rank 0 writes it, the others wait for it).  Same contract as
+    BucketAllReduce: ``launch`` is called with the stream current on which the stage's gradients are complete and queues the
+    collective there; ``finish`` makes the then-current stream wait for all queued collectives."""
+
+    def __init__(self, rank: int, world_size: int, uid_path: str, force: bool = False, timeout_s: float = 120.0):
+        import ctypes as C
+        import os
+        import time
+        from . import _lib
+        self._lib, self._C = _lib, C
+        self.lib = _lib.load()
+        self.world_size, self.force = world_size, force
+        self.bucket_bytes: List[int] = []
+        self._events: List = []
+        uid = C.create_string_buffer(_lib.COMM_UID_BYTES)
+        if rank == 0:
+            _lib.check(self.lib.vdqn_comm_unique_id(uid), "vdqn_comm_unique_id")
+            tmp = uid_path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(uid.raw)
+            os.replace(tmp, uid_path)
+        else:
+            t0 = time.monotonic()
+            while not os.path.exists(uid_path):
+                if time.monotonic() - t0 > timeout_s:
+                    raise _lib.VdqnError(f"rank {rank}: no rendezvous id at {uid_path} after {timeout_s} s")
+                time.sleep(0.02)
+            uid.raw = open(uid_path, "rb").read()
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.vdqn_comm_init(rank, world_size, uid, C.byref(self.handle)), "vdqn_comm_init")
+
+    def launch(self, grad_slice: torch.Tensor, stage: int) -> None:
+        if self.world_size == 1 and not self.force:
+            return
+        if stage == 0:
+            self.bucket_bytes = []
+        self.bucket_bytes.append(grad_slice.numel() * grad_slice.element_size())
+        st = torch.cuda.current_stream()
+        self._lib.check(self.lib.vdqn_allreduce_bucket(self.handle, grad_slice.data_ptr(), grad_slice.numel(), self._lib.VDQN_F32,
+                                                       st.cuda_stream), "vdqn_allreduce_bucket")
+        ev = torch.cuda.Event()
+        ev.record(st)
+        self._events.append(ev)
+
+    def finish(self) -> None:
+        cur = torch.cuda.current_stream()
+        for ev in self._events:
+            cur.wait_event(ev)
+        self._events.clear()
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.vdqn_comm_destroy(self.handle)
+            self.handle = None
+
+
 def shard_indices(n_items: int, rank: int, world_size: int, batch_per_rank: int, epoch_perm) -> list:
     """Rank-strided, drop_last sharding of one shuffled epoch (mirrors DataLoader(shuffle=True, drop_last=True),
     train_q_network.py:98,114): rank r takes perm[r::world]; every rank gets the same number of full batches."""

@@ -74,6 +74,33 @@ def _init_like_reference(engine: NetEngine, seed=None):
     engine.mark_dirty()
 
 
+def load_torchvision_resnet18(engine: NetEngine, sd, source: str = "state_dict") -> int:
+    """`models.resnet18(pretrained=True)` (archs/HabitatDQNMultiAction.py:11) from a file: copy a torchvision-keyed ResNet-18
+    state_dict ('conv1.weight', 'layer1.0.bn1.running_mean', ..., 'fc.bias') into the engine's `resnet.*` tensors.  Strict, as
+    torchvision's own load_state_dict is: EVERY trunk tensor the engine holds (20 convolutions, 20 BatchNorm layers with their
+    running statistics, the frozen fc) must be present with its exact shape; a file that covers only part of the trunk, or a
+    tensor of the wrong shape (a ResNet-34 / a different width), is an error and nothing is copied.  `num_batches_tracked`
+    entries are accepted and ignored (eval-mode statistics do not use them); any other unknown key is an error.  Returns the
+    number of tensors copied."""
+    if hasattr(sd, "state_dict"):
+        sd = sd.state_dict()
+    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]  # the Places365 checkpoints the paper's footnote points at wrap the tensors this way
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    want = {name[len("resnet."):]: s for name, s in engine.slots.items() if name.startswith("resnet.")}
+    missing = sorted(k for k in want if k not in sd)
+    unknown = sorted(k for k in sd if k not in want and not k.endswith("num_batches_tracked"))
+    wrong = sorted(f"{k}: {tuple(sd[k].shape)} != {tuple(want[k].shape)}" for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k].shape))
+    if missing or unknown or wrong:
+        raise ValueError(f"{source} is not a torchvision ResNet-18 state_dict: {len(missing)} trunk tensors missing "
+                         f"(e.g. {missing[:3]}), {len(unknown)} unknown keys (e.g. {unknown[:3]}), {len(wrong)} wrong shapes (e.g. {wrong[:3]})")
+    with torch.no_grad():
+        for k in want:
+            engine.view("resnet." + k).copy_(sd[k].to(torch.float32))
+    engine.mark_dirty()
+    return len(want)
+
+
 class HabitatDQNMultiAction(nn.Module):
     def __init__(self, action_dim, num_classes=5, extra_capacity=False, panorama=True, num_frames=None,
                  dtype=None, device=None, max_batch=64, pretrained_weights=None, deterministic=None):
@@ -97,17 +124,8 @@ class HabitatDQNMultiAction(nn.Module):
         pre = pretrained_weights or os.environ.get("VDQN_RESNET18_WEIGHTS")
         self.pretrained_loaded = False
         if pre:
-            sd = torch.load(pre, map_location="cpu")
-            hit = 0
-            with torch.no_grad():
-                for k, v in sd.items():
-                    if "resnet." + k in self.engine.slots:
-                        self.engine.view("resnet." + k).copy_(v)
-                        hit += 1
-            if hit == 0:
-                raise ValueError(f"{pre}: no tensor of a torchvision resnet18 state_dict found (expected keys like 'conv1.weight')")
+            load_torchvision_resnet18(self.engine, torch.load(pre, map_location="cpu"), source=str(pre))
             self.pretrained_loaded = True
-            self.engine.mark_dirty()
 
     # ---- structure ----------------------------------------------------------------------------------
     def _build_tree(self):

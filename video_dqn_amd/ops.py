@@ -67,9 +67,10 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
 
 def conv2d_wgrad(gy: torch.Tensor, x: torch.Tensor, *, co: int, r: int, s: int, stride: int, pad: int,
                  ci: Optional[int] = None, pix_stride: Optional[int] = None, splitk: int = 0, want_dbias: bool = True,
-                 deterministic: bool = False):
+                 deterministic: bool = False, poison_workspace: bool = False):
     """gy: [n, ho, wo, ldg]; x: [n, hi, wi, c].  Returns dw f32 [co_pad, r, s, ci] (and dbias [co_pad]).
-    deterministic: the two-stage ordered reduction (a workspace of vdqn_conv2d_wgrad_workspace_bytes) instead of atomics."""
+    deterministic: the two-stage ordered reduction (a workspace of vdqn_conv2d_wgrad_workspace_bytes) instead of atomics;
+    poison_workspace fills that workspace with NaN first (tests: nothing the call does not write may reach dw)."""
     lib = _lib.load()
     n, ho, wo, ldg = gy.shape
     _, hi, wi, cx = x.shape
@@ -90,6 +91,8 @@ def conv2d_wgrad(gy: torch.Tensor, x: torch.Tensor, *, co: int, r: int, s: int, 
         if nbytes < 0:
             _lib.check(-1, "vdqn_conv2d_wgrad_workspace_bytes")
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        if poison_workspace:
+            ws.fill_(0xFF)  # every f32 word a NaN
         a.workspace, a.workspace_bytes = _ptr(ws), nbytes
     _lib.check(lib.vdqn_conv2d_wgrad(C.byref(a), _stream()), "vdqn_conv2d_wgrad")
     return (dw, db) if want_dbias else dw
@@ -183,22 +186,33 @@ def adam(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
 
 
 def bn_train_fwd(y: torch.Tensor, gamma, beta, running_mean=None, running_var=None, *, resid=None, relu=False,
-                 num_frames=1, imgs_per_half=None, momentum=0.1, eps=1e-5):
+                 num_frames=1, imgs_per_half=None, momentum=0.1, eps=1e-5, deterministic=False):
     """Train-mode BatchNorm2d over NHWC y [n, h, w, c] (statistic groups: see include/vdqn.h).
-    Returns (z, work) — `work` f32 [groups, 6, c] is what bn_train_bwd needs."""
+    Returns (z, work) — `work` f32 [groups, 6, c] is what bn_train_bwd needs.
+    deterministic: ordered two-stage statistic sums (a NaN-filled workspace of vdqn_bn_train_workspace_bytes) instead of atomics."""
     lib = _lib.load()
     n, h, w, c = y.shape
     iph = n if imgs_per_half is None else imgs_per_half
     groups = n // iph * num_frames
     z = torch.empty_like(y)
     work = torch.zeros((groups, 6, c), dtype=torch.float32, device=y.device)
+    ws, nbytes = _bn_workspace(lib, y, n, h * w, c, num_frames, iph, deterministic)
     _lib.check(lib.vdqn_bn_train_fwd(_ptr(y), _ptr(resid), _ptr(z), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                     _ptr(work), n, h * w, c, num_frames, iph, int(relu), momentum, eps, dtype_code(y), _stream()),
-               "vdqn_bn_train_fwd")
+                                     _ptr(work), n, h * w, c, num_frames, iph, int(relu), momentum, eps, dtype_code(y), _ptr(ws), nbytes,
+                                     _stream()), "vdqn_bn_train_fwd")
     return z, work
 
 
-def bn_train_bwd(g: torch.Tensor, y: torch.Tensor, work: torch.Tensor, *, num_frames=1, imgs_per_half=None):
+def _bn_workspace(lib, y, n, hw, c, num_frames, iph, deterministic):
+    if not deterministic:
+        return None, 0
+    nbytes = lib.vdqn_bn_train_workspace_bytes(n, hw, c, num_frames, iph)
+    if nbytes < 0:
+        _lib.check(-1, "vdqn_bn_train_workspace_bytes")
+    return torch.full((max(nbytes, 16),), 0xFF, dtype=torch.uint8, device=y.device), nbytes
+
+
+def bn_train_bwd(g: torch.Tensor, y: torch.Tensor, work: torch.Tensor, *, num_frames=1, imgs_per_half=None, deterministic=False):
     """Returns (dy, dgamma, dbeta) for the BatchNorm whose forward filled `work`."""
     lib = _lib.load()
     n, h, w, c = y.shape
@@ -206,8 +220,9 @@ def bn_train_bwd(g: torch.Tensor, y: torch.Tensor, work: torch.Tensor, *, num_fr
     dy = torch.empty_like(y)
     dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    ws, nbytes = _bn_workspace(lib, y, n, h * w, c, num_frames, iph, deterministic)
     _lib.check(lib.vdqn_bn_train_bwd(_ptr(g), _ptr(y), _ptr(dy), _ptr(work), _ptr(dgamma), _ptr(dbeta), n, h * w, c, num_frames, iph,
-                                     dtype_code(y), _stream()), "vdqn_bn_train_bwd")
+                                     dtype_code(y), _ptr(ws), nbytes, _stream()), "vdqn_bn_train_bwd")
     return dy, dgamma, dbeta
 
 

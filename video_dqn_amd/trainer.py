@@ -242,16 +242,13 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                             valid if config.REMOVE_BEFORE_REWARD else None,
                             gt if config.TRAIN_ON_GROUND_TRUTH else None,
                             finish_allreduce=(comm.finish if comm else None))
-        # every rank's `loss` is its share of the global mean (the TD kernel divides by the global batch).  The sum over
-        # ranks is only needed where the reference reports the loss — the tensorboard scalar every 100 updates (:236-238)
-        # and the checkpoint step — so the collective runs at that cadence, not per update; in between rank 0's progress
-        # line shows its own share scaled by the world size (an unbiased estimate of the global mean)
-        report = world_size > 1 and (sample_number % 100 == 0 or sample_number % config.CHECKPOINT_INTERVAL == 0 or sample_number == num_steps)
-        if report:
+        # every rank's `loss` is its share of the global mean (the TD kernel divides by the global batch): their SUM is the
+        # batch-mean loss the reference feeds into its running average every update (:228-231).  The 4-byte all-reduce is
+        # queued on the compute stream every update (tens of microseconds beside a multi-millisecond update), so the average
+        # that is printed, logged and returned is the reference's: an EMA of the true global batch-mean loss
+        if world_size > 1:
             loss = loss.clone()
             torch.distributed.all_reduce(loss)
-        elif world_size > 1:
-            loss = loss * float(world_size)
         slot = sample_number & 1
         host_loss[slot:slot + 1].copy_(loss, non_blocking=True)
         ev = torch.cuda.Event()
@@ -259,9 +256,13 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
         if pending is not None:
             consume(pending)
         pending = (slot, ev)
+        log_now = sample_number % 100 == 0 and rank == 0 and hasattr(config, "writer")
+        if log_now:  # the reference logs the average INCLUDING this update's loss (:228-238): take it in before writing
+            consume(pending)
+            pending = None
         if rank == 0 and running_loss is not None:
             print(f"\rbatch:{sample_number}/{config.NUM_STEPS} avg_loss: {running_loss}", end="")
-        if sample_number % 100 == 0 and rank == 0 and running_loss is not None and hasattr(config, "writer"):
+        if log_now and running_loss is not None:
             config.writer.add_scalar("avg_q_loss/train", running_loss, sample_number)  # :236-238
         if sample_number % config.CHECKPOINT_INTERVAL == 0 and rank == 0:  # :241-247
             torch.cuda.synchronize()
