@@ -94,6 +94,15 @@ typedef struct vdqn_conv_args {
   const float* bias2;
   void* out2;
   int32_t co2, ldo2, relu2, ci2;
+  /* Optional grouped forward (mode 0, no sibling / mask / column sums): TWO weight sets over one batch — images [0, split_img)
+   * are computed with wt / bias, images [split_img, n_img) with wt_b / bias_b (same shapes).  One TD update runs the online
+   * network on [s; s'] and the target network on s' (train_q_network.py:131,140,142): with the three image ranges in one tensor
+   * every layer is one launch instead of two.  Each output element is bit-identical to the two separate calls; kernels without a
+   * grouped form (or a split that is not a multiple of their tile height) run the two ranges as two launches internally.
+   * All NULL / 0 = plain call. */
+  const void* wt_b;
+  const float* bias_b;
+  int32_t split_img;
 } vdqn_conv_args;
 int vdqn_conv2d(const vdqn_conv_args* a, void* stream);
 
@@ -357,8 +366,11 @@ typedef struct vdqn_step_args {
   float gamma;
   float inv_count;            /* 1 / (num_classes * global_batch) */
   int32_t clip_rect, linear, use_valid, train_on_ground_truth, value_learning;
-  void* acts_online;          /* vdqn_net_acts_bytes(2B) */
-  void* acts_target;          /* vdqn_net_acts_bytes(B)  */
+  void* acts_online;          /* vdqn_net_acts_bytes(2B); vdqn_net_acts_bytes(3B) when acts_target is NULL (grouped forward) */
+  void* acts_target;          /* vdqn_net_acts_bytes(B); NULL (TD branch, extra_capacity only) = GROUPED forward: the target network's
+                                 pass over s' shares the online workspace (samples 2B .. 3B-1 of every activation tensor) and every
+                                 layer behind the stem is ONE launch over [s | s' | s'] with two weight sets (vdqn_conv_args.wt_b):
+                                 bit-identical Q-values, a third fewer launches */
   void* bwd;                  /* vdqn_net_bwd_bytes(B)   */
   float* grads;               /* flat f32 [trainable_numel] */
   float* loss;                /* f32 scalar (device) */

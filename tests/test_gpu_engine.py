@@ -84,7 +84,7 @@ def _run_steps(dtype, steps, B=8):
                         term.float().to(DEV))
         torch.cuda.synchronize()
         out.append(dict(loss=loss.item(), q_before=stp.q_before.cpu().clone(), grads=stp.grads.cpu().clone(),
-                        params=net.params.cpu().clone(), acts=stp.acts_online))
+                        params=net.params.cpu().clone(), acts=stp.acts_online, layout_samples=stp.layout_samples))
     return net, out
 
 
@@ -211,7 +211,7 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
         m0.load_state_dict(synth.make_state_dict(7))
         m0.eval()
         feats = _oracle_relu_outputs(m0, tup[0])
-        flips = _count_relu_flips(net, out[0]["acts"], 2 * B, B, feats)
+        flips = _count_relu_flips(net, out[0]["acts"], out[0]["layout_samples"], B, feats)
         total = sum(int(v.numel()) for v in feats.values())
         assert flips <= 1e-5 * total
         bad, report = _f64_yardstick(net, out[0]["grads"], make_trainer, tup, "f32 parity gate (B=8, F=1)")
@@ -375,7 +375,7 @@ def test_td_step_multi_frame_matches_oracle_f32():
     assert abs(stp.loss.item() - loss.item()) <= 1e-4 * abs(loss.item())
     assert relerr(stp.q_before, d["before_values"].detach().reshape(B, 15)) < 1e-3
     feats = _oracle_relu_outputs(tr.model, before.reshape(B * F, 3, 224, 224))
-    flips = _count_relu_flips(net, stp.acts_online, 2 * B, B * F, feats)
+    flips = _count_relu_flips(net, stp.acts_online, stp.layout_samples, B * F, feats)
     assert flips <= 8
     bad, report = _f64_yardstick(net, stp.grads, lambda: ref_cpu.Trainer(ref_cpu.default_config(), synth.make_state_dict(7, num_frames=F), num_frames=F),
                                  tup, f"f32 parity gate (B={B}, F={F})")
@@ -405,6 +405,48 @@ def test_side_stream_overlap_matches_serial():
             assert abs(l - res[0][1]) <= 1e-6 * abs(res[0][1])
             assert relerr(g, res[0][0]) < 1e-5, rep
     net.lib.vdqn_net_set_overlap(net.handle, 1)
+
+
+@pytest.mark.parametrize("dtype,B,F", [("bf16", 128, 1), ("bf16", 8, 1), ("f32", 4, 1), ("bf16", 4, 4)])
+def test_grouped_forward_is_bit_identical_to_two_passes(dtype, B, F):
+    """The online pass over [s; s'] and the target pass over s' as ONE chain of grouped launches (vdqn_step_args.acts_target == NULL,
+    vdqn_conv_args.wt_b: tiles from row 2B*H*W on take the target network's weights) against the two separate passes
+    (train_q_network.py:131,140,142 — three model calls): Q(s), the online Q(s'), the TARGET Q(s') and every saved activation
+    of the online range must be the same bits, hence loss and (deterministic mode) gradients too.  B = 128 puts every layer on
+    its grouped kernel (split rows a multiple of 256); B = 8 / 4 mix grouped kernels with the internal two-launch fall-back
+    (14 x 14 and 7 x 7 maps: 2B*H*W is not a multiple of the tile height); f32 runs the kernels that have no grouped form."""
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    res = {}
+    for grouped in (False, True):
+        net = NetEngine(3, 5, F, True, dtype, 2 * B, deterministic=True)
+        net.load_tensors(synth.make_state_dict(7, num_frames=F))
+        stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, grouped_forward=grouped)
+        tnet = NetEngine(3, 5, F, True, dtype, 2 * B)
+        tnet.load_tensors(synth.make_state_dict(8, num_frames=F))  # a target network that differs from the online one
+        tnet.pack_weights(stp.packed_target)
+        assert stp.grouped == grouped and (stp.acts_target is None) == grouped
+        (tup, raw) = synth.make_batch(900 + B, B, F, structured=True, reward_p=0.3)
+        stp.forward_backward(torch.from_numpy(raw[0]).to(DEV), torch.from_numpy(raw[1]).to(DEV), 0, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV))
+        torch.cuda.synchronize()
+        n = stp.layout_samples
+        q_all = _act_f32(net, stp.acts_online, n, "qf", (n, 64)).clone()
+        q_tgt = q_all[2 * B:3 * B] if grouped else _act_f32(net, stp.acts_target, B, "qf", (B, 64)).clone()
+        acts = {name: _act(net, stp.acts_online, n, name, (n * F, 56 >> (int(name[1]) // 2), 56 >> (int(name[1]) // 2), 64 << (int(name[1]) // 2)))[:2 * B * F].clone()
+                for name in ("o0", "h2", "o3", "o5", "h7", "o7")}
+        res[grouped] = (q_all[:2 * B], q_tgt, stp.loss.clone(), stp.grads.clone(), acts)
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0]), "online Q differs"
+    assert torch.equal(a[1], b[1]), "target Q differs"
+    assert (a[1] != a[0][B:]).any()  # the target range really used the other weight set
+    for name in a[4]:
+        assert torch.equal(a[4][name], b[4][name]), name
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+def _act_f32(net, buf, n_samples, name, shape):
+    off = net.lib.vdqn_net_act_offset(net.handle, n_samples, name.encode())
+    assert off >= 0, name
+    return buf[off:off + int(np.prod(shape)) * 4].view(torch.float32).view(shape)
 
 
 @pytest.mark.parametrize("dtype,B", [("bf16", 16), ("f32", 6)])

@@ -25,7 +25,8 @@ class ConvArgs(C.Structure):
                 ("r", c_i32), ("s", c_i32), ("stride", c_i32), ("pad", c_i32),
                 ("mode", c_i32), ("relu", c_i32), ("dtype", c_i32),
                 ("in2", c_vp), ("wt2", c_vp), ("bias2", c_vp), ("out2", c_vp),
-                ("co2", c_i32), ("ldo2", c_i32), ("relu2", c_i32), ("ci2", c_i32)]
+                ("co2", c_i32), ("ldo2", c_i32), ("relu2", c_i32), ("ci2", c_i32),
+                ("wt_b", c_vp), ("bias_b", c_vp), ("split_img", c_i32)]
 
 
 class WgradArgs(C.Structure):

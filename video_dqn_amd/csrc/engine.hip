@@ -846,13 +846,20 @@ int fuse_ds_mask() {
 bool fuse_ds() { return (fuse_ds_mask() & 1) != 0; }
 bool fuse_ds_fwd() { return (fuse_ds_mask() & 2) != 0; }
 
+// packed_b / split_units: grouped forward — units [split_units, n_units) run with the second network's packed weights
 int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* in, void* out, int n_units, const void* resid,
-             int relu, float* out_f32, hipStream_t st, const Layer* sib = nullptr, void* sib_out = nullptr) {
+             int relu, float* out_f32, hipStream_t st, const Layer* sib = nullptr, void* sib_out = nullptr, const unsigned char* packed_b = nullptr,
+             int split_units = 0) {
   vdqn_conv_args a;
   memset(&a, 0, sizeof(a));
   a.in = in;
   a.wt = packed + L.wf_off;
   a.bias = reinterpret_cast<const float*>(packed + L.bias_off);
+  if (packed_b) {
+    a.wt_b = packed_b + L.wf_off;
+    a.bias_b = reinterpret_cast<const float*>(packed_b + L.bias_off);
+    a.split_img = split_units;
+  }
   a.resid = resid;
   a.mask = nullptr;
   a.out = out;
@@ -944,34 +951,43 @@ int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const voi
   } while (0)
 
 // forward over n_samples samples whose packed input already sits at `t_in`
+// packed_b != nullptr: GROUPED pass — samples [0, split_samples) with `packed`, samples [split_samples, n_samples) with `packed_b`
+// (the online network on [s; s'] and the target network on s' of one TD update as ONE chain of launches; t_in_b = packed frames of
+// the second range).  The stem runs once per range (its weights live in registers), every later layer is one vdqn_conv2d call.
 int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t_in, int n_samples, unsigned char* acts, const ActLayout& A,
-                 hipStream_t st, bool trunk_only = false) {
+                 hipStream_t st, bool trunk_only = false, const unsigned char* packed_b = nullptr, int split_samples = 0, const void* t_in_b = nullptr) {
   const int n = n_samples * net->cfg.num_frames;
   const int dt = net->cfg.dtype;
+  const int n_a = packed_b ? split_samples * net->cfg.num_frames : n;  // frames of the first range
   if (A.c1 >= 0) {  // 'basic' eval path keeps the separate kernels (its train path needs the raw conv output anyway)
     RC(run_conv(net, net->layers[net->l_conv1], packed, t_in, acts + A.c1, n, nullptr, 1, nullptr, st));
     RC(vdqn_maxpool_fwd(acts + A.c1, acts + A.pool, acts + A.idx, n, 112, 112, 64, dt, st));
   } else {
     const Layer& L1 = net->layers[net->l_conv1];
-    prof_layer(L1, n);
-    RC(vdqn_stem_conv_pool(t_in, packed + L1.wf_off, reinterpret_cast<const float*>(packed + L1.bias_off), acts + A.pool, acts + A.idx, n, dt, st));
+    prof_layer(L1, n_a);
+    RC(vdqn_stem_conv_pool(t_in, packed + L1.wf_off, reinterpret_cast<const float*>(packed + L1.bias_off), acts + A.pool, acts + A.idx, n_a, dt, st));
+    if (packed_b) {
+      prof_layer(L1, n - n_a);
+      RC(vdqn_stem_conv_pool(t_in_b, packed_b + L1.wf_off, reinterpret_cast<const float*>(packed_b + L1.bias_off),
+                             acts + A.pool + (int64_t)n_a * 56 * 56 * 64 * net->esz, acts + A.idx + (int64_t)n_a * 56 * 56 * 64, n - n_a, dt, st));
+    }
   }
   const unsigned char* x = acts + A.pool;
   for (int b = 0; b < 8; ++b) {
     const Layer& c1 = net->layers[net->l_b_conv1[b]];
     const Layer& c2 = net->layers[net->l_b_conv2[b]];
     const void* identity = x;
-    if (net->l_b_ds[b] >= 0 && fuse_ds_fwd()) {  // stride-2 block: conv1 and the downsample read the same pixels — one launch
+    if (net->l_b_ds[b] >= 0 && fuse_ds_fwd() && !packed_b) {  // stride-2 block: conv1 and the downsample read the same pixels — one launch
       RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st, &net->layers[net->l_b_ds[b]], acts + A.ds[b]));
       identity = acts + A.ds[b];
     } else {
-      RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st));
+      RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st, nullptr, nullptr, packed_b, n_a));
       if (net->l_b_ds[b] >= 0) {
-        RC(run_conv(net, net->layers[net->l_b_ds[b]], packed, x, acts + A.ds[b], n, nullptr, 0, nullptr, st));
+        RC(run_conv(net, net->layers[net->l_b_ds[b]], packed, x, acts + A.ds[b], n, nullptr, 0, nullptr, st, nullptr, nullptr, packed_b, n_a));
         identity = acts + A.ds[b];
       }
     }
-    RC(run_conv(net, c2, packed, acts + A.h[b], acts + A.o[b], n, identity, 1, nullptr, st));
+    RC(run_conv(net, c2, packed, acts + A.h[b], acts + A.o[b], n, identity, 1, nullptr, st, nullptr, nullptr, packed_b, n_a));
     x = acts + A.o[b];
   }
   if (trunk_only) return VDQN_OK;  // the 512 x 7 x 7 features are in o7
@@ -980,10 +996,11 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
     RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.avg, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
     return VDQN_OK;
   }
-  RC(run_conv(net, net->layers[net->l_f8], packed, x, acts + A.f8, n, nullptr, 1, nullptr, st));
-  RC(run_conv(net, net->layers[net->l_top0], packed, acts + A.f8, acts + A.l0, n_samples, nullptr, 1, nullptr, st));
-  RC(run_conv(net, net->layers[net->l_top2], packed, acts + A.l0, acts + A.l1, n_samples, nullptr, 1, nullptr, st));
-  RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.l1, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
+  RC(run_conv(net, net->layers[net->l_f8], packed, x, acts + A.f8, n, nullptr, 1, nullptr, st, nullptr, nullptr, packed_b, n_a));
+  RC(run_conv(net, net->layers[net->l_top0], packed, acts + A.f8, acts + A.l0, n_samples, nullptr, 1, nullptr, st, nullptr, nullptr, packed_b, split_samples));
+  RC(run_conv(net, net->layers[net->l_top2], packed, acts + A.l0, acts + A.l1, n_samples, nullptr, 1, nullptr, st, nullptr, nullptr, packed_b, split_samples));
+  RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.l1, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st, nullptr, nullptr,
+              packed_b, split_samples));
   return VDQN_OK;
 }
 
@@ -1220,16 +1237,30 @@ extern "C" int vdqn_net_forward_train(vdqn_net* net, const float* params, float*
   return VDQN_OK;
 }
 
+// Grouped TD update (vdqn_step_args.acts_target == NULL): online and target forward share one 3B-sample workspace.
+static bool step_grouped(const vdqn_net* net, const vdqn_step_args* a) {
+  return !a->train_on_ground_truth && a->acts_target == nullptr && !net->basic();
+}
+// samples the `acts_online` workspace of this update is laid out for
+static int step_layout_samples(const vdqn_net* net, const vdqn_step_args* a) {
+  if (a->train_on_ground_truth) return a->batch;
+  return step_grouped(net, a) ? 3 * a->batch : 2 * a->batch;
+}
+
 extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream) {
   VDQN_CHECK(net && a, "vdqn_net_td_forward: null arg");
   VDQN_CHECK(a->params && a->bnstats && a->packed_online && a->before && a->act && a->acts_online && a->bwd && a->loss, "vdqn_net_td_forward: null buffer");
   const int B = a->batch;
   const bool gtb = a->train_on_ground_truth != 0;
   VDQN_CHECK(B >= 1 && 2 * B <= net->cfg.max_batch, "vdqn_net_td_forward: batch %d needs max_batch >= %d", B, 2 * B);
-  VDQN_CHECK(gtb ? (a->gt != nullptr) : (a->after && a->packed_target && a->acts_target && a->rew && a->term), "vdqn_net_td_forward: missing inputs for this loss branch");
+  VDQN_CHECK(gtb ? (a->gt != nullptr) : (a->after && a->packed_target && a->rew && a->term), "vdqn_net_td_forward: missing inputs for this loss branch");
+  // acts_target == NULL (TD branch, extra_capacity): GROUPED forward — `acts_online` holds 3B samples [s | s' | s' again for the
+  // target network] and every layer behind the stem is ONE launch over all three ranges (vdqn_conv_args.wt_b)
+  const bool grouped = step_grouped(net, a);
+  VDQN_CHECK(gtb || grouped || a->acts_target, "vdqn_net_td_forward: acts_target is NULL (only the grouped extra_capacity TD update runs without it)");
   hipStream_t st = (hipStream_t)stream;
   const int F = net->cfg.num_frames, dt = net->cfg.dtype;
-  const int ns_online = gtb ? B : 2 * B;
+  const int ns_online = step_layout_samples(net, a);
   const ActLayout A = act_layout(net, ns_online);
   const BwdLayout W = bwd_layout(net, B);
   net->bwd_samples = B;
@@ -1244,11 +1275,18 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
   RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
   if (tst != st) join_side(net, st);  // packed input ready for the online pass
-  if (!gtb) {
+  if (grouped) {
+    // [s; s'] with the online weights and s' with the target's, one chain of launches on the caller's stream (the side stream
+    // carries nothing during the forward); the target range's stem reads the packed s' frames of the online range
+    RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, 3 * B, ao, A, st, false, (const unsigned char*)a->packed_target, 2 * B,
+                    ao + A.t_in + (int64_t)B * F * frame_bytes));
+  } else if (!gtb) {
     const ActLayout T = act_layout(net, B);
     RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst));
   }
-  if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
+  if (grouped) {
+    // (done above)
+  } else if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
     RC(forward_train_impl(net, (const unsigned char*)a->packed_online, a->params, a->bnstats, ao + A.t_in, ns_online, gtb ? 1 : 2, ao, A, st));
   else {
     // VDQN_SPLIT_ONLINE=1: the online pass over [before; after] as two independent half-batch passes on two streams (BatchNorm in
@@ -1282,7 +1320,7 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     memset(&t, 0, sizeof(t));
     t.q_before = qf_online;
     t.q_after_online = qf_online + (size_t)B * 64;
-    t.q_after_target = reinterpret_cast<const float*>(at + T.qf);
+    t.q_after_target = grouped ? qf_online + (size_t)2 * B * 64 : reinterpret_cast<const float*>(at + T.qf);
     t.act = a->act; t.rew = a->rew; t.term = a->term; t.valid = a->valid;
     t.loss = a->loss;
     t.dq = bw + W.dq;
@@ -1396,7 +1434,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   hipStream_t st = (hipStream_t)stream;
   const int B = a->batch, F = net->cfg.num_frames, n = B * F, dt = net->cfg.dtype;
   const bool gtb = a->train_on_ground_truth != 0;
-  const ActLayout A = act_layout(net, gtb ? B : 2 * B);
+  const ActLayout A = act_layout(net, step_layout_samples(net, a));
   const BwdLayout W = bwd_layout(net, B);
   const unsigned char* pk = (const unsigned char*)a->packed_online;
   unsigned char* ao = (unsigned char*)a->acts_online;

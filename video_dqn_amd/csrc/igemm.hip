@@ -120,7 +120,9 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
   long long a_rem = p.in_bytes - a_base_off;
   if (a_rem > 0x7fffffffLL) a_rem = 0x7fffffffLL;
   const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.in + a_base_off);
-  const unsigned long long b_ptr = (unsigned long long)(sib ? p.wt2 : p.wt);
+  // grouped forward: the tiles from row m_split on use the second weight set (same size, so the descriptor range is the same)
+  const bool grp_b = MODE == 0 && m0 >= p.m_split;
+  const unsigned long long b_ptr = (unsigned long long)(sib ? p.wt2 : (grp_b ? p.wt_b : p.wt));
   const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
                       __builtin_amdgcn_readfirstlane((int)a_rem), 0x00020000};
   const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
@@ -536,10 +538,10 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     IgemmParams q = p;
     q.bias = p.bias2; q.out = p.out2; q.relu = p.relu2; q.co = p.co2; q.ldo = p.ldo2;
     q.resid = nullptr; q.mask = nullptr; q.out_f32 = nullptr; q.colsum_part = nullptr;
-    igemm_epilogue<T, BM, BN, MODE, WN>(q, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw);
+    igemm_epilogue<T, BM, BN, MODE, WN>(q, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw, q.bias);
     return;
   }
-  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw);
+  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw, grp_b ? p.bias_b : p.bias);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void igemm_win_kernel(const 
 #undef VDQN_ISSUE_B
 #undef VDQN_ADV
 #undef VDQN_DMA4
-  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, 0, 0);
+  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, 0, 0, p.bias);
 }
 
 template <typename T, int BN, int MODE>
@@ -1031,7 +1033,7 @@ __global__ __launch_bounds__(256, 2) void igemm_win9_kernel(const IgemmParams p,
 #ifdef VDQN_STAMP
   const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
 #endif
-  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, p.howo, W, 0, 0);
+  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, p.howo, W, 0, 0, p.bias);
 #ifdef VDQN_STAMP
   if (p.pool_out && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left
@@ -1089,23 +1091,37 @@ constexpr int kC64WinRows = 248;                 // 128 + 2 * 56 + 2 = 242 rows,
 constexpr int kC64WinBytes = kC64WinRows * 128;
 constexpr int kC64LoadTap = 4;                   // K-loop tap in front of which the epilogue's residual / mask loads are issued
 constexpr int kC64RegTaps = 7;                   // taps whose weight fragments live in registers; the rest are read from LDS
-constexpr int kC64Smem = 2 * kC64WinBytes + 128 + 512 + 256 + (9 - kC64RegTaps) * 8192;  // windows, zero row, column-sum scratch, bias, LDS taps
+constexpr int kC64Smem = 2 * kC64WinBytes + 256 + 512 + 256 + (9 - kC64RegTaps) * 8192;  // windows, zero pair, column-sum scratch, bias, LDS taps
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, const int n_tiles, const FastDiv d_wo, const FastDiv d_howo) {
+__global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, const int n_tiles, const FastDiv d_wo, const FastDiv d_howo, const int grp_a_blocks) {
   using T = bf16raw;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sZ = smem + 2 * kC64WinBytes;
-  float* sScratch = reinterpret_cast<float*>(sZ + 128);       // [2 wave rows][64] partial column sums
-  float* sBias = reinterpret_cast<float*>(sZ + 128 + 512);
-  unsigned char* sWt = sZ + 128 + 512 + 256;  // [9 - kC64RegTaps][64 channels][128 B], chunk c of row r stored at c ^ (r & 7)
+  // sZ: 256 bytes of zeros at a 256-byte boundary = every LDS bank once.  A lane whose tap leaves the image reads the zeros at its
+  // OWN position modulo 256, so the 16 lanes of a ds_read_b128 group still hit 16 different bank quads (one shared zero-row
+  // address made every edge lane collide with a neighbour in each of its four lane groups: SQ_LDS_BANK_CONFLICT 11-15 %)
+  float* sScratch = reinterpret_cast<float*>(sZ + 256);       // [2 wave rows][64] partial column sums
+  float* sBias = reinterpret_cast<float*>(sZ + 256 + 512);
+  unsigned char* sWt = sZ + 256 + 512 + 256;  // [9 - kC64RegTaps][64 channels][128 B], chunk c of row r stored at c ^ (r & 7)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
   const int W = p.wo, H = p.ho;
-  if (tid < 8) reinterpret_cast<uint4*>(sZ)[tid] = make_uint4(0, 0, 0, 0);
-  if (tid >= 64 && tid < 128) sBias[tid - 64] = p.bias ? p.bias[tid - 64] : 0.f;
+  // grouped forward (IgemmParams::m_split): the weights live in registers for the life of a workgroup, so the GRID is split — the
+  // first grp_a_blocks workgroups walk the tiles below row m_split with the first weight set, the others the tiles from m_split on
+  // with wt_b / bias_b (both counts are multiples of 8: the XCD-contiguous tile order holds inside each range).  Not grouped:
+  // grp_a_blocks = gridDim.x and one range.
+  const bool grp_b = (int)blockIdx.x >= grp_a_blocks;
+  const int g_first = grp_b ? p.m_split / 128 : 0;                                   // first tile of this workgroup's range
+  const int g_tiles = grp_b ? n_tiles - g_first : (grp_a_blocks < (int)gridDim.x ? p.m_split / 128 : n_tiles);
+  const int g_blocks = grp_b ? (int)gridDim.x - grp_a_blocks : grp_a_blocks;
+  const int g_bid = grp_b ? (int)blockIdx.x - grp_a_blocks : (int)blockIdx.x;
+  const unsigned char* w_src = reinterpret_cast<const unsigned char*>(grp_b ? p.wt_b : p.wt);
+  const float* bias_src = grp_b ? p.bias_b : p.bias;
+  if (tid < 16) reinterpret_cast<uint4*>(sZ)[tid] = make_uint4(0, 0, 0, 0);
+  if (tid >= 64 && tid < 128) sBias[tid - 64] = bias_src ? bias_src[tid - 64] : 0.f;
   // output / residual / mask / column-sum buffers as buffer resources: rows past M get an out-of-range offset, so every
   // lane issues the same instructions whatever its rows are (loads return 0, stores are dropped)
   const int io_bytes = (int)((long long)p.M * p.ldo * 2);
@@ -1130,10 +1146,10 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
   for (int i = tid; i < (9 - kC64RegTaps) * 512; i += 256) {
     const int tt = i >> 9, r = (i >> 3) & 63, c = i & 7;
     *reinterpret_cast<uint4*>(sWt + tt * 8192 + r * 128 + ((c ^ (r & 7)) << 4)) =
-        *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.wt) + (size_t)r * (576 * 2) + (kC64RegTaps + tt) * 128 + c * 16);
+        *reinterpret_cast<const uint4*>(w_src + (size_t)r * (576 * 2) + (kC64RegTaps + tt) * 128 + c * 16);
   }
   {
-    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wt) + (size_t)wrow0 * (576 * 2) + g * 16;
+    const unsigned char* wbase = w_src + (size_t)wrow0 * (576 * 2) + g * 16;
 #pragma unroll
     for (int t = 0; t < kC64RegTaps; ++t)
 #pragma unroll
@@ -1181,14 +1197,14 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     }
   };
 
-  int t = blockIdx.x, buf = 0;
-  if (t < n_tiles) issue_window((int)xcd_remap((uint32_t)t, (uint32_t)n_tiles), 0);
-  for (; t < n_tiles; t += gridDim.x, buf ^= 1) {
-    const int tl = (int)xcd_remap((uint32_t)t, (uint32_t)n_tiles);
+  int t = g_bid, buf = 0;
+  if (t < g_tiles) issue_window(g_first + (int)xcd_remap((uint32_t)t, (uint32_t)g_tiles), 0);
+  for (; t < g_tiles; t += g_blocks, buf ^= 1) {
+    const int tl = g_first + (int)xcd_remap((uint32_t)t, (uint32_t)g_tiles);
     const int m0 = tl * 128;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // window t visible; everyone is done with the other buffer (and with the scratch)
-    if (t + (int)gridDim.x < n_tiles) issue_window((int)xcd_remap((uint32_t)(t + gridDim.x), (uint32_t)n_tiles), buf ^ 1);
+    if (t + g_blocks < g_tiles) issue_window(g_first + (int)xcd_remap((uint32_t)(t + g_blocks), (uint32_t)g_tiles), buf ^ 1);
 #pragma unroll
     for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b128(held[f], r_out, (int)held_off[f], 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(held_cs), r_cs, (int)held_cs_off, 0, 0);
@@ -1208,7 +1224,6 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned char* a_rd = smem + buf * kC64WinBytes + (wr * 64 + i16) * 128;
-    const unsigned char* z_rd = sZ + (g << 4);
     // epilogue operands: offsets now, the residual / mask loads are issued in the middle of the K loop (tap kC64LoadTap) so
     // that the remaining taps' MFMAs cover most of their latency
     const int ncol = wc * 32 + g * 8;
@@ -1237,14 +1252,16 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
       const uint32_t tapbits = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u);
       const int off = W * ky + kx;           // wave-uniform window row offset of this tap
       const int key = (i16 + off) & 7;
+      const int par = ((i16 + off) & 1) << 7;  // (window buffers start at multiples of 256 bytes: row parity = address bit 7)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int coff = ((g + 4 * h) ^ key) << 4;
+        const unsigned char* z_rd = sZ + par + coff;  // the lane's own position inside the zero pair
         u32x4 fa[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
           const bool z = (edge[f] & tapbits) != 0u;
-          fa[f] = *reinterpret_cast<const u32x4*>(z ? z_rd + 64 * h : a_rd + (f * 16 + off) * 128 + coff);
+          fa[f] = *reinterpret_cast<const u32x4*>(z ? z_rd : a_rd + (f * 16 + off) * 128 + coff);
         }
         u32x4 wj[2];
 #pragma unroll
@@ -1334,10 +1351,22 @@ int launch_conv64(const IgemmParams& p, hipStream_t stream) {
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&conv64_kernel<MODE>), (size_t)kC64Smem);
   const int n_cu = vdqn_num_cus();
   const int n_tiles = (p.M + 127) / 128;
-  const int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
+  int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
+  int grp_a = grid;  // workgroups of the first weight set (all of them unless this is a grouped forward)
+  if (MODE == 0 && p.wt_b) {
+    // grouped forward: the workgroups are dealt to the two row ranges in proportion to their tile counts, in multiples of 8 (one
+    // per XCD) so that each range keeps the XCD-contiguous tile order
+    const int ta = p.m_split / 128, tb = n_tiles - ta;
+    grid = (grid + 7) & ~7;
+    if (grid < 16) grid = 16;
+    grp_a = (int)(((long long)grid * ta / n_tiles + 4) & ~7ll);
+    if (grp_a < 8) grp_a = 8;
+    if (grp_a > grid - 8) grp_a = grid - 8;
+    (void)tb;
+  }
   vdqn_prof_begin(MODE == 0 ? "conv64<bf16,fwd>" : "conv64<bf16,dgrad>", 2.0 * p.M * p.co * p.ktot,
                   2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
-  hipLaunchKernelGGL((conv64_kernel<MODE>), dim3(grid), dim3(256), kC64Smem, stream, p, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo));
+  hipLaunchKernelGGL((conv64_kernel<MODE>), dim3(grid), dim3(256), kC64Smem, stream, p, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), grp_a);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
@@ -1393,7 +1422,10 @@ int launch_mode(const IgemmParams& p, int mode, hipStream_t st) {
 extern "C" void vdqn_debug_stamp_buffer(void* p) { g_stamp_buffer = p; }  // diagnostic builds only (not part of include/vdqn.h)
 #endif
 
-extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
+// One launch of the layer.  group_rows > 0: a grouped forward was asked for (a->wt_b); the kernel this call selects takes it in
+// ONE launch when group_rows is a multiple of its tile height — otherwise *grouped_done stays 0 and nothing is launched (the
+// caller then issues the two row ranges as two calls).
+static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, int* grouped_done) {
   VDQN_CHECK(a != nullptr, "vdqn_conv2d: null args");
   VDQN_CHECK(a->dtype == VDQN_F32 || a->dtype == VDQN_BF16, "vdqn_conv2d: bad dtype %d", a->dtype);
   const int esz = a->dtype == VDQN_BF16 ? 2 : 4;
@@ -1410,6 +1442,15 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   p.pool_out = nullptr; p.pool_idx = nullptr;
   p.in2 = nullptr; p.wt2 = nullptr; p.bias2 = nullptr; p.out2 = nullptr;
   p.co2 = p.ldo2 = p.relu2 = p.ci2 = p.wt2_bytes = 0;
+  p.wt_b = nullptr; p.bias_b = nullptr; p.m_split = 0x7fffffff;
+  // grouped forward, decided per kernel below: `grp(bm)` arms it if the split is a multiple of that kernel's tile height
+  auto grp = [&](int bm) {
+    if (group_rows <= 0) return true;       // not a grouped call
+    if (group_rows % bm != 0) return false;  // a tile would mix the two weight sets: the caller falls back to two launches
+    p.wt_b = a->wt_b; p.bias_b = a->bias_b; p.m_split = group_rows;
+    *grouped_done = 1;
+    return true;
+  };
   p.n_img = a->n_img; p.hi = a->hi; p.wi = a->wi; p.ci = a->ci; p.pix_stride = a->pix_stride;
   p.ho = a->ho; p.wo = a->wo; p.co = a->co; p.ldo = a->ldo; p.r = a->r; p.s = a->s; p.stride = a->stride; p.pad = a->pad;
   p.relu = a->relu;
@@ -1469,8 +1510,10 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   static const int use_c64 = [] { const char* e = getenv("VDQN_CONV64"); return e ? atoi(e) : 1; }();
   if (use_c64 && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && mode != 2 && a->ci == 64 && a->co == 64 &&
       a->pix_stride == 64 && a->hi == a->ho && a->wi == a->wo && a->wo >= 2 && a->wo <= 56 && p.in_bytes < 0x7fffffffLL && (long long)p.M * 128 < 0x7fffffffLL &&
-      a->out && !a->out_f32 && p.vec_ok && (long long)p.M * a->ldo * 2 < 0x7fffffffLL && (mode == 1 || !a->colsum_part))
+      a->out && !a->out_f32 && p.vec_ok && (long long)p.M * a->ldo * 2 < 0x7fffffffLL && (mode == 1 || !a->colsum_part)) {
+    if (!grp(128)) return VDQN_OK;
     return mode == 0 ? launch_conv64<0>(p, st) : launch_conv64<1>(p, st);
+  }
   static const int use_win = [] { const char* e = getenv("VDQN_IGEMM_WINDOW"); return e ? atoi(e) : 1; }();
   if (use_win && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && mode != 2 && a->pix_stride == a->ci && a->wo >= 2) {
     if (a->dtype == VDQN_BF16) {
@@ -1478,22 +1521,63 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
       if (bn == 128 && use_win != 2 && a->wo <= 28 && a->hi == a->ho && a->wi == a->wo && p.in_bytes < 0x7fffffffLL) {
         // VDQN_WIN9_UNROLLED (default 1): the K loop unrolled over a chunk pair (win9.hip: half the instructions per K-step); 0: igemm_win9_kernel
         static const int unrolled = [] { const char* e = getenv("VDQN_WIN9_UNROLLED"); return e ? atoi(e) : 1; }();
-        if (unrolled && a->ci % 128 == 0) return vdqn_launch_win9u(&p, mode, st);
+        if (unrolled && a->ci % 128 == 0) {
+          if (!grp(256)) return VDQN_OK;  // (256: also right for the optional 256-row tiles)
+          return vdqn_launch_win9u(&p, mode, st);
+        }
+        if (group_rows > 0) return VDQN_OK;  // the remaining window kernels have no grouped form: two launches
         return mode == 0 ? launch_igemm_win9<bf16raw, 0>(p, st) : launch_igemm_win9<bf16raw, 1>(p, st);
       }
+      if (group_rows > 0) return VDQN_OK;
       if (bn == 128) return mode == 0 ? launch_igemm_win<bf16raw, 128, 0>(p, st) : launch_igemm_win<bf16raw, 128, 1>(p, st);
       return mode == 0 ? launch_igemm_win<bf16raw, 64, 0>(p, st) : launch_igemm_win<bf16raw, 64, 1>(p, st);
     }
+    if (group_rows > 0) return VDQN_OK;
     if (bn == 128) return mode == 0 ? launch_igemm_win<float, 128, 0>(p, st) : launch_igemm_win<float, 128, 1>(p, st);
     return mode == 0 ? launch_igemm_win<float, 64, 0>(p, st) : launch_igemm_win<float, 64, 1>(p, st);
   }
   static const long long min256 = [] { const char* e = getenv("VDQN_BM256_MIN_ROWS"); return e ? atoll(e) : 256ll * 1024; }();
   if (bn == 64 && mode != 2 && p.M >= min256 && !has_sib) {
+    if (!grp(256)) return VDQN_OK;
     p.tiles_m = (p.M + 255) / 256;
     return a->dtype == VDQN_BF16 ? launch_mode<bf16raw, 256, 64>(p, mode, st) : launch_mode<float, 256, 64>(p, mode, st);
   }
+  if (!grp(128)) return VDQN_OK;
   if (a->dtype == VDQN_BF16) return bn == 128 ? launch_mode<bf16raw, 128, 128>(p, mode, st) : launch_mode<bf16raw, 128, 64>(p, mode, st);
   return bn == 128 ? launch_mode<float, 128, 128>(p, mode, st) : launch_mode<float, 128, 64>(p, mode, st);
+}
+
+extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
+  VDQN_CHECK(a != nullptr, "vdqn_conv2d: null args");
+  if (!a->wt_b) return conv2d_impl(a, stream, 0, nullptr);
+  // grouped forward: images [0, split_img) with wt / bias, images [split_img, n_img) with wt_b / bias_b
+  VDQN_CHECK(a->mode == 0 && !a->wt2 && !a->in2 && !a->colsum_part && !a->mask, "vdqn_conv2d: wt_b (grouped forward) needs a plain forward call");
+  VDQN_CHECK(a->split_img > 0 && a->split_img < a->n_img, "vdqn_conv2d: split_img %d outside (0, n_img = %d)", a->split_img, a->n_img);
+  VDQN_CHECK((a->bias != nullptr) == (a->bias_b != nullptr) && (((uintptr_t)a->wt_b) & 15) == 0, "vdqn_conv2d: bias_b must be given iff bias is; wt_b 16-byte aligned");
+  const int64_t rows_a = (int64_t)a->split_img * a->ho * a->wo;
+  VDQN_CHECK(rows_a < (1ll << 31), "vdqn_conv2d: too many output pixels");
+  static const int one_launch = [] { const char* e = getenv("VDQN_GROUPED_LAUNCH"); return e ? atoi(e) : 1; }();
+  int done = 0;
+  if (one_launch) {
+    const int rc = conv2d_impl(a, stream, (int)rows_a, &done);
+    if (rc != VDQN_OK || done) return rc;
+  }
+  // this layer's kernel has no grouped form, or the split is not a multiple of its tile height: the two row ranges as two launches
+  const int esz = a->dtype == VDQN_BF16 ? 2 : 4;
+  vdqn_conv_args lo = *a, hi = *a;
+  lo.wt_b = nullptr; lo.bias_b = nullptr; lo.split_img = 0; lo.n_img = a->split_img;
+  hi.wt_b = nullptr; hi.bias_b = nullptr; hi.split_img = 0; hi.n_img = a->n_img - a->split_img;
+  hi.wt = a->wt_b; hi.bias = a->bias_b;
+  hi.in = (const unsigned char*)a->in + (int64_t)a->split_img * a->hi * a->wi * a->pix_stride * esz;
+  if (a->out) hi.out = (unsigned char*)a->out + rows_a * a->ldo * esz;
+  if (a->out_f32) hi.out_f32 = a->out_f32 + rows_a * a->ldo;
+  if (a->resid) hi.resid = (const unsigned char*)a->resid + rows_a * a->ldo * esz;
+  const double flops = g_prof_alg_flops;  // the engine's figure covers both ranges
+  if (flops > 0) g_prof_alg_flops = flops * a->split_img / a->n_img;
+  const int rc = conv2d_impl(&lo, stream, 0, nullptr);
+  if (rc != VDQN_OK) return rc;
+  if (flops > 0) g_prof_alg_flops = flops * (a->n_img - a->split_img) / a->n_img;
+  return conv2d_impl(&hi, stream, 0, nullptr);
 }
 
 extern "C" int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img, int32_t dtype,

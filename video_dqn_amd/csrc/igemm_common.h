@@ -38,6 +38,13 @@ struct IgemmParams {
   const float* bias2;
   void* out2;
   int co2, ldo2, relu2, ci2, wt2_bytes, tiles_n1;
+  // grouped forward (two weight sets over one row range, e.g. the online and the target network of a TD update in ONE launch,
+  // train_q_network.py:131,140,142): output rows m >= m_split are computed with wt_b / bias_b.  m_split is a multiple of the
+  // kernel's tile height (the launcher falls back to two launches otherwise), so no tile mixes the sets and every output element
+  // is bit-identical to the two-launch result.  Not grouped: m_split = INT_MAX.
+  const void* wt_b;
+  const float* bias_b;
+  int m_split;
 };
 
 constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (num_records <= 0x7fffffff)
@@ -46,7 +53,8 @@ constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (
 // [ncol, ncol + CPL) of pixels f*16 + i16 of its wave's 64 rows ----
 template <typename T, int BM, int BN, int MODE, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[4][BN / (16 * WN)], unsigned char* smem, int m0, int n0, int tile_m,
-                                               int rows_total, int pix_per_img, int row_w, int cls_ph, int cls_pw, int tid_override = -1) {
+                                               int rows_total, int pix_per_img, int row_w, int cls_ph, int cls_pw, const float* __restrict__ bias,
+                                               int tid_override = -1) {
   constexpr int ESZ = (int)sizeof(T);
   constexpr int NF = BN / (16 * WN);
   constexpr int CPL = 4 * NF;
@@ -68,7 +76,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     const bool vec = p.vec_ok && (ncol + CPL <= p.co);
     float bv[CPL];
 #pragma unroll
-    for (int e = 0; e < CPL; ++e) bv[e] = (p.bias && ncol + e < p.co) ? p.bias[ncol + e] : 0.f;
+    for (int e = 0; e < CPL; ++e) bv[e] = (bias && ncol + e < p.co) ? bias[ncol + e] : 0.f;  // (grouped forward: the tile's own set)
     size_t o[4];
     bool okr[4];
 #pragma unroll

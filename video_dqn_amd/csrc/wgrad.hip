@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int j = 0; j < NFR; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = WSPLIT ? 0 : (wave >> 1), wc = WSPLIT ? 0 : (wave & 1);
+  const int wr = WSPLIT ? 0 : (wave >> 1), wc = wave & 1;
   const int grp = lane >> 4, i16 = lane & 15;
 
   auto compute = [&](int buf) {
@@ -363,19 +363,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
   constexpr int E16 = 8;
   constexpr int RBG = BCO * 2, RBX = BCI * 2;      // bytes per staged gy / x row (one pixel)
   constexpr int CPRG = RBG / 16, CPRX = RBX / 16;
-  constexpr bool WSPLIT = (BCO == 64 && BCI == 64);  // every wave owns the whole 64x64 tile for one 32-pixel sub-step
+  // WSPLIT (64 x 64 tiles): wave (wave & 1) owns ALL 64 output channels x one HALF of the input channels (three taps: 24
+  // accumulator tiles = 96 VGPRs) for TWO of the four 32-pixel sub-steps of a staged K-step (waves 0, 1: sub-steps 0, 1; waves
+  // 2, 3: sub-steps 2, 3); the two partial tiles of a channel half are summed through LDS before the atomics.  (Round 2 gave
+  // every wave the whole 64 x 64 x 3 tile = 192 accumulator VGPRs for one sub-step: no room for a second fragment set, every
+  // group of four MFMAs waited lgkmcnt(0) for its own fragment pair, and five registers spilled into the K loop.)
+  constexpr bool WSPLIT = (BCO == 64 && BCI == 64);
   constexpr int KSUB = WSPLIT ? 4 : 2;
   constexpr int KP = 32 * KSUB;
   constexpr int NLG = (KP * CPRG) / 256;
   constexpr int WR = KP + 8;                       // window rows (KP + 2 needed)
   constexpr int NLX = (WR * CPRX + 255) / 256;     // 16-byte slots per thread for the window (the last pass is partial)
   constexpr int NFA = WSPLIT ? 4 : BCO / 32;       // 16-wide fragments per wave: output channels
-  constexpr int NFB = WSPLIT ? 4 : BCI / 32;       //                              input channels
+  constexpr int NFB = BCI / 32;                    //                              input channels
   static_assert((KP * CPRG) % 256 == 0 && (WR * CPRX - 256 * (NLX - 1)) % 64 == 0, "staging passes are whole waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;                         // [2][KP * RBG]   gy tiles
   unsigned char* sX = smem + 2 * KP * RBG;          // [2][WR * RBX]   x windows
-  unsigned char* sZ = sX + 2 * WR * RBX;            // [RBX]           zeros
+  unsigned char* sZ = sX + 2 * WR * RBX;            // [256]           zeros: every LDS bank once (a multiple of 256 from smem)
+  static_assert((2 * KP * RBG) % 256 == 0 && (WR * RBX) % 256 == 0, "window buffers and the zero block sit at 256-byte boundaries");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
   const int kend = min(p.M, kbeg + p.kchunk);
   if (kbeg >= kend) return;
   const int nk = (kend - kbeg + KP - 1) / KP;
-  for (int i = tid; i < RBX / 16; i += 256) reinterpret_cast<uint4*>(sZ)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 16) reinterpret_cast<uint4*>(sZ)[tid] = make_uint4(0, 0, 0, 0);
 
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const unsigned long long g_ptr = (unsigned long long)p.gy, x_ptr = (unsigned long long)p.x;
@@ -445,59 +451,109 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
 #pragma unroll
       for (int j = 0; j < NFB; ++j) acc[k3][f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = WSPLIT ? 0 : (wave >> 1), wc = WSPLIT ? 0 : (wave & 1);
+  const int wr = WSPLIT ? 0 : (wave >> 1), wc = wave & 1;
   const int grp = lane >> 4, i16 = lane & 15;
   const int q4 = i16 >> 2, pp = i16 & 3;
   const int row = 4 * grp + q4;            // pixel row (of 32) this lane addresses in a transposing read; + 16 for the high half
   const int sub8 = (pp & 1) << 3;
   const int szA = wg_swz<T, BCO>(row);
 
+  typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+  // border flags of the two output pixels this lane addresses in sub-step `sub` (rows `row` and `row + 16`): bit hh = the tap ks
+  // of kernel row kr leaves the image for pixel hh -> that lane reads zeros
+  auto border = [&](int kb, int sub, uint32_t (&zmask)[3]) {
+    zmask[0] = zmask[1] = zmask[2] = 0u;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const uint32_t pm = (uint32_t)(kb + sub * 32 + row + 16 * hh);
+      const uint32_t rem = pm - fastdiv(pm, p.d_howo) * p.d_howo.div;
+      const uint32_t oh = fastdiv(rem, p.d_wo);
+      const uint32_t ow = rem - oh * p.d_wo.div;
+      // (bitwise, not short-circuit: the compiler otherwise branches per lane inside the K loop)
+      const uint32_t e_v = ((uint32_t)(kr == 0) & (uint32_t)(oh == 0)) | ((uint32_t)(kr == 2) & (uint32_t)(oh == (uint32_t)p.ho - 1));  // whole kernel row outside
+      zmask[0] |= (e_v | (uint32_t)(ow == 0)) << hh;
+      zmask[1] |= e_v << hh;
+      zmask[2] |= (e_v | (uint32_t)(ow == (uint32_t)p.wo - 1)) << hh;
+    }
+  };
+  // x fragment (input channels cb .. cb + 15) of tap ks for sub-step `sub`: two transposing reads, a border lane reads the zeros
+  // at its OWN position modulo 256 bytes (the lane groups of the read then still hit distinct banks)
+  auto load_x = [&](const unsigned char* xw, int sub, int ks, int cb, uint32_t zm) -> s16x8 {
+    const int jr = sub * 32 + row + ks;  // window row of the low half; high half: + 16 (same swizzle key for both)
+    const int szX = wg_swz<T, BCI>(jr);
+    const int off = jr * RBX + ((((cb >> 3) + (pp >> 1)) ^ szX) << 4) + sub8;
+    const unsigned char* p0 = (zm & 1u) ? sZ + (off & 255) : xw + off;
+    const unsigned char* p1 = (zm & 2u) ? sZ + ((off + 16 * RBX) & 255) : xw + off + 16 * RBX;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)p1);
+    return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  auto load_g = [&](const unsigned char* a, int cb) -> s16x8 {
+    const int off = row * RBG + ((((cb >> 3) + (pp >> 1)) ^ szA) << 4) + sub8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a + off + 16 * RBG));
+    return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+
+  // WSPLIT: the border masks of the wave's two sub-steps live across K tiles — those of tile k + 1 are computed inside tile k's
+  // stages (under its MFMAs), not in front of its first fragment read (~120 VALU instructions with two divisions per pixel)
+  const int sub_a = WSPLIT ? (wave >> 1) * 2 : 0, sub_b = sub_a + 1;
+  uint32_t zm_a[3] = {0u, 0u, 0u}, zm_b[3] = {0u, 0u, 0u};
+  if constexpr (WSPLIT) {
+    border(kbeg, sub_a, zm_a);
+    border(kbeg, sub_b, zm_b);
+  }
+
   auto compute = [&](int buf, int kb) {
+    const unsigned char* xw = sX + buf * (WR * RBX);
+    if constexpr (WSPLIT) {
+      // Software pipeline over the wave's two sub-steps: 2 x (3 taps x 2 channel fragments) = 12 stages of four MFMAs (one x
+      // fragment against the four gy fragments).  The x fragment of stage s + 2 is read while stage s computes (three
+      // register sets), the gy fragments of the second sub-step while the first one's last stages compute: no MFMA waits for
+      // an LDS read it has just issued.
+      const unsigned char* ga = sA + buf * (KP * RBG) + sub_a * (32 * RBG);
+      s16x8 af[2][NFA], bj[3];
+#pragma unroll
+      for (int f = 0; f < NFA; ++f) af[0][f] = load_g(ga, f * 16);
+      auto stage_x = [&](int st) -> s16x8 {  // st = sub-step * 6 + ks * 2 + j
+        const int sb = st / 6, ks = (st % 6) >> 1, j = st & 1;
+        return load_x(xw, sb ? sub_b : sub_a, ks, wc * (BCI / 2) + j * 16, (sb ? zm_b : zm_a)[ks]);
+      };
+      bj[0] = stage_x(0);
+      bj[1] = stage_x(1);
+#pragma unroll
+      for (int st = 0; st < 12; ++st) {
+        if (st + 2 < 12) bj[(st + 2) % 3] = stage_x(st + 2);
+        if (st >= 2 && st < 2 + NFA) af[1][st - 2] = load_g(ga + 32 * RBG, (st - 2) * 16);  // second sub-step's gy fragments, one per stage
+        if (st == 6) border(kb + KP, sub_a, zm_a);   // the next tile's masks: sub-step a's were last used by stage 3's read,
+        if (st == 10) border(kb + KP, sub_b, zm_b);  // sub-step b's by stage 9's
+        const int sb = st / 6, ks = (st % 6) >> 1, j = st & 1;
+#pragma unroll
+        for (int f = 0; f < NFA; ++f)
+          acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[sb][f]), __builtin_bit_cast(bf16x8, bj[st % 3]), acc[ks][f][j], 0, 0, 0);
+        // pin the stage order: left to itself the scheduler sinks every read to just in front of its first use and waits
+        // lgkmcnt(0) there.  With a scheduling fence per stage the reads stay two stages ahead and the compiler's own counted
+        // lgkmcnt waits (it tracks the builtin reads) let each stage start as soon as ITS fragment has landed.
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll 1
-    for (int sub0 = 0; sub0 < (WSPLIT ? 1 : KSUB); ++sub0) {
-      const int sub = WSPLIT ? wave : sub0;
-      const unsigned char* a = sA + buf * (KP * RBG) + sub * (32 * RBG);
-      const unsigned char* xw = sX + buf * (WR * RBX);
-      // border flags of this lane's two output pixels (rows `row` and `row + 16` of the sub-step): the taps that leave the image
-      // on that side read the zero row.  e_v: the whole kernel row kr is outside (top row with kr = 0, bottom row with kr = 2).
-      bool e_l[2], e_r[2], e_v[2];
+      for (int sub = 0; sub < KSUB; ++sub) {
+        const unsigned char* a = sA + buf * (KP * RBG) + sub * (32 * RBG);
+        uint32_t zm[3];
+        border(kb, sub, zm);
+        s16x8 af[NFA];
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const uint32_t pm = (uint32_t)(kb + sub * 32 + row + 16 * hh);
-        const uint32_t rem = pm - fastdiv(pm, p.d_howo) * p.d_howo.div;
-        const uint32_t oh = fastdiv(rem, p.d_wo);
-        const uint32_t ow = rem - oh * p.d_wo.div;
-        e_l[hh] = ow == 0;
-        e_r[hh] = ow == (uint32_t)p.wo - 1;
-        e_v[hh] = (kr == 0 && oh == 0) || (kr == 2 && oh == (uint32_t)p.ho - 1);
-      }
-      s16x8 af[NFA];
+        for (int f = 0; f < NFA; ++f) af[f] = load_g(a, wr * (BCO / 2) + f * 16);
 #pragma unroll
-      for (int f = 0; f < NFA; ++f) {
-        const int cb = wr * (BCO / 2) + f * 16;
-        const int off = row * RBG + ((((cb >> 3) + (pp >> 1)) ^ szA) << 4) + sub8;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + off + 16 * RBG));
-        af[f] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
+        for (int ks = 0; ks < 3; ++ks) {
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        const int jr = sub * 32 + row + ks;  // window row of the low half; high half: + 16 (same swizzle key for both)
-        const int szX = wg_swz<T, BCI>(jr);
-        const bool z0 = e_v[0] || (ks == 0 && e_l[0]) || (ks == 2 && e_r[0]);
-        const bool z1 = e_v[1] || (ks == 0 && e_l[1]) || (ks == 2 && e_r[1]);
+          for (int j = 0; j < NFB; ++j) {  // one x fragment live at a time (register budget)
+            const s16x8 bj = load_x(xw, sub, ks, wc * (BCI / 2) + j * 16, zm[ks]);
 #pragma unroll
-        for (int j = 0; j < NFB; ++j) {  // one x fragment live at a time (register budget)
-          const int cb = wc * (BCI / 2) + j * 16;
-          const int off = jr * RBX + ((((cb >> 3) + (pp >> 1)) ^ szX) << 4) + sub8;
-          const unsigned char* p0 = z0 ? sZ + sub8 : xw + off;
-          const unsigned char* p1 = z1 ? sZ + sub8 : xw + off + 16 * RBX;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
-          const s16x8 bj = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-          for (int f = 0; f < NFA; ++f)
-            acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bj), acc[ks][f][j], 0, 0, 0);
+            for (int f = 0; f < NFA; ++f)
+              acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bj), acc[ks][f][j], 0, 0, 0);
+          }
         }
       }
     }
@@ -527,12 +583,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
 #pragma unroll
         for (int j = 0; j < NFB; ++j)
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) red[wave * 4096 + (f * 16 + grp * 4 + reg) * 64 + j * 16 + i16] = acc[ks][f][j][reg];
+          for (int reg = 0; reg < 4; ++reg) red[(wave >> 1) * 4096 + (f * 16 + grp * 4 + reg) * 64 + wc * 32 + j * 16 + i16] = acc[ks][f][j][reg];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int o = tid + 256 * e;
-        const float v = red[o] + red[4096 + o] + red[8192 + o] + red[12288 + o];
+        const float v = red[o] + red[4096 + o];
         const int co = co0 + (o >> 6), ci = ci0 + (o & 63);
         if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, v);
       }
@@ -973,8 +1029,8 @@ int launch_stem_wgrad(const WgradParams& p, hipStream_t stream) {
 template <int BCO, int BCI>
 int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
   constexpr int KP = 32 * ((BCO == 64 && BCI == 64) ? 4 : 2);
-  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * (KP + 8) + 1) * BCI * 2;
-  const size_t smem_epi = (BCO == 64 && BCI == 64) ? (size_t)4 * 64 * 64 * 4 : (size_t)BCO * BCI * 4;
+  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * (KP + 8)) * BCI * 2 + 256;  // gy tiles, x windows, zero block
+  const size_t smem_epi = (BCO == 64 && BCI == 64) ? (size_t)2 * 64 * 64 * 4 : (size_t)BCO * BCI * 4;
   const size_t smem = smem_stage > smem_epi ? smem_stage : smem_epi;
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI>), (size_t)smem);
   vdqn_prof_begin(BCO == 128 ? "wgrad_win<bf16,128x64>" : "wgrad_win<bf16,64>", 2.0 * p.M * p.co * p.taps * p.ci,

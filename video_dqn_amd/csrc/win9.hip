@@ -12,8 +12,8 @@
 // 18 K-steps of a chunk pair, so every step knows its tap, its LDS buffers and its register set at compile time:
 //   * per-lane fragment addresses of the nine taps (row offset W ky + kx and the XOR swizzle key of that row) are computed once
 //     per workgroup (18 VGPRs); the window buffer, the fragment row f and the weight-ring slot are ds_read immediates;
-//   * the zero row of an edge lane is selected with one v_cndmask per fragment read from a per-(f, K-half) address that already
-//     has the immediate subtracted; the centre tap and taps that cannot leave the image on a side skip the test;
+//   * the zeros of an edge lane are selected with one v_and_or + one v_cndmask per fragment pair (a zero PAIR of rows, read at the
+//     lane's own bank position: conflict-free); the centre tap and taps that cannot leave the image on a side skip the test;
 //   * scalar work per step: the weight tile's K offset (one add), M0 for the LDS-DMA pieces.
 // ~85 instructions per wave and K-step instead of ~170.
 //
@@ -80,8 +80,16 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   const unsigned long long b_ptr = (unsigned long long)p.wt;
   const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
                       __builtin_amdgcn_readfirstlane((int)p.in_bytes), 0x00020000};
-  const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
-                      __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
+  const i32x4 rs_b0 = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
+                       __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
+  // grouped forward (IgemmParams::m_split): tiles from row m_split on take the second weight set.  A persistent workgroup may walk
+  // tiles of both sets, so the weight descriptor is chosen per tile (four scalar selects) — for the tile being computed (rs_b) and
+  // for the next tile, whose first two weight tiles are staged under this tile's last steps (rs_bn).
+  const unsigned long long bb_ptr = (unsigned long long)(MODE == 0 && p.wt_b ? p.wt_b : p.wt);
+  const i32x4 rs_b1 = {__builtin_amdgcn_readfirstlane((int)(unsigned)bb_ptr), __builtin_amdgcn_readfirstlane((int)((bb_ptr >> 32) & 0xffff)),
+                       __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
+  const int m_split = MODE == 0 ? p.m_split : 0x7fffffff;
+  i32x4 rs_b = m0 >= m_split ? rs_b1 : rs_b0;
 
   // ---- window rows staged by this thread: j = lrow + RPP i; rows past BM + 2 W + 2 (and pixels outside the tensor) are zero.
   // The offsets are rebuilt from (q0, lchunk) at every window issue (once per nine K-steps) instead of held in registers:
@@ -135,8 +143,9 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
                    ::"v"(a_off[4]), "s"(l4_), "s"(rs_a), "s"(so_a_) : "memory");                                    \
     }                                                                                                               \
   }
-#define VDQN_ISSUE_B(BUF, SOFF, BOFF)                                                                                   \
+#define VDQN_ISSUE_B(BUF, SOFF, BOFF, RSB)                                                                              \
   {                                                                                                                 \
+    const i32x4 rs_sel_ = (RSB);                                                                                    \
     const uint32_t lb_ = lds_wave + (uint32_t)((BUF)*kU_WtTile);                                                    \
     const int so0_ = (SOFF), so1_ = so0_ + b_row32;                                                                 \
     if constexpr (G::BPass == 4) {                                                                                  \
@@ -146,13 +155,13 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
           "s_add_u32 m0, %1, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds\n\t"                        \
           "s_add_u32 m0, %1, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %5 offen lds\n\t"                        \
           "s_add_u32 m0, %1, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %6 offen lds"                             \
-          ::"v"(BOFF), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "s"(so2_), "s"(so3_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
+          ::"v"(BOFF), "s"(lb_), "s"(rs_sel_), "s"(so0_), "s"(so1_), "s"(so2_), "s"(so3_), "n"(PSTR), "n"(2 * PSTR), "n"(3 * PSTR) \
           : "memory", "scc");                                                                                       \
     } else {                                                                                                        \
       asm volatile(                                                                                                 \
           "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds\n\t"                            \
           "s_add_u32 m0, %1, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds"                             \
-          ::"v"(BOFF), "s"(lb_), "s"(rs_b), "s"(so0_), "s"(so1_), "n"(PSTR)                                         \
+          ::"v"(BOFF), "s"(lb_), "s"(rs_sel_), "s"(so0_), "s"(so1_), "n"(PSTR)                                      \
           : "memory", "scc");                                                                                       \
     }                                                                                                               \
   }
@@ -190,10 +199,15 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     const int key = (i16 + W * ky + kx) & 7;  // (wr * 64 is a multiple of 8)
     ab[t] = (uint32_t)(row * 128 + ((g ^ key) << 4));
   }
-  // zs[f]: the zero row (last row of a window buffer), minus the f * 16 rows the read's immediate adds
+  // zs[f]: the zero PAIR (the last two rows of a window buffer: 256 bytes at a 256-byte boundary = every LDS bank once), minus
+  // the f * 16 rows the read's immediate adds.  An edge lane reads the zeros at ITS OWN position inside the pair (its address
+  // modulo 256): the lanes of a ds_read_b128 group then still hit 16 different bank quads.  With one shared zero-row address per
+  // K-chunk (round 2) every edge lane collided with a neighbour in each of its four lane groups — one extra LDS cycle per group,
+  // i.e. a fragment read with an edge pixel took 8 cycles instead of 4: 27-43 % of the activation-fragment LDS cycles by the bank
+  // model (left / right image borders fall into almost every 16-pixel fragment), 23 % of all LDS cycles by SQ_LDS_BANK_CONFLICT.
   uint32_t zs[4];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) zs[f] = (uint32_t)((wrows - 1) * 128 + (g << 4) - f * 16 * 128);
+  for (int f = 0; f < 4; ++f) zs[f] = (uint32_t)((wrows - 2) * 128 - f * 16 * 128);
   // bb[h]: weight fragment j = 0, relative to a weight tile (rows read in the permuted order the epilogue expects)
   const uint32_t bb0 = (uint32_t)((wc * (BN / WN) + (i16 >> 2) * CPL + (i16 & 3)) * 128 + ((g ^ (i16 & 7)) << 4));
   const uint32_t bb1 = (uint32_t)((wc * (BN / WN) + (i16 >> 2) * CPL + (i16 & 3)) * 128 + (((g + 4) ^ (i16 & 7)) << 4));
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
       uint32_t a0_ = ab[TAP_];                                                                                           \
       if constexpr (tb_ != 0u) { /* an edge lane's tap leaves the image: read the zero row */                            \
         const bool z_ = (edge16 & (tb_ << (4 * f_))) != 0u;                                                              \
-        a0_ = z_ ? zs[f_] : a0_;                                                                                         \
+        a0_ = z_ ? ((a0_ & 255u) | zs[f_]) : a0_;                                                                        \
       }                                                                                                                  \
       const uint32_t a1_ = a0_ ^ 64u;                                                                                    \
       fa[SET][0][f_] = *reinterpret_cast<const u32x4*>(wb_ + f_ * 16 * 128 + a0_);                                       \
@@ -269,10 +283,10 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
        iteration — chunk 0 of the workgroup's NEXT tile (so_nx / b_nx / q_nx), whose prologue thereby runs under this tile's   \
        last steps and epilogue */                                                                                         \
     if constexpr (ci_ == 2) {                                                                                            \
-      VDQN_ISSUE_B(cur_, ti_ * tap_k + so_nx, b_nx)                                                                      \
+      VDQN_ISSUE_B(cur_, ti_ * tap_k + so_nx, b_nx, rs_bn)                                                               \
       if constexpr (ti_ == 0) VDQN_ISSUE_AW(0, so_nx, q_nx)                                                              \
     } else {                                                                                                             \
-      VDQN_ISSUE_B(cur_, ti_ * tap_k + (cc2 + ci_) * 128, b_off0)                                                        \
+      VDQN_ISSUE_B(cur_, ti_ * tap_k + (cc2 + ci_) * 128, b_off0, rs_b)                                                  \
       if constexpr (ti_ == 0) VDQN_ISSUE_AW(ci_ & 1, (cc2 + ci_) * 128, q0)                                              \
     }                                                                                                                    \
     VDQN_ST(st_issue)                                                                                                    \
@@ -284,9 +298,9 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   }
 
   // prologue of the workgroup's FIRST tile: K-steps 0 and 1 (window of chunk 0, weight tiles of taps 0 and 1)
-  VDQN_ISSUE_B(0, 0, b_off0)
+  VDQN_ISSUE_B(0, 0, b_off0, rs_b)
   VDQN_ISSUE_AW(0, 0, q0)
-  VDQN_ISSUE_B(1, tap_k, b_off0)
+  VDQN_ISSUE_B(1, tap_k, b_off0, rs_b)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #ifdef VDQN_STAMP
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     const int tm_nx = has_nx ? (int)((x_first + lt_nx) / (uint32_t)p.tiles_n) : tile_m;
     const int q0_t = tm_nx * BM - W - 1 + lrow;
     const uint32_t b_t = (uint32_t)(tn_nx * BN + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
+    const i32x4 rs_t = tm_nx * BM >= m_split ? rs_b1 : rs_b0;  // the next tile's weight set
 #pragma clang loop unroll(disable)
     for (int it = 0; it < n_it; ++it) {
       const int cc2 = 2 * it;            // first chunk of this iteration
@@ -313,6 +328,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
       const int so_nx = last_it ? 0 : (cc2 + 2) * 128;
       const int q_nx = last_it ? q0_t : q0;
       const uint32_t b_nx = last_it ? b_t : b_off0;
+      const i32x4 rs_bn = last_it ? rs_t : rs_b;
       VDQN_USTEP(0) VDQN_USTEP(1) VDQN_USTEP(2) VDQN_USTEP(3) VDQN_USTEP(4) VDQN_USTEP(5) VDQN_USTEP(6) VDQN_USTEP(7) VDQN_USTEP(8)
       VDQN_USTEP(9) VDQN_USTEP(10) VDQN_USTEP(11) VDQN_USTEP(12) VDQN_USTEP(13) VDQN_USTEP(14) VDQN_USTEP(15) VDQN_USTEP(16) VDQN_USTEP(17)
     }
@@ -323,13 +339,15 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     st_loop_end = __builtin_amdgcn_s_memtime();
 #endif
     // the epilogue's scratch (column sums) is window buffer 1: its last reader was step 16
-    igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem + kU_WinBase + kU_WinStride, m0, n0, tile_m, rows_total, p.howo, W, 0, 0);
+    igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem + kU_WinBase + kU_WinStride, m0, n0, tile_m, rows_total, p.howo, W, 0, 0,
+                                        m0 >= m_split ? p.bias_b : p.bias);
     if (!has_nx) break;
     lt = lt_nx;
     tile_n = tn_nx; tile_m = tm_nx;
     n0 = tile_n * BN; m0 = tile_m * BM;
     q0 = q0_t;
     b_off0 = b_t;
+    rs_b = rs_t;
     edge16 = edge_bits(m0);
   }
 #undef VDQN_USTEP

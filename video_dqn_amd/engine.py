@@ -234,7 +234,7 @@ class TDStepper:
     def __init__(self, net: NetEngine, batch: int, lr: float, gamma: float, clip_rect: bool, linear: bool = False,
                  remove_before_reward: bool = False, train_on_ground_truth: bool = False, value_learning: bool = False,
                  target_update_interval: int = 8000, betas=(0.9, 0.999), eps: float = 1e-8, world_size: int = 1,
-                 allreduce=None, loss_kind: str = "l2"):
+                 allreduce=None, loss_kind: str = "l2", grouped_forward: Optional[bool] = None):
         net._need_gpu()
         self.net, self.B = net, batch
         self.lib = net.lib
@@ -254,8 +254,15 @@ class TDStepper:
         with torch.cuda.device(dev):
             self.packed_online = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
             self.packed_target = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
-            self.acts_online = torch.empty(net.acts_bytes(batch if self.gtb else 2 * batch), dtype=torch.uint8, device=dev)
-            self.acts_target = None if self.gtb else torch.empty(net.acts_bytes(batch), dtype=torch.uint8, device=dev)
+            # grouped forward (default for the TD branch of extra_capacity; VDQN_GROUPED_FWD=0 / grouped_forward=False = two passes):
+            # the target network's pass over s' runs inside the online pass's launches (include/vdqn.h, vdqn_step_args.acts_target)
+            if grouped_forward is None:
+                grouped_forward = os.environ.get("VDQN_GROUPED_FWD", "1") != "0"
+            self.grouped = bool(grouped_forward) and not self.gtb and net.extra_capacity
+            n_online = batch if self.gtb else (3 * batch if self.grouped else 2 * batch)
+            self.layout_samples = n_online  # what vdqn_net_act_offset must be asked for to find a tensor inside acts_online
+            self.acts_online = torch.empty(net.acts_bytes(n_online), dtype=torch.uint8, device=dev)
+            self.acts_target = None if (self.gtb or self.grouped) else torch.empty(net.acts_bytes(batch), dtype=torch.uint8, device=dev)
             net.register_sync_buffer(self.acts_online)
             self.bwd = torch.empty(net.bwd_bytes(batch), dtype=torch.uint8, device=dev)
             self.grads = torch.zeros(nt, dtype=torch.float32, device=dev)
