@@ -511,6 +511,11 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_FUSE_POOL_BWD": "0"},      # max-pool backward + stem weight gradient as two launches
     {"VDQN_WIN9_BM256": "2"},         # 256-row tiles of the nine-tap window kernel
     {"VDQN_FUSE_DS": "3"},            # 1x1 downsample fused into its sibling 3x3/2 in the forward pass too
+    {"VDQN_GROUPED_FWD": "0"},        # online and target forward as two separate passes
+    {"VDQN_GROUPED_LAUNCH": "0"},     # grouped forward, every layer through the internal two-launch fall-back
+    {"VDQN_WIN9_MFMA32": "1"},        # nine-tap window kernel on 32x32x16 MFMAs (win9m.hip)
+    {"VDQN_WIN9_MFMA32": "0"},        # ... on 16x16x32 MFMAs (win9.hip)
+    {"VDQN_WGRAD_WINDOW": "3"},       # 64x64 window weight-gradient tiles for every 3x3 / stride-1 layer (layer4 too)
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_non_default_kernel_selections(env):
     """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and

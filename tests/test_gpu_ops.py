@@ -548,3 +548,19 @@ def test_nine_tap_window_kernel_nonsquare(geom):
     torch.cuda.synchronize()
     assert relerr(got.float().cpu().permute(0, 3, 1, 2), refg) < TOL[dtype]
     assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
+
+
+@pytest.mark.parametrize("mfma32", ["0", "1"])
+def test_nine_tap_kernels_both_mfma_shapes(mfma32):
+    """The nine-tap window kernel exists on 16x16x32 MFMAs (win9.hip) and on 32x32x16 MFMAs (win9m.hip: other fragment layout,
+    other LDS swizzles, its own epilogue); VDQN_WIN9_MFMA32 (read once per process) selects one.  The operator tests that reach
+    it — layer2-4 geometries, edge geometries, persistent multi-tile launches, non-square images, forward with residual + ReLU
+    and f32 output, data gradient with mask and column sums — run in a child process under each setting."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "(nine_tap and not both_mfma) or (test_conv_forward and bfloat16) or (test_conv_dgrad and bfloat16)"],
+                       env=dict(os.environ, VDQN_WIN9_MFMA32=mfma32), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]

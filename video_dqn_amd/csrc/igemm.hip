@@ -28,6 +28,7 @@
 #include "common.h"
 
 int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, hipStream_t st);  // stem.hip
+int vdqn_launch_win9m(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9m.hip
 int vdqn_launch_win9u(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9.hip
 
 #include "igemm_common.h"
@@ -1523,6 +1524,9 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
         static const int unrolled = [] { const char* e = getenv("VDQN_WIN9_UNROLLED"); return e ? atoi(e) : 1; }();
         if (unrolled && a->ci % 128 == 0) {
           if (!grp(256)) return VDQN_OK;  // (256: also right for the optional 256-row tiles)
+          // VDQN_WIN9_MFMA32: the same kernel on 32x32x16 MFMAs (win9m.hip; vector epilogue only)
+          static const int mfma32 = [] { const char* e = getenv("VDQN_WIN9_MFMA32"); return e ? atoi(e) : 0; }();
+          if (mfma32 && p.vec_ok && a->co % 128 == 0) return vdqn_launch_win9m(&p, mode, st);
           return vdqn_launch_win9u(&p, mode, st);
         }
         if (group_rows > 0) return VDQN_OK;  // the remaining window kernels have no grouped form: two launches
