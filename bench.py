@@ -132,6 +132,7 @@ def pmc_traffic(kernel: str, batch: int, frames: int, dtype: str, arch: str = "e
 def main():
     args = parse()
     from video_dqn_amd import launch
+    launch.die_with_parent()  # a rank started by spawn_ranks goes down with its launcher
     if args.gpus > 1 and not launch.in_rank_env():
         # no launcher around us: become one.  Nothing above has touched the GPU (importing torch does not), so the
         # children are started from a HIP-free parent that only waits for them.

@@ -11,6 +11,7 @@ from video_dqn_amd import launch  # noqa: E402
 
 if __name__ == "__main__":
     n = int(sys.argv[sys.argv.index("--gpus") + 1])
+    launch.die_with_parent()  # a rank started by spawn_ranks goes down with its launcher
     if n > 1 and not launch.in_rank_env():
         sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], n))
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

@@ -69,7 +69,7 @@ def test_forward_matches_reference_golden(golden):
         assert relerr(q, ref) < 1e-3
 
 
-def _run_steps(dtype, steps, B=8):
+def _run_steps(dtype, steps, B=8, batch_seed0=100):
     from video_dqn_amd.engine import TDStepper
     net = make_engine(dtype, seed=7, max_batch=2 * B)
     stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True)
@@ -78,7 +78,7 @@ def _run_steps(dtype, steps, B=8):
     tnet.pack_weights(stp.packed_target)
     out = []
     for step in range(1, steps + 1):
-        (tup, raw) = synth.make_batch(100 + step, B, 1, structured=True, reward_p=0.3)
+        (tup, raw) = synth.make_batch(batch_seed0 + step, B, 1, structured=True, reward_p=0.3)
         before, after, act, rew, term, gt, vm = tup
         loss = stp.step(before.contiguous().to(DEV), after.contiguous().to(DEV), 1, act.to(DEV), rew.float().to(DEV),
                         term.float().to(DEV))
@@ -139,50 +139,101 @@ def cosine(a, b):
     return (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
 
 
-def _f64_yardstick(net, engine_grads, make_trainer, tup, what):
+class _EngineReLU(torch.nn.Module):
+    """Stand-in for a BasicBlock's (shared) nn.ReLU in the ORACLE, test-side only: the first len(masks) calls — the two ReLUs of
+    the block in the model(before) pass, the only pass gradients flow through — take the ENGINE's decisions (x * mask, gradient
+    g * mask); later calls (the model(after) pass) are plain ReLUs.  With it the float64 oracle differentiates the same piecewise
+    linear function the engine evaluated, so what remains between the two gradients is arithmetic, not a ReLU whose
+    pre-activation rounds to the other side of zero."""
+
+    def __init__(self, masks):
+        super().__init__()
+        self.masks, self.calls = masks, 0
+
+    def forward(self, x):
+        i = self.calls
+        self.calls += 1
+        return x * self.masks[i].to(x.dtype) if i < len(self.masks) else torch.relu(x)
+
+
+def _engine_relu_masks(net, acts, layout_samples, n_frames):
+    """(h > 0, o > 0) of the 8 BasicBlocks for the first n_frames frames, NCHW bool, from the engine's saved activations."""
+    F = net.num_frames
+    out = []
+    for b in range(8):
+        sp, c = 56 >> (b // 2), 64 << (b // 2)
+        pair = []
+        for name in (f"h{b}", f"o{b}"):
+            a = _act(net, acts, layout_samples, name, (layout_samples * F, sp, sp, c))[:n_frames]
+            pair.append((a.float() > 0).cpu().permute(0, 3, 1, 2).contiguous())
+        out.append(pair)
+    return out
+
+
+def _f64_yardstick(net, engine_grads, make_trainer, tup, what, relu_masks=None):
     """The f32 gradient gate (north_star: 1e-3 relative, fp32): the oracle is run in float64 AND float32 on the same minibatch;
-    per gradient tensor the engine's distance to the float64 gradients must satisfy
+    per gradient tensor the engine's distance to the float64 gradients is measured and compared with the fp32 oracle's own:
         L2:  err(engine, f64) <= max(1e-3, 1.5 * err(oracle_f32, f64))      max element:  <= max(5e-3, 1.5 * err_max(oracle_f32, f64))
     (the rule of tests/test_gpu_basic.py: two fp32 implementations are both measured against the exact answer, neither against
-    the other).  Returns (bad, report): the tensors that fail and a line naming the worst tensor with its measured numbers —
-    emitted as a pytest warning so a `-q` log shows how far from 1e-3 the run was."""
+    the other).  With `relu_masks` (the engine's ReLU decisions, `_engine_relu_masks`) a third float64 run differentiates the
+    function the engine actually evaluated (`_EngineReLU`); against it the gate is the strict one, L2 <= 1e-3 and max <= 5e-3
+    for every tensor.  Returns (bad_natural, bad_forced, report): the tensors outside either gate and a line naming the worst
+    tensors with their measured numbers — emitted as a pytest warning so a `-q` log shows how far from 1e-3 the run was."""
     from oracle import ref_cpu
-    grads = {}
-    for prec in (torch.float32, torch.float64):
+
+    def run(prec, masks=None):
         tr = make_trainer()
         tr.model.to(prec)
         tr.target_net.to(prec)
+        if masks is not None:
+            for b in range(8):
+                getattr(tr.model.resnet, f"layer{b // 2 + 1}")[b % 2].relu = _EngineReLU(masks[b])
         tr.model.set_train()
         tr.optimizer.zero_grad()
         loss = ref_cpu.process_batch(tr.model, tr.target_net, tr.config, (tup[0].to(prec), tup[1].to(prec)) + tuple(tup[2:]))
         loss.backward()
-        grads[prec] = {n: p.grad.double() for n, p in tr.model.named_parameters() if p.grad is not None}
-    bad, rows = [], []
-    for name, r in grads[torch.float64].items():
+        return {n: p.grad.double() for n, p in tr.model.named_parameters() if p.grad is not None}
+    g32, g64 = run(torch.float32), run(torch.float64)
+    g64f = run(torch.float64, relu_masks) if relu_masks is not None else None
+    bad, bad_forced, rows, rows_f = [], [], [], []
+    for name, r in g64.items():
         s = net.slots[name]
         ge = engine_grads[s.offset:s.offset + s.numel].view(s.shape).double().cpu()
-        g32 = grads[torch.float32][name]
         rn, rm = r.norm().clamp_min(1e-300), r.abs().max().clamp_min(1e-300)
         e_l2, e_mx = ((ge - r).norm() / rn).item(), ((ge - r).abs().max() / rm).item()
-        o_l2, o_mx = ((g32 - r).norm() / rn).item(), ((g32 - r).abs().max() / rm).item()
+        o_l2, o_mx = ((g32[name] - r).norm() / rn).item(), ((g32[name] - r).abs().max() / rm).item()
         rows.append((e_l2, e_mx, o_l2, o_mx, name))
         if e_l2 > max(1e-3, 1.5 * o_l2) or e_mx > max(5e-3, 1.5 * o_mx):
             bad.append((name, e_l2, e_mx, o_l2, o_mx))
+        if g64f is not None:
+            rf = g64f[name]
+            f_l2 = ((ge - rf).norm() / rf.norm().clamp_min(1e-300)).item()
+            f_mx = ((ge - rf).abs().max() / rf.abs().max().clamp_min(1e-300)).item()
+            rows_f.append((f_l2, f_mx, name))
+            if f_l2 > 1e-3 or f_mx > 5e-3:
+                bad_forced.append((name, f_l2, f_mx))
     w = max(rows)
     wm = max(rows, key=lambda t: t[1])
     report = (f"{what}: worst gradient tensor vs the float64 oracle: L2 {w[0]:.3g} ({w[4]}; fp32 oracle's own {w[2]:.3g}), "
               f"max element {wm[1]:.3g} ({wm[4]}; fp32 oracle's own {wm[3]:.3g}); gate L2 <= max(1e-3, 1.5 x oracle), "
-              f"max <= max(5e-3, 1.5 x oracle); {len(bad)} of {len(rows)} tensors outside")
-    return bad, report
+              f"max <= max(5e-3, 1.5 x oracle): {len(bad)} of {len(rows)} tensors outside")
+    if rows_f:
+        wf, wfm = max(rows_f), max(rows_f, key=lambda t: t[1])
+        report += (f"; vs the float64 oracle on the ENGINE's ReLU decisions: L2 {wf[0]:.3g} ({wf[2]}), max {wfm[1]:.3g} ({wfm[2]}); strict gate "
+                   f"1e-3 / 5e-3: {len(bad_forced)} outside")
+    return bad, bad_forced, report
 
 
-@pytest.mark.parametrize("dtype,tol_q,tol_g", [("f32", 1e-3, 1e-3), ("bf16", 4e-2, None)])
-def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
+@pytest.mark.parametrize("dtype,tol_q,tol_g,batch_seed", [("f32", 1e-3, 1e-3, 101), ("f32", 1e-3, 1e-3, 102), ("f32", 1e-3, 1e-3, 103), ("bf16", 4e-2, None, 101)])
+def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g, batch_seed):
     """One update compared over every gradient element with the oracle run on the GPU box's host.
-    f32: every gradient tensor is measured against the oracle run in float64; its relative L2 error must be <= 1e-3 (north_star)
-    and its max error <= 5e-3 of the tensor's max — or within 1.5x the distance of the fp32 oracle itself from float64
-    (`_f64_yardstick`; the measured worst tensor is emitted as a pytest warning).  ReLU sign disagreements between engine and
-    fp32 oracle are counted and reported as information; they do not change the tolerance.
+    f32 (three minibatches): every gradient tensor is measured against the oracle run in float64 (`_f64_yardstick`; the measured
+    worst tensors are emitted as a pytest warning).  Gate 1, always strict: against the float64 oracle that takes the ENGINE's
+    ReLU decisions, relative L2 <= 1e-3 (north_star) and max error <= 5e-3 of the tensor's max, every tensor.  Gate 2, against the
+    float64 oracle as it is: the same bounds or 1.5x the fp32 oracle's own distance from float64; a ReLU whose pre-activation
+    rounds to the other side of zero in the engine (expected about once per 1e7 activations for ANY two fp32 implementations:
+    measured 0-1 per minibatch of 13.6 M) moves the tensors downstream of it by ~1e-3 of their norm — a minibatch with such a
+    flip is held to 3e-3 / 1.5e-2 there, and the flips themselves to <= 1e-5 of the activations.
     bf16 (throughput mode): the TD error Q_b - y is a difference of O(1) Q-values carrying ~1e-2 bf16 error and
     bf16 activations flip many ReLU masks, so element-wise agreement with an fp32 run is not defined; gate on
     direction and scale instead: the WHOLE gradient must agree with the oracle's to cosine >= 0.995 and 2 % in norm
@@ -193,14 +244,14 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
     from oracle import ref_cpu
     torch.set_num_threads(max(1, torch.get_num_threads()))
     B = 8
-    net, out = _run_steps(dtype, 1, B)
+    net, out = _run_steps(dtype, 1, B, batch_seed0=batch_seed - 1)
 
     def make_trainer():
         t = ref_cpu.Trainer(ref_cpu.default_config(), synth.make_state_dict(7))
         t.target_net.load_state_dict(synth.make_state_dict(8))
         return t
     tr = make_trainer()
-    (tup, _) = synth.make_batch(101, B, 1, structured=True, reward_p=0.3)
+    (tup, _) = synth.make_batch(batch_seed, B, 1, structured=True, reward_p=0.3)
     d = {}
     loss = tr.step(tup, d)
     assert abs(out[0]["loss"] - loss) <= tol_q * abs(loss) * 5
@@ -214,9 +265,13 @@ def test_td_step_matches_oracle_all_elements(dtype, tol_q, tol_g):
         flips = _count_relu_flips(net, out[0]["acts"], out[0]["layout_samples"], B, feats)
         total = sum(int(v.numel()) for v in feats.values())
         assert flips <= 1e-5 * total
-        bad, report = _f64_yardstick(net, out[0]["grads"], make_trainer, tup, "f32 parity gate (B=8, F=1)")
+        masks = _engine_relu_masks(net, out[0]["acts"], out[0]["layout_samples"], B)
+        bad, bad_forced, report = _f64_yardstick(net, out[0]["grads"], make_trainer, tup, f"f32 parity gate (B=8, F=1, minibatch {batch_seed})", masks)
         import warnings  # the warnings summary is what a `pytest -q` log keeps
-        warnings.warn(report + f"; ReLU sign disagreements engine vs fp32 oracle: {flips} of {total} (information only)")
+        warnings.warn(report + f"; ReLU sign disagreements engine vs fp32 oracle: {flips} of {total}")
+        assert not bad_forced, bad_forced
+        if flips > 0:  # tensors downstream of a flipped ReLU: bounded, not exempted
+            bad = [t for t in bad if t[1] > 3e-3 or t[2] > 1.5e-2]
     all_g, all_ref = [], []
     for name, p in tr.model.named_parameters():
         if p.grad is None:
@@ -377,10 +432,14 @@ def test_td_step_multi_frame_matches_oracle_f32():
     feats = _oracle_relu_outputs(tr.model, before.reshape(B * F, 3, 224, 224))
     flips = _count_relu_flips(net, stp.acts_online, stp.layout_samples, B * F, feats)
     assert flips <= 8
-    bad, report = _f64_yardstick(net, stp.grads, lambda: ref_cpu.Trainer(ref_cpu.default_config(), synth.make_state_dict(7, num_frames=F), num_frames=F),
-                                 tup, f"f32 parity gate (B={B}, F={F})")
+    masks = _engine_relu_masks(net, stp.acts_online, stp.layout_samples, B * F)
+    bad, bad_forced, report = _f64_yardstick(net, stp.grads, lambda: ref_cpu.Trainer(ref_cpu.default_config(), synth.make_state_dict(7, num_frames=F), num_frames=F),
+                                             tup, f"f32 parity gate (B={B}, F={F})", masks)
     import warnings
-    warnings.warn(report + f"; ReLU sign disagreements engine vs fp32 oracle: {flips} (information only)")
+    warnings.warn(report + f"; ReLU sign disagreements engine vs fp32 oracle: {flips}")
+    assert not bad_forced, bad_forced
+    if flips > 0:  # with 12 frames a flipped ReLU moves the 7x7-map gradients more: bounded at 1e-2 / 5e-2, not exempted
+        bad = [t for t in bad if t[1] > 1e-2 or t[2] > 5e-2]
     assert not bad, bad
 
 
@@ -523,6 +582,6 @@ def test_non_default_kernel_selections(env):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_engine.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "td_step_matches_oracle_all_elements or side_stream_overlap or deterministic_mode_is_bit_identical"],
+                        "-k", "(td_step_matches_oracle_all_elements and 101) or side_stream_overlap or deterministic_mode_is_bit_identical"],
                        env=dict(os.environ, **env), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]

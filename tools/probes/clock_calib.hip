@@ -161,7 +161,8 @@ int main(int argc, char** argv) {
     for (int shape = 0; shape < 2; ++shape) {
       for (int iters : {400, 60000}) {
         const double est_ms = 512.0 * iters / 2.0e6;  // at ~2 GHz
-        const int heat = (int)std::min(20000.0, 2000.0 / est_ms);
+        // CALIB_QUICK=1 (runs under `rocprofv3 --pmc`, where every dispatch is serialised and slow): three heat launches only
+        const int heat = getenv("CALIB_QUICK") ? 3 : (int)std::min(20000.0, 2000.0 / est_ms);
         Result r = shape == 0 ? run<0>(d_data, d_st, d_sink, blocks, iters, heat) : run<1>(d_data, d_st, d_sink, blocks, iters, heat);
         printf("%-10s %-9s %9d %8.1f us | %12.4f %12.3f %10.3f %9.1f\n", fill == 0 ? "zeros" : "random", shape == 0 ? "16x16x32" : "32x32x16", iters, r.us,
                r.ticks_per_mfma_cycle, r.memtime_ghz, r.wall_ghz, r.tflops);

@@ -39,6 +39,7 @@ if __name__ == "__main__":
 
     from video_dqn_amd import launch
     gpu_ids = [g for g in args.gpu.split(",") if g != ""]
+    launch.die_with_parent()  # a rank started by spawn_ranks goes down with its launcher
     if len(gpu_ids) > 1 and not launch.in_rank_env():
         # one rank per listed GPU; this parent never initialises HIP and exits with the ranks' code
         single = os.environ.get("VDQN_SINGLE_DEVICE") == "1"  # functional test: every rank on the first listed GPU

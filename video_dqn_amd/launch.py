@@ -23,6 +23,22 @@ def in_rank_env() -> bool:
     return "RANK" in os.environ and "WORLD_SIZE" in os.environ
 
 
+def die_with_parent() -> None:
+    """Called by a rank program at start-up (bench.py, train_q_network.py, before they touch the GPU): if this process was
+    started by ``spawn_ranks`` it gets SIGTERM when the launcher dies, however that happens.  Done here rather than in a
+    ``preexec_fn`` of the launcher, which is not safe once the launching process has threads (it has: torch is imported)."""
+    ppid = os.environ.get("VDQN_LAUNCHER_PID")
+    if not ppid or not in_rank_env():
+        return
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
+        if os.getppid() != int(ppid):  # the launcher died before the prctl took effect
+            os.kill(os.getpid(), signal.SIGTERM)
+    except Exception:
+        pass
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -62,23 +78,15 @@ def spawn_ranks(argv: Sequence[str], world_size: int, extra_env: Optional[Dict[s
     No rank outlives this call: the ranks are stopped (SIGTERM to each rank's own session, SIGKILL after 20 s) when one of
     them fails, when ``timeout_s`` (default: ``VDQN_LAUNCH_TIMEOUT`` seconds, unset = none) runs out, when a rank is still
     running ``straggler_grace_s`` after the first one exited cleanly (a peer stuck in a collective), when this process gets
-    SIGTERM / SIGINT / SIGHUP (returns 128 + signal), and on any exception (try/finally).  Each child also asks the kernel
-    for SIGTERM should this process die without running any of that (PR_SET_PDEATHSIG)."""
+    SIGTERM / SIGINT / SIGHUP (returns 128 + signal), and on any exception (try/finally).  Should this process die without
+    running any of that (SIGKILL), the ranks still go: each rank program calls ``die_with_parent()`` first thing, which asks
+    the kernel for SIGTERM on the launcher's death (PR_SET_PDEATHSIG; VDQN_LAUNCHER_PID tells it who the launcher is)."""
     if timeout_s is None and os.environ.get("VDQN_LAUNCH_TIMEOUT"):
         timeout_s = float(os.environ["VDQN_LAUNCH_TIMEOUT"])
     if os.environ.get("VDQN_LAUNCH_STRAGGLER_GRACE"):
         straggler_grace_s = float(os.environ["VDQN_LAUNCH_STRAGGLER_GRACE"])
     port = os.environ.get("MASTER_PORT") or str(free_port())
     parent = os.getpid()
-
-    def _child_setup():  # runs in the child between fork and exec (no GPU, no threads yet)
-        try:
-            import ctypes
-            ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
-            if os.getppid() != parent:  # the parent died before the prctl took effect
-                os.kill(os.getpid(), signal.SIGTERM)
-        except Exception:
-            pass
 
     procs: List[subprocess.Popen] = []
     got_signal: List[int] = []
@@ -101,11 +109,12 @@ def spawn_ranks(argv: Sequence[str], world_size: int, extra_env: Optional[Dict[s
             # The image exports it already; it is repeated here so that a rank started from a scrubbed environment (pytest's
             # subprocess env, a service manager) still gets it.  A value the caller set wins.
             env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world_size), "LOCAL_WORLD_SIZE": str(world_size),
-                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                        "VDQN_LAUNCHER_PID": str(parent)})
             if extra_env:
                 env.update(extra_env)
             procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if rank == 0 else sys.stderr,
-                                          start_new_session=True, preexec_fn=_child_setup))
+                                          start_new_session=True))  # (no preexec_fn: unsafe once the parent has threads)
         t0 = time.monotonic()
         first_clean_exit: Optional[float] = None
         live = list(procs)
