@@ -157,16 +157,22 @@ class _EngineReLU(torch.nn.Module):
 
 
 def _engine_relu_masks(net, acts, layout_samples, n_frames):
-    """(h > 0, o > 0) of the 8 BasicBlocks for the first n_frames frames, NCHW bool, from the engine's saved activations."""
+    """The engine's ReLU decisions for the first n_frames frames, per BasicBlock the list the oracle's shared nn.ReLU meets in
+    the model(before) pass: the reference applies `features` one frame slot at a time (archs/HabitatDQNMultiAction.py:49-51), so
+    the block's ReLU is called as (h, o) of slot 0, (h, o) of slot 1, ... — NCHW bool masks of B samples each (engine images
+    are sample-major, frame-minor: slot f = images f, f + F, ...)."""
     F = net.num_frames
     out = []
     for b in range(8):
         sp, c = 56 >> (b // 2), 64 << (b // 2)
-        pair = []
+        full = []
         for name in (f"h{b}", f"o{b}"):
             a = _act(net, acts, layout_samples, name, (layout_samples * F, sp, sp, c))[:n_frames]
-            pair.append((a.float() > 0).cpu().permute(0, 3, 1, 2).contiguous())
-        out.append(pair)
+            full.append((a.float() > 0).cpu().permute(0, 3, 1, 2).contiguous())
+        calls = []
+        for f in range(F):
+            calls += [full[0][f::F].contiguous(), full[1][f::F].contiguous()]
+        out.append(calls)
     return out
 
 
@@ -570,8 +576,8 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_FUSE_POOL_BWD": "0"},      # max-pool backward + stem weight gradient as two launches
     {"VDQN_WIN9_BM256": "2"},         # 256-row tiles of the nine-tap window kernel
     {"VDQN_FUSE_DS": "3"},            # 1x1 downsample fused into its sibling 3x3/2 in the forward pass too
-    {"VDQN_GROUPED_FWD": "0"},        # online and target forward as two separate passes
-    {"VDQN_GROUPED_LAUNCH": "0"},     # grouped forward, every layer through the internal two-launch fall-back
+    {"VDQN_GROUPED_FWD": "1"},        # online and target forward as one chain of grouped launches
+    {"VDQN_GROUPED_FWD": "1", "VDQN_GROUPED_LAUNCH": "0"},  # grouped forward, every layer through the internal two-launch fall-back
     {"VDQN_WIN9_MFMA32": "1"},        # nine-tap window kernel on 32x32x16 MFMAs (win9m.hip)
     {"VDQN_WIN9_MFMA32": "0"},        # ... on 16x16x32 MFMAs (win9.hip)
     {"VDQN_WGRAD_WINDOW": "3"},       # 64x64 window weight-gradient tiles for every 3x3 / stride-1 layer (layer4 too)

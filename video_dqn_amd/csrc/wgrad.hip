@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int j = 0; j < NFR; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = WSPLIT ? 0 : (wave >> 1), wc = wave & 1;
+  const int wr = WSPLIT ? 0 : (wave >> 1), wc = WSPLIT ? 0 : (wave & 1);
   const int grp = lane >> 4, i16 = lane & 15;
 
   auto compute = [&](int buf) {

@@ -254,10 +254,13 @@ class TDStepper:
         with torch.cuda.device(dev):
             self.packed_online = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
             self.packed_target = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
-            # grouped forward (default for the TD branch of extra_capacity; VDQN_GROUPED_FWD=0 / grouped_forward=False = two passes):
-            # the target network's pass over s' runs inside the online pass's launches (include/vdqn.h, vdqn_step_args.acts_target)
+            # grouped forward (VDQN_GROUPED_FWD=1 / grouped_forward=True; TD branch of extra_capacity): the target network's pass over
+            # s' runs inside the online pass's launches (include/vdqn.h, vdqn_step_args.acts_target).  Off by default: it saves
+            # 0.26 ms of kernel time per update (fewer partial rounds, 21 launches fewer) but the update gets 0.2 ms LONGER — as
+            # two passes the target forward runs on the engine's side stream and fills the online chain's launch gaps and tail
+            # rounds, which one merged chain cannot (profiles/r03b_ab_grouped_mfma32_wgradwin.txt: 5.98 vs 5.77 ms)
             if grouped_forward is None:
-                grouped_forward = os.environ.get("VDQN_GROUPED_FWD", "1") != "0"
+                grouped_forward = os.environ.get("VDQN_GROUPED_FWD", "0") == "1"
             self.grouped = bool(grouped_forward) and not self.gtb and net.extra_capacity
             n_online = batch if self.gtb else (3 * batch if self.grouped else 2 * batch)
             self.layout_samples = n_online  # what vdqn_net_act_offset must be asked for to find a tensor inside acts_online
