@@ -564,3 +564,17 @@ def test_nine_tap_kernels_both_mfma_shapes(mfma32):
                         "-k", "(nine_tap and not both_mfma) or (test_conv_forward and bfloat16) or (test_conv_dgrad and bfloat16)"],
                        env=dict(os.environ, VDQN_WIN9_MFMA32=mfma32), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("win128", ["0", "1"])
+def test_weight_gradient_kernels_both_tilings(win128):
+    """The 3x3 / stride-1 weight gradients of the 128+ channel layers run on 128 x 128 window tiles (eight waves, VDQN_WGRAD_WIN128=1,
+    default) or on round 2's 64 x 64 window / generic 128 x 128 tiles (=0): the weight-gradient operator tests under each setting."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), os.path.join(root, "tests", "test_gpu_engine.py"),
+                        "-m", "gpu", "-q", "-x", "-k", "(test_conv_wgrad and not both_tilings) or deterministic_wgrad_operator"],
+                       env=dict(os.environ, VDQN_WGRAD_WIN128=win128), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]

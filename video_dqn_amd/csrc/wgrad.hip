@@ -357,10 +357,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // byte the block does three times the MFMAs of wgrad_kernel (which restages both operands for every tap).
 // Grid: (co tile, kernel row, ci tile) x split of the pixel range.
 // ---------------------------------------------------------------------------------------------------------
-template <int BCO, int BCI>
-__global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) {
+// NW = 4 waves, two workgroups per CU (64 x 64 tiles, and 128 x 64 as a 2 x 2 wave grid); NW = 8 waves, ONE workgroup per CU:
+// 128 x 128 tiles for the 128+ channel layers — wave (co half, ci quarter) owns 64 x 32 x 3 taps = 96 accumulator VGPRs for all
+// four sub-steps, nothing is summed across waves, and per staged byte the tile does twice the MFMAs of two 64 x 64 tiles:
+// 66 KB per 128 pixels and CU for 6.3 MMAC instead of 66 KB for 3.1.  (The 64 x 64 tiles of two co-resident workgroups ask the
+// L2 -> LDS path for 43 B per cycle and CU at full MFMA rate, against the ~33 it delivers — MI355X_MICROARCH.md, gather into LDS —
+// which is why pipelining their fragment stream alone did not move them: profiles/r03b_ab_grouped_mfma32_wgradwin.txt.)
+template <int BCO, int BCI, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams p) {
   typedef bf16raw T;
   constexpr int E16 = 8;
+  constexpr int NT = 64 * NW;
   constexpr int RBG = BCO * 2, RBX = BCI * 2;      // bytes per staged gy / x row (one pixel)
   constexpr int CPRG = RBG / 16, CPRX = RBX / 16;
   // WSPLIT (64 x 64 tiles): wave (wave & 1) owns ALL 64 output channels x one HALF of the input channels (three taps: 24
@@ -369,14 +376,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
   // every wave the whole 64 x 64 x 3 tile = 192 accumulator VGPRs for one sub-step: no room for a second fragment set, every
   // group of four MFMAs waited lgkmcnt(0) for its own fragment pair, and five registers spilled into the K loop.)
   constexpr bool WSPLIT = (BCO == 64 && BCI == 64);
-  constexpr int KSUB = WSPLIT ? 4 : 2;
+  static_assert(NW == 4 || (NW == 8 && BCO == 128 && BCI == 128), "8 waves: the 128 x 128 tile");
+  constexpr bool PIPE = WSPLIT || NW == 8;         // software-pipelined fragment stream (see compute)
+  constexpr int KSUB = PIPE ? 4 : 2;
   constexpr int KP = 32 * KSUB;
-  constexpr int NLG = (KP * CPRG) / 256;
+  constexpr int NLG = (KP * CPRG) / NT;
   constexpr int WR = KP + 8;                       // window rows (KP + 2 needed)
-  constexpr int NLX = (WR * CPRX + 255) / 256;     // 16-byte slots per thread for the window (the last pass is partial)
+  constexpr int NLX = (WR * CPRX + NT - 1) / NT;   // 16-byte slots per thread for the window (the last pass is partial)
+  constexpr int WCOLS = WSPLIT ? 2 : NW / 2;       // wave grid: 2 output-channel halves (1 for WSPLIT) x WCOLS input-channel parts
   constexpr int NFA = WSPLIT ? 4 : BCO / 32;       // 16-wide fragments per wave: output channels
-  constexpr int NFB = BCI / 32;                    //                              input channels
-  static_assert((KP * CPRG) % 256 == 0 && (WR * CPRX - 256 * (NLX - 1)) % 64 == 0, "staging passes are whole waves");
+  constexpr int NFB = BCI / (16 * WCOLS);          //                              input channels
+  constexpr int NSUBW = WSPLIT ? 2 : KSUB;         // sub-steps of a staged K-step this wave computes
+  static_assert((KP * CPRG) % NT == 0 && (WR * CPRX - NT * (NLX - 1)) % 64 == 0, "staging passes are whole waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;                         // [2][KP * RBG]   gy tiles
   unsigned char* sX = smem + 2 * KP * RBG;          // [2][WR * RBX]   x windows
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
   const uint32_t lds_wave = lds_base + (uint32_t)wave_u * 1024u;
   const uint32_t ldg_b = (uint32_t)p.ldg * 2u;
   const uint32_t pix_b = (uint32_t)p.pix_stride * 2u;
-  constexpr int X_TAIL_WAVES = (WR * CPRX - 256 * (NLX - 1)) / 64;  // waves that take part in the last window pass
+  constexpr int X_TAIL_WAVES = (WR * CPRX - NT * (NLX - 1)) / 64;  // waves that take part in the last window pass
 
   // Staging addresses are LINEAR in the pixel index: gy row pm, and — stride 1, pad 1, same-size images laid end to end — the
   // x pixel one kernel-row offset away is pixel pm + (kr - 1) W of the flat tensor.  A pixel index below 0 or past the tensor
@@ -424,21 +435,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
   // repeat every 8 rows), so one per-lane offset per operand serves all pieces and the piece's row block is a scalar
   const uint32_t g_lane = (uint32_t)(tid / CPRG) * ldg_b + (uint32_t)((co0 + ((tid % CPRG) ^ wg_swz<T, BCO>(tid / CPRG)) * E16) * 2);
   const uint32_t x_lane = (uint32_t)(tid / CPRX) * pix_b + (uint32_t)((ci0 + ((tid % CPRX) ^ wg_swz<T, BCI>(tid / CPRX)) * E16) * 2);
-  static_assert((256 / CPRG) % 8 == 0 && (256 / CPRX) % 8 == 0, "swizzle keys repeat over the pieces of one thread");
+  static_assert((NT / CPRG) % 8 == 0 && (NT / CPRX) % 8 == 0, "swizzle keys repeat over the pieces of one thread");
   const int x_shift = (kr - 1) * p.wo - 1;  // window row j = pixel kb + j + x_shift
 
   auto issue_tile = [&](int kb, int buf) {
 #pragma unroll
     for (int i = 0; i < NLG; ++i) {
-      const uint32_t vg = g_lane + (uint32_t)(kb + (256 / CPRG) * i) * ldg_b;
-      const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RBG) + i * 4096);
+      const uint32_t vg = g_lane + (uint32_t)(kb + (NT / CPRG) * i) * ldg_b;
+      const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RBG) + i * (NT * 16));
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vg), "s"(la), "s"(rs_g) : "memory");
     }
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
       if (i == NLX - 1 && wave_u >= X_TAIL_WAVES) break;
-      const uint32_t vx = x_lane + (uint32_t)(kb + x_shift + (256 / CPRX) * i) * pix_b;  // may wrap below zero: out of range, zero-filled
-      const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RBG + buf * (WR * RBX) + i * 4096);
+      const uint32_t vx = x_lane + (uint32_t)(kb + x_shift + (NT / CPRX) * i) * pix_b;  // may wrap below zero: out of range, zero-filled
+      const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RBG + buf * (WR * RBX) + i * (NT * 16));
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vx), "s"(lx), "s"(rs_x) : "memory");
     }
   };
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
 #pragma unroll
       for (int j = 0; j < NFB; ++j) acc[k3][f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = WSPLIT ? 0 : (wave >> 1), wc = wave & 1;
+  const int wr = WSPLIT ? 0 : wave / WCOLS, wc = WSPLIT ? (wave & 1) : wave % WCOLS;
   const int grp = lane >> 4, i16 = lane & 15;
   const int q4 = i16 >> 2, pp = i16 & 3;
   const int row = 4 * grp + q4;            // pixel row (of 32) this lane addresses in a transposing read; + 16 for the high half
@@ -495,42 +506,49 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
     return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
 
-  // WSPLIT: the border masks of the wave's two sub-steps live across K tiles — those of tile k + 1 are computed inside tile k's
-  // stages (under its MFMAs), not in front of its first fragment read (~120 VALU instructions with two divisions per pixel)
-  const int sub_a = WSPLIT ? (wave >> 1) * 2 : 0, sub_b = sub_a + 1;
-  uint32_t zm_a[3] = {0u, 0u, 0u}, zm_b[3] = {0u, 0u, 0u};
-  if constexpr (WSPLIT) {
-    border(kbeg, sub_a, zm_a);
-    border(kbeg, sub_b, zm_b);
+  // PIPE: the border masks of the wave's NSUBW sub-steps live across K tiles — those of tile k + 1 are computed inside tile k's
+  // stages (under its MFMAs), not in front of its first fragment read (~30 VALU instructions with two divisions per pixel pair)
+  const int sub0 = WSPLIT ? (wave >> 1) * 2 : 0;  // first sub-step of this wave
+  uint32_t zm[NSUBW][3];
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int i = 0; i < NSUBW; ++i) border(kbeg, sub0 + i, zm[i]);
   }
 
   auto compute = [&](int buf, int kb) {
     const unsigned char* xw = sX + buf * (WR * RBX);
-    if constexpr (WSPLIT) {
-      // Software pipeline over the wave's two sub-steps: 2 x (3 taps x 2 channel fragments) = 12 stages of four MFMAs (one x
-      // fragment against the four gy fragments).  The x fragment of stage s + 2 is read while stage s computes (three
-      // register sets), the gy fragments of the second sub-step while the first one's last stages compute: no MFMA waits for
-      // an LDS read it has just issued.
-      const unsigned char* ga = sA + buf * (KP * RBG) + sub_a * (32 * RBG);
+    if constexpr (PIPE) {
+      // Software pipeline over the wave's NSUBW sub-steps: NSUBW x (3 taps x NFB channel fragments) stages of NFA MFMAs (one x
+      // fragment against the NFA gy fragments).  The x fragment of stage s + 2 is read while stage s computes (three register
+      // sets), the gy fragments of the next sub-step (second register set) while the current one's stages 2.. compute: no MFMA
+      // waits for an LDS read it has just issued.
+      constexpr int SPS = 3 * NFB;           // stages per sub-step
+      constexpr int NST = NSUBW * SPS;
+      static_assert(NFB == 2 && NFA == 4 && SPS >= 2 + NFA, "stage layout: the next sub-step's four gy fragments load in stages 2..5");
+      const unsigned char* ga = sA + buf * (KP * RBG) + sub0 * (32 * RBG);
       s16x8 af[2][NFA], bj[3];
 #pragma unroll
-      for (int f = 0; f < NFA; ++f) af[0][f] = load_g(ga, f * 16);
-      auto stage_x = [&](int st) -> s16x8 {  // st = sub-step * 6 + ks * 2 + j
-        const int sb = st / 6, ks = (st % 6) >> 1, j = st & 1;
-        return load_x(xw, sb ? sub_b : sub_a, ks, wc * (BCI / 2) + j * 16, (sb ? zm_b : zm_a)[ks]);
+      for (int f = 0; f < NFA; ++f) af[0][f] = load_g(ga, wr * (BCO / 2) + f * 16);
+      auto stage_x = [&](int st) -> s16x8 {  // st = sub-step * SPS + ks * NFB + j
+        const int sb = st / SPS, ks = (st % SPS) / NFB, j = st % NFB;
+        return load_x(xw, sub0 + sb, ks, wc * (16 * NFB) + j * 16, zm[sb][ks]);
       };
       bj[0] = stage_x(0);
       bj[1] = stage_x(1);
 #pragma unroll
-      for (int st = 0; st < 12; ++st) {
-        if (st + 2 < 12) bj[(st + 2) % 3] = stage_x(st + 2);
-        if (st >= 2 && st < 2 + NFA) af[1][st - 2] = load_g(ga + 32 * RBG, (st - 2) * 16);  // second sub-step's gy fragments, one per stage
-        if (st == 6) border(kb + KP, sub_a, zm_a);   // the next tile's masks: sub-step a's were last used by stage 3's read,
-        if (st == 10) border(kb + KP, sub_b, zm_b);  // sub-step b's by stage 9's
-        const int sb = st / 6, ks = (st % 6) >> 1, j = st & 1;
+      for (int st = 0; st < NST; ++st) {
+        const int sb = st / SPS, ss = st % SPS, ks = ss / NFB, j = ss % NFB;
+        if (st + 2 < NST) bj[(st + 2) % 3] = stage_x(st + 2);
+        // the next sub-step's gy fragments, one per stage (its register set was last read by the previous sub-step's final stage)
+        if (sb + 1 < NSUBW && ss >= 2 && ss < 2 + NFA) af[(sb + 1) & 1][ss - 2] = load_g(ga + (sb + 1) * (32 * RBG), wr * (BCO / 2) + (ss - 2) * 16);
+        // the NEXT tile's border masks of sub-step sb: its current masks were last used by the read issued two stages ago
+        if (ss == 2) {
+          if (sb > 0) border(kb + KP, sub0 + sb - 1, zm[sb - 1]);
+        }
+        if (st == NST - 1) border(kb + KP, sub0 + NSUBW - 1, zm[NSUBW - 1]);
 #pragma unroll
         for (int f = 0; f < NFA; ++f)
-          acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[sb][f]), __builtin_bit_cast(bf16x8, bj[st % 3]), acc[ks][f][j], 0, 0, 0);
+          acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[sb & 1][f]), __builtin_bit_cast(bf16x8, bj[st % 3]), acc[ks][f][j], 0, 0, 0);
         // pin the stage order: left to itself the scheduler sinks every read to just in front of its first use and waits
         // lgkmcnt(0) there.  With a scheduling fence per stage the reads stay two stages ahead and the compiler's own counted
         // lgkmcnt waits (it tracks the builtin reads) let each stage start as soon as ITS fragment has landed.
@@ -540,8 +558,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
 #pragma unroll 1
       for (int sub = 0; sub < KSUB; ++sub) {
         const unsigned char* a = sA + buf * (KP * RBG) + sub * (32 * RBG);
-        uint32_t zm[3];
-        border(kb, sub, zm);
+        uint32_t zl[3];
+        border(kb, sub, zl);
         s16x8 af[NFA];
 #pragma unroll
         for (int f = 0; f < NFA; ++f) af[f] = load_g(a, wr * (BCO / 2) + f * 16);
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
         for (int ks = 0; ks < 3; ++ks) {
 #pragma unroll
           for (int j = 0; j < NFB; ++j) {  // one x fragment live at a time (register budget)
-            const s16x8 bj = load_x(xw, sub, ks, wc * (BCI / 2) + j * 16, zm[ks]);
+            const s16x8 bj = load_x(xw, sub, ks, wc * (16 * NFB) + j * 16, zl[ks]);
 #pragma unroll
             for (int f = 0; f < NFA; ++f)
               acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bj), acc[ks][f][j], 0, 0, 0);
@@ -599,11 +617,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) 
         for (int j = 0; j < NFB; ++j)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg)
-            red[(wr * (BCO / 2) + f * 16 + grp * 4 + reg) * BCI + wc * (BCI / 2) + j * 16 + i16] = acc[ks][f][j][reg];
+            red[(wr * (BCO / 2) + f * 16 + grp * 4 + reg) * BCI + wc * (16 * NFB) + j * 16 + i16] = acc[ks][f][j][reg];
       __syncthreads();
 #pragma unroll 8
-      for (int e = 0; e < BCO * BCI / 256; ++e) {
-        const int o = tid + 256 * e;
+      for (int e = 0; e < BCO * BCI / NT; ++e) {
+        const int o = tid + NT * e;
         const int co = co0 + o / BCI, ci = ci0 + o % BCI;
         if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, red[o]);
       }
@@ -1026,16 +1044,16 @@ int launch_stem_wgrad(const WgradParams& p, hipStream_t stream) {
   return VDQN_OK;
 }
 
-template <int BCO, int BCI>
+template <int BCO, int BCI, int NW = 4>
 int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
-  constexpr int KP = 32 * ((BCO == 64 && BCI == 64) ? 4 : 2);
+  constexpr int KP = 32 * (((BCO == 64 && BCI == 64) || NW == 8) ? 4 : 2);
   const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * (KP + 8)) * BCI * 2 + 256;  // gy tiles, x windows, zero block
   const size_t smem_epi = (BCO == 64 && BCI == 64) ? (size_t)2 * 64 * 64 * 4 : (size_t)BCO * BCI * 4;
   const size_t smem = smem_stage > smem_epi ? smem_stage : smem_epi;
-  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI>), (size_t)smem);
-  vdqn_prof_begin(BCO == 128 ? "wgrad_win<bf16,128x64>" : "wgrad_win<bf16,64>", 2.0 * p.M * p.co * p.taps * p.ci,
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI, NW>), (size_t)smem);
+  vdqn_prof_begin(NW == 8 ? "wgrad_win<bf16,128>" : (BCO == 128 ? "wgrad_win<bf16,128x64>" : "wgrad_win<bf16,64>"), 2.0 * p.M * p.co * p.taps * p.ci,
                   2.0 * ((double)p.M * p.ldg + (double)p.n_img * p.hi * p.wi * p.ci) + 4.0 * p.co * p.taps * p.ci, stream);
-  hipLaunchKernelGGL((wgrad_win_kernel<BCO, BCI>), dim3(tiles * splitk), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((wgrad_win_kernel<BCO, BCI, NW>), dim3(tiles * splitk), dim3(64 * NW), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
@@ -1043,7 +1061,7 @@ int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t st
 
 // Which kernel a call runs on and how its pixel range is split (shared by the launch and by the workspace-size query).
 struct WgradPlan {
-  int variant;      // 0 stem kernel, 1 window 64x64, 2 window 128x64, 3 generic
+  int variant;      // 0 stem kernel, 1 window 64x64, 2 window 128x64, 3 generic, 4 window 128x128 (eight waves)
   int bt, ci_tiles, tiles, splitk, kchunk;
   int copies;       // partial copies of dw the deterministic mode stores (active splits, or blocks of the stem kernel)
   long long copy_elems;  // floats per copy
@@ -1098,8 +1116,20 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
     pl->kchunk = M;
     return VDQN_OK;
   }
-  if (use_win && (small_win || use_win >= 2) && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 &&
-      a->pix_stride == a->ci && a->wo >= 2 && a->hi == a->ho && a->wi == a->wo) {
+  // VDQN_WGRAD_WIN128 (default 1): 128 x 128 window tiles on eight waves, one workgroup per CU, for the 3x3 / stride-1 layers with
+  // 128+ channels (layer2 - layer4): twice the MFMAs per staged byte of the 64 x 64 tiles, no sum across waves; 0 = round 2's choice
+  static const int use_win128 = [] { const char* e = getenv("VDQN_WGRAD_WIN128"); return e ? atoi(e) : 1; }();
+  const bool win_geom = a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && a->pix_stride == a->ci && a->wo >= 2 &&
+                        a->hi == a->ho && a->wi == a->wo;
+  if (use_win && use_win128 && use_win < 3 && win_geom && co_pad % 128 == 0 && a->ci % 128 == 0) {
+    pl->variant = 4;
+    pl->ci_tiles = a->ci / 128;
+    pl->tiles = (co_pad / 128) * 3 * pl->ci_tiles;
+    const int target8 = [] { const char* e = getenv("VDQN_WGRAD_BLOCKS8"); return e ? atoi(e) : 256; }();  // one workgroup per CU
+    splitk = a->splitk > 0 ? a->splitk : target8 / pl->tiles;
+    if (splitk > max_split) splitk = max_split;
+    if (splitk < 1) splitk = 1;
+  } else if (use_win && (small_win || use_win >= 2) && win_geom) {
     const int bco = (small_win || use_win >= 3) ? 64 : bt, bci = 64;
     pl->variant = bco == 128 ? 2 : 1;
     pl->ci_tiles = a->ci / bci;
@@ -1158,6 +1188,7 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   }
   int rc;
   if (pl.variant == 0) rc = launch_stem_wgrad(p, st);
+  else if (pl.variant == 4) rc = launch_wgrad_win<128, 128, 8>(p, pl.tiles, pl.splitk, st);
   else if (pl.variant == 2) rc = launch_wgrad_win<128, 64>(p, pl.tiles, pl.splitk, st);
   else if (pl.variant == 1) rc = launch_wgrad_win<64, 64>(p, pl.tiles, pl.splitk, st);
   else if (a->dtype == VDQN_BF16) rc = pl.bt == 128 ? launch_wgrad<bf16raw, 128>(p, pl.tiles, pl.splitk, st) : launch_wgrad<bf16raw, 64>(p, pl.tiles, pl.splitk, st);
