@@ -581,7 +581,8 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_WIN9_MFMA32": "1"},        # nine-tap window kernel on 32x32x16 MFMAs (win9m.hip)
     {"VDQN_WIN9_MFMA32": "0"},        # ... on 16x16x32 MFMAs (win9.hip)
     {"VDQN_WGRAD_WINDOW": "3"},       # 64x64 window weight-gradient tiles for every 3x3 / stride-1 layer (layer4 too)
-    {"VDQN_WGRAD_WIN128": "0"},       # round 2's weight-gradient kernels for the 128+ channel layers (no eight-wave 128x128 tiles)
+    {"VDQN_WGRAD_WIN128": "1"},       # eight-wave 128x128 window weight-gradient tiles for the 128+ channel layers
+    {"VDQN_WGRAD_TWO_STAGE": "1"},    # split-K partials as plain stores + ordered reduce kernels instead of f32 atomics
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_non_default_kernel_selections(env):
     """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and

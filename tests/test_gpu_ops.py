@@ -568,8 +568,8 @@ def test_nine_tap_kernels_both_mfma_shapes(mfma32):
 
 @pytest.mark.parametrize("win128", ["0", "1"])
 def test_weight_gradient_kernels_both_tilings(win128):
-    """The 3x3 / stride-1 weight gradients of the 128+ channel layers run on 128 x 128 window tiles (eight waves, VDQN_WGRAD_WIN128=1,
-    default) or on round 2's 64 x 64 window / generic 128 x 128 tiles (=0): the weight-gradient operator tests under each setting."""
+    """The 3x3 / stride-1 weight gradients of the 128+ channel layers run on 64 x 64 window / generic 128 x 128 tiles (default) or on
+    128 x 128 window tiles (eight waves, VDQN_WGRAD_WIN128=1): the weight-gradient operator tests under each setting."""
     import os
     import subprocess
     import sys

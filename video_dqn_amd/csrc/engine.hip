@@ -736,6 +736,8 @@ ActLayout shift_layout(const vdqn_net* net, ActLayout A, int first) {
   return A;
 }
 
+bool wgrad_two_stage();
+
 BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
   const int64_t F = net->cfg.num_frames, n = (int64_t)n_samples * F, e = net->esz;
   BwdLayout L;
@@ -775,7 +777,7 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
   }
   L.det_ws = -1;
   L.det_ws_bytes = 0;
-  if (net->cfg.deterministic) {
+  if (net->cfg.deterministic || wgrad_two_stage()) {
     for (const Layer& ly : net->layers) {
       const int64_t units = ly.per_sample ? n_samples : n;
       const int64_t mx = wgrad_max_imgs(net, ly);
@@ -839,6 +841,14 @@ int64_t wgrad_max_imgs(const vdqn_net* net, const Layer& L) {
 // extra K-steps of the 3x3's stride-2 data gradient, the shortcut gradient never exists (0.27 instead of 0.42 ms per update);
 // bit 1 (default off): forward — second output of one launch, three launches fewer per pass, bit-identical outputs, but the
 // short sibling tiles (1-4 K-steps) between the long ones cost 0.07 ms per update more than their own launch did.
+// VDQN_WGRAD_TWO_STAGE=1: the split-K weight-gradient partials as plain stores into per-split copies + one ordered reduce kernel
+// per layer (the deterministic mode's path, include/vdqn.h vdqn_wgrad_args.workspace) also in the default mode — instead of
+// ~25-50 MB of f32 atomics per launch at the ~1.3 TB/s the memory side sustains for them
+bool wgrad_two_stage() {
+  static const bool on = [] { const char* e = getenv("VDQN_WGRAD_TWO_STAGE"); return e && e[0] == '1'; }();
+  return on;
+}
+
 int fuse_ds_mask() {
   static const int m = [] { const char* e = getenv("VDQN_FUSE_DS"); return e ? atoi(e) : 1; }();
   return m;
@@ -916,7 +926,7 @@ int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const voi
   a.x = x;
   a.dw = reinterpret_cast<float*>(bwd + L.dw_off);
   a.dbias = colsum_kernel ? reinterpret_cast<float*>(bwd + L.db_off) : nullptr;  // else: dgrad-epilogue partials
-  if (net->cfg.deterministic) {  // all weight gradients of an update run on ONE stream, so they can share the workspace
+  if (net->cfg.deterministic || wgrad_two_stage()) {  // all weight gradients of an update run on ONE stream, so they can share the workspace
     const BwdLayout W = bwd_layout(net, net->bwd_samples);
     a.workspace = bwd + W.det_ws;
     a.workspace_bytes = W.det_ws_bytes;

@@ -1116,9 +1116,11 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
     pl->kchunk = M;
     return VDQN_OK;
   }
-  // VDQN_WGRAD_WIN128 (default 1): 128 x 128 window tiles on eight waves, one workgroup per CU, for the 3x3 / stride-1 layers with
-  // 128+ channels (layer2 - layer4): twice the MFMAs per staged byte of the 64 x 64 tiles, no sum across waves; 0 = round 2's choice
-  static const int use_win128 = [] { const char* e = getenv("VDQN_WGRAD_WIN128"); return e ? atoi(e) : 1; }();
+  // VDQN_WGRAD_WIN128=1: 128 x 128 window tiles on eight waves, one workgroup per CU, for the 3x3 / stride-1 layers with 128+ channels
+  // (layer2 - layer4): twice the MFMAs per staged byte of the 64 x 64 tiles, no sum across waves.  Measured SLOWER (0.94 ms per update
+  // for the nine launches against 0.47 + 0.28 on 64 x 64 window / generic 128 x 128 tiles, profiles/r03d_ab_wgrad_win128.txt): at one
+  // block per CU every block ends with 196 KB of f32 atomics (50 MB per launch against 25-28 MB) — off by default
+  static const int use_win128 = [] { const char* e = getenv("VDQN_WGRAD_WIN128"); return e ? atoi(e) : 0; }();
   const bool win_geom = a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && a->pix_stride == a->ci && a->wo >= 2 &&
                         a->hi == a->ho && a->wi == a->wo;
   if (use_win && use_win128 && use_win < 3 && win_geom && co_pad % 128 == 0 && a->ci % 128 == 0) {
