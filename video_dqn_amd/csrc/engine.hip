@@ -114,6 +114,7 @@ struct vdqn_net {
   // need gy, the data-gradient chain does not wait for them) and the target-network forward.  Blocks of the side
   // kernels fill the tail rounds of the main kernels (784..3136-block grids on 512 resident blocks).
   BnSync bn_sync = {nullptr, nullptr, nullptr, 1};  // SyncBN hook ('basic' under data parallelism)
+  int wgrad_rr = 0;                                  // VDQN_WGRAD_STREAMS=2: which side stream took the last weight gradient
   int overlap = 1;
   int bwd_samples = 0;  // batch of the update in flight (set by vdqn_net_td_forward; sizes the bwd workspace layout)
   hipStream_t side = nullptr;
@@ -176,6 +177,28 @@ void join_side2(vdqn_net* net, hipStream_t main) {
   hipEvent_t e = next_event(net);
   (void)hipEventRecord(e, net->side2);
   (void)hipStreamWaitEvent(main, e, 0);
+}
+
+// Stream of the next weight-gradient launch.  VDQN_WGRAD_STREAMS=2: the launches alternate between the two side streams, so that
+// one kernel's tail (a single round of split-K blocks that all end in f32 atomics) runs beside the next kernel's start; not in the
+// deterministic / two-stage modes, whose partial copies share one workspace.  The stage's unfold kernel waits for both
+// (join_wgrad_streams).
+bool wgrad_two_streams(const vdqn_net* net) {
+  static const bool on = [] { const char* e = getenv("VDQN_WGRAD_STREAMS"); return e && atoi(e) == 2; }();
+  static const bool two_stage = [] { const char* e = getenv("VDQN_WGRAD_TWO_STAGE"); return e && e[0] == '1'; }();
+  return on && !two_stage && !net->cfg.deterministic;
+}
+hipStream_t wgrad_stream(vdqn_net* net, hipStream_t main) {
+  if (!wgrad_two_streams(net)) return fork_side(net, main);
+  net->wgrad_rr ^= 1;
+  return net->wgrad_rr ? fork_side2(net, main) : fork_side(net, main);
+}
+// the first side stream (where the unfold kernel runs) waits for the weight gradients queued on the second one
+void join_wgrad_streams(vdqn_net* net) {
+  if (!wgrad_two_streams(net) || !net->overlap || !net->side2) return;
+  hipEvent_t e = next_event(net);
+  (void)hipEventRecord(e, net->side2);
+  (void)hipStreamWaitEvent(net->side, e, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1365,11 +1388,11 @@ int block_backward(vdqn_net* net, const vdqn_step_args* a, int b, const ActLayou
   unsigned char* gx = b == 0 ? bw + W.g_pool : bw + W.g_o[b - 1];
   const void* g_out = bw + W.g_o[b];
   // conv2: weight gradient, then data gradient into g_h masked by relu(h)
-  hipStream_t ws = fork_side(net, st);  // g_out is complete on `st`
+  hipStream_t ws = wgrad_stream(net, st);  // g_out is complete on `st`
   RC(run_wgrad(net, c2, bw, g_out, ao + A.h[b], n, ws));
   if (net->l_b_ds[b] >= 0) RC(run_wgrad(net, net->layers[net->l_b_ds[b]], bw, g_out, x, n, ws));
   RC(run_dgrad(net, c2, pk, g_out, bw + W.g_h[b], n, nullptr, ao + A.h[b], st, bw + W.p_h[b]));
-  ws = fork_side(net, st);  // g_h is complete
+  ws = wgrad_stream(net, st);  // g_h is complete
   RC(run_wgrad(net, c1, bw, bw + W.g_h[b], x, n, ws));
   const void* resid = g_out;  // identity shortcut
   if (net->l_b_ds[b] >= 0) {
@@ -1454,7 +1477,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   if (net->basic()) {
     if (stage == 0) {
       const Layer& top = net->layers[net->l_top4];
-      RC(run_wgrad(net, top, bw, bw + W.dq, ao + A.avg, B, fork_side(net, st), true));
+      RC(run_wgrad(net, top, bw, bw + W.dq, ao + A.avg, B, wgrad_stream(net, st), true));
       RC(run_dgrad(net, top, pk, bw + W.dq, bw + W.g_avg, B, nullptr, nullptr, st));
       RC(vdqn_avgpool_bwd(bw + W.g_avg, ao + A.o[7], bw + W.g_o[7], n, 49, 512, dt, st));
       RC(block_backward_train(net, a, 7, A, W, n, st));
@@ -1466,20 +1489,20 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
       for (int b = 3; b >= 0; --b) RC(block_backward_train(net, a, b, A, W, n, st));
       RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
       RC(run_bn_bwd(net, a, net->l_conv1, A, bw + W.g_c1, ao + A.r_c1, bw + W.g_c1, n, st));
-      RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
+      RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, wgrad_stream(net, st)));
     }
   } else if (stage == 0) {
     const Layer& t4 = net->layers[net->l_top4];
     const Layer& t2 = net->layers[net->l_top2];
     const Layer& t0 = net->layers[net->l_top0];
     const Layer& f8 = net->layers[net->l_f8];
-    RC(run_wgrad(net, t4, bw, bw + W.dq, ao + A.l1, B, fork_side(net, st), true));
+    RC(run_wgrad(net, t4, bw, bw + W.dq, ao + A.l1, B, wgrad_stream(net, st), true));
     RC(run_dgrad(net, t4, pk, bw + W.dq, bw + W.g_l1, B, nullptr, ao + A.l1, st, bw + W.p_l1));
-    RC(run_wgrad(net, t2, bw, bw + W.g_l1, ao + A.l0, B, fork_side(net, st)));
+    RC(run_wgrad(net, t2, bw, bw + W.g_l1, ao + A.l0, B, wgrad_stream(net, st)));
     RC(run_dgrad(net, t2, pk, bw + W.g_l1, bw + W.g_l0, B, nullptr, ao + A.l0, st, bw + W.p_l0));
-    RC(run_wgrad(net, t0, bw, bw + W.g_l0, ao + A.f8, B, fork_side(net, st)));
+    RC(run_wgrad(net, t0, bw, bw + W.g_l0, ao + A.f8, B, wgrad_stream(net, st)));
     RC(run_dgrad(net, t0, pk, bw + W.g_l0, bw + W.g_f8, B, nullptr, ao + A.f8, st, bw + W.p_f8));
-    RC(run_wgrad(net, f8, bw, bw + W.g_f8, ao + A.o[7], n, fork_side(net, st)));
+    RC(run_wgrad(net, f8, bw, bw + W.g_f8, ao + A.o[7], n, wgrad_stream(net, st)));
     RC(run_dgrad(net, f8, pk, bw + W.g_f8, bw + W.g_o[7], n, nullptr, ao + A.o[7], st, bw + W.p_o[7]));
     RC(block_backward(net, a, 7, A, W, n, st));
     RC(block_backward(net, a, 6, A, W, n, st));
@@ -1535,7 +1558,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     }
     // max-pool backward on the caller's stream, the weight gradient behind it on the side stream
     RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
-    RC(run_wgrad(net, L1, bw, bw + W.g_c1, ao + A.t_in, n, fork_side(net, st)));
+    RC(run_wgrad(net, L1, bw, bw + W.g_c1, ao + A.t_in, n, wgrad_stream(net, st)));
     return VDQN_OK;
   };
   if (stem_tail && !split_conv1) RC(conv1_chain());
@@ -1544,6 +1567,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   // data gradients; only stage 2 joins the side stream back (before Adam).  vdqn_net_grad_stream() is where a stage's range of
   // `grads` is complete.
   hipStream_t us = fork_side(net, st);  // == st when the overlap is off
+  join_wgrad_streams(net);
   const double unfold_bytes = (double)(net->stage_end[stage] - net->stage_begin[stage]) * 12.0;
   if (split_conv1) {
     {
@@ -1552,6 +1576,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
                          a->params, a->bnstats, (const unsigned char*)bw, a->grads, 0);
     }
     RC(conv1_chain());
+    join_wgrad_streams(net);
     ProfScope ps_("unfold_grads", 0.0, 0.0, net->side);
     hipLaunchKernelGGL(unfold_kernel, dim3(net->layers[net->l_conv1].co, 1), dim3(256), 0, net->side, net->fold, pt, net->l_conv1, a->params, a->bnstats,
                        (const unsigned char*)bw, a->grads, 0);

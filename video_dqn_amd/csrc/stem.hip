@@ -108,16 +108,6 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   if (tid < 64) reinterpret_cast<float*>(sW + kBiasRow * 128)[tid] = p.bias[tid];  // visible after the first tile's barrier
 
   const int coff0 = ((g ^ (i16 & 7)) << 4), coff1 = (((g + 4) ^ (i16 & 7)) << 4);
-  // LDS image of the ReLU'd 16 x 16 x 64 patch (bf16 elements): conv pixel r = 16 py + px, 16-byte channel chunk c.  The pooling
-  // reads walk rows 2 pj + kw of one patch row for consecutive pooled pixels — a stride of TWO rows — so with plain 128-byte rows
-  // and the chunk key r & 7 the 16 lanes of a ds_read_b128 group met only 8 of the 16 bank positions (SQ_LDS_BANK_CONFLICT 36 % of
-  // the LDS cycles; bank model: 684 cycles per tile for 252 conflict-free).  Rows are therefore stored pair-swapped on odd row
-  // pairs (r ^ ((r >> 1) & 1): consecutive even rows alternate between the two 128-byte halves of a bank row) and the chunk key
-  // takes row bits 0, 2 and 5: 288 cycles for the reads, the epilogue's ds_write_b128 stay conflict-free.
-  auto patch_off = [](int r, int c) -> size_t {
-    const int key = (r & 1) | (((r >> 2) & 1) << 1) | (((r >> 5) & 1) << 2);
-    return (size_t)(r ^ ((r >> 1) & 1)) * 64 + (size_t)((c ^ key) * 8);
-  };
 
   int t = blockIdx.x, buf = 0;
   if (t < p.n_tiles) issue_window(t, 0);
@@ -149,6 +139,11 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     }
 
     // ---- bias + ReLU -> bf16 patch in LDS (over the window just consumed), then the 7x7 pooled pixels ----
+    // (The pooling reads walk the patch with a stride of TWO rows and meet only half of the LDS banks: 36 % of this kernel's LDS
+    // cycles are bank conflicts.  Round 3 tried the layout the bank model prefers — rows pair-swapped, another chunk key: 684 -> 288
+    // model cycles per tile — and the kernel went from 0.49 to 0.87 ms per update: its limit is VALU issue (≈ 650 vector
+    // instructions per tile and wave beside 128 MFMAs; SQ_ACTIVE_INST_VALU is the largest share), and the per-access key
+    // arithmetic costs more issue slots than the conflicts cost LDS cycles.  Kept as it was.)
     __syncthreads();
     bf16raw* sT = reinterpret_cast<bf16raw*>(sW + buf * kWBytes);
     float bv[16];  // (re-read per tile from LDS: the weights occupy the registers a resident copy would need)
@@ -163,7 +158,10 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) ov[j * 4 + q] = f32_to_bf16(fmaxf(acc[f][j][q] + bv[j * 4 + q], 0.f));
 #pragma unroll
-      for (int c = 0; c < 2; ++c) *reinterpret_cast<uint4*>(sT + patch_off(r, g * 2 + c)) = reinterpret_cast<const uint4*>(ov)[c];
+      for (int c = 0; c < 2; ++c) {
+        const int chunk = (g * 2 + c) ^ (r & 7);
+        *reinterpret_cast<uint4*>(sT + (size_t)r * 64 + chunk * 8) = reinterpret_cast<const uint4*>(ov)[c];
+      }
     }
     __syncthreads();
     const int tl = (int)xcd_remap((uint32_t)t, (uint32_t)p.n_tiles);
@@ -181,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int r = (2 * pi + kh) * 16 + 2 * pj + kw;
-          v[kh * 3 + kw] = *reinterpret_cast<const uint4*>(sT + patch_off(r, cg));
+          v[kh * 3 + kw] = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * 8));
         }
       // post-ReLU bf16 bit patterns order like unsigned integers: key = bits << 4 | (8 - tap), one v_max_u32 per element and tap
       uint32_t key[8];

@@ -15,6 +15,8 @@
 //
 // Replaces the convolution_backward / addmm weight-gradient kernels behind loss.backward()
 // (train_q_network.py:226).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -363,6 +365,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // 66 KB per 128 pixels and CU for 6.3 MMAC instead of 66 KB for 3.1.  (The 64 x 64 tiles of two co-resident workgroups ask the
 // L2 -> LDS path for 43 B per cycle and CU at full MFMA rate, against the ~33 it delivers — MI355X_MICROARCH.md, gather into LDS —
 // which is why pipelining their fragment stream alone did not move them: profiles/r03b_ab_grouped_mfma32_wgradwin.txt.)
+constexpr int kWgZeroBytes = 16 * 256 + 256;  // wgrad_win: zero block (covers the +16-row immediate of high-half reads for 128- and 256-byte rows)
+constexpr int kWgCodeBytes = 3200;            // border-code table: images up to 56 x 56
+
 template <int BCO, int BCI, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams p) {
   typedef bf16raw T;
@@ -391,7 +396,8 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;                         // [2][KP * RBG]   gy tiles
   unsigned char* sX = smem + 2 * KP * RBG;          // [2][WR * RBX]   x windows
-  unsigned char* sZ = sX + 2 * WR * RBX;            // [256]           zeros: every LDS bank once (a multiple of 256 from smem)
+  unsigned char* sZ = sX + 2 * WR * RBX;            // [kWgZeroBytes]  zeros at +0 and at +16 rows (every LDS bank once each; a multiple of 256 from smem)
+  unsigned char* sCode = sZ + kWgZeroBytes;         // [kWgCodeBytes]  PIPE: border code of every pixel position of an image
   static_assert((2 * KP * RBG) % 256 == 0 && (WR * RBX) % 256 == 0, "window buffers and the zero block sit at 256-byte boundaries");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -408,7 +414,18 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   const int kend = min(p.M, kbeg + p.kchunk);
   if (kbeg >= kend) return;
   const int nk = (kend - kbeg + KP - 1) / KP;
-  if (tid < 16) reinterpret_cast<uint4*>(sZ)[tid] = make_uint4(0, 0, 0, 0);
+  // zeros: [0, 256) for the low-half reads of border lanes and [16 RBX, 16 RBX + 256) for their high-half reads, which carry the
+  // same +16-row immediate as the reads of the window (so one select serves an address pair)
+  for (int i = tid; i < 32; i += NT) reinterpret_cast<uint4*>(sZ + (i >> 4) * (16 * RBX))[i & 15] = make_uint4(0, 0, 0, 0);
+  const int howo = (int)p.d_howo.div;
+  if constexpr (PIPE) {
+    // border code of image position rem = oh * W + ow: 1 top row, 2 bottom row, 4 left column, 8 right column.  One table per
+    // workgroup instead of two divisions per pixel and K tile in every lane.
+    for (int i = tid; i < howo; i += NT) {
+      const uint32_t oh = fastdiv((uint32_t)i, p.d_wo), ow = (uint32_t)i - oh * p.d_wo.div;
+      sCode[i] = (unsigned char)((oh == 0 ? 1u : 0u) | (oh == (uint32_t)p.ho - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)p.wo - 1 ? 8u : 0u));
+    }
+  }
 
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const unsigned long long g_ptr = (unsigned long long)p.gy, x_ptr = (unsigned long long)p.x;
@@ -506,17 +523,76 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
 
-  // PIPE: the border masks of the wave's NSUBW sub-steps live across K tiles — those of tile k + 1 are computed inside tile k's
-  // stages (under its MFMAs), not in front of its first fragment read (~30 VALU instructions with two divisions per pixel pair)
+  // ---- PIPE path: everything a fragment read needs is a per-lane constant of the workgroup, computed here once ----
+  // The K loop of round 2 issued ~4.8 vector instructions per MFMA (SQ_INSTS_VALU / SQ_INSTS_MFMA = 6 over the whole kernel): LDS
+  // addresses rebuilt for every read, two divisions per pixel for the border test, selects — at 4 issue cycles each beside 8 per
+  // MFMA that is 1300 issue cycles per wave and K tile for 768 cycles of matrix work, with two waves per SIMD: the loop was bound
+  // by VALU issue, not by LDS, the L2 -> LDS fill or the atomics (profiles/r03d_pmc_mfma.json; the experiments that moved those
+  // three are in experiments/README.md).  Now: xo[i][ks][j] = LDS offset (inside a window buffer) of the x fragment of the wave's
+  // sub-step i, tap ks, channel fragment j; go[f] = offset of gy fragment f inside a sub-step's 32 gy rows; the buffer index is a
+  // compile-time constant (the K loop is unrolled by two), so buffer / sub-step / high-half offsets are ds_read immediates; a
+  // border lane's read pair is redirected by ONE select pair to the zero block at its own bank position (off & 255).
   const int sub0 = WSPLIT ? (wave >> 1) * 2 : 0;  // first sub-step of this wave
-  uint32_t zm[NSUBW][3];
+  uint32_t xo[NSUBW][3][NFB], go[NFA];
+  uint32_t rem[NSUBW][2];  // position inside its image (oh * W + ow) of the wave's pixels (sub-step i, half hh) of the CURRENT K tile
+  bool zb[NSUBW][3][2];    // zb[i][ks][hh]: tap ks of kernel row kr leaves the image for that pixel (lane masks in scalar registers)
+  const uint32_t lds_smem = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t z_base = lds_smem + (uint32_t)(sZ - smem);
+  const uint32_t vmask = kr == 0 ? 1u : (kr == 2 ? 2u : 0u);  // border code bits that put the whole kernel row outside
+  const uint32_t kp_mod = (uint32_t)(KP % howo);
+  auto masks_from_rem = [&](int i) {
+    uint32_t c[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) c[hh] = sCode[rem[i][hh]];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      zb[i][0][hh] = (c[hh] & (vmask | 4u)) != 0u;  // kernel row outside, or left column with tap 0
+      zb[i][1][hh] = (c[hh] & vmask) != 0u;
+      zb[i][2][hh] = (c[hh] & (vmask | 8u)) != 0u;  // ... or right column with tap 2
+    }
+  };
+  auto advance_rem = [&](int i) {  // the same pixels of the next K tile: KP positions further on, modulo the image
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      uint32_t r = rem[i][hh] + kp_mod;
+      r -= r >= (uint32_t)howo ? (uint32_t)howo : 0u;
+      rem[i][hh] = r;
+    }
+  };
   if constexpr (PIPE) {
 #pragma unroll
-    for (int i = 0; i < NSUBW; ++i) border(kbeg, sub0 + i, zm[i]);
+    for (int f = 0; f < NFA; ++f) {
+      const int cb = wr * (BCO / 2) + f * 16;
+      go[f] = lds_smem + (uint32_t)((sub0 * 32 + row) * RBG + ((((cb >> 3) + (pp >> 1)) ^ szA) << 4) + sub8);
+    }
+#pragma unroll
+    for (int i = 0; i < NSUBW; ++i) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int jr = (sub0 + i) * 32 + row + ks;
+        const int szX = wg_swz<T, BCI>(jr);
+#pragma unroll
+        for (int j = 0; j < NFB; ++j) {
+          const int cb = wc * (16 * NFB) + j * 16;
+          xo[i][ks][j] = lds_smem + (uint32_t)(2 * KP * RBG + jr * RBX + ((((cb >> 3) + (pp >> 1)) ^ szX) << 4) + sub8);
+        }
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const uint32_t pm = (uint32_t)(kbeg + (sub0 + i) * 32 + row + 16 * hh);
+        rem[i][hh] = pm - fastdiv(pm, p.d_howo) * p.d_howo.div;
+      }
+    }
+    __syncthreads();  // the code table is complete
+#pragma unroll
+    for (int i = 0; i < NSUBW; ++i) masks_from_rem(i);
   }
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  auto lds_tr = [](uint32_t addr, int imm) -> s16x4 {  // ds_read_b64_tr_b16 addr offset:imm
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr) + imm / 8);
+  };
 
-  auto compute = [&](int buf, int kb) {
-    const unsigned char* xw = sX + buf * (WR * RBX);
+  auto compute_pipe = [&](int buf) {
     if constexpr (PIPE) {
       // Software pipeline over the wave's NSUBW sub-steps: NSUBW x (3 taps x NFB channel fragments) stages of NFA MFMAs (one x
       // fragment against the NFA gy fragments).  The x fragment of stage s + 2 is read while stage s computes (three register
@@ -525,14 +601,25 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
       constexpr int SPS = 3 * NFB;           // stages per sub-step
       constexpr int NST = NSUBW * SPS;
       static_assert(NFB == 2 && NFA == 4 && SPS >= 2 + NFA, "stage layout: the next sub-step's four gy fragments load in stages 2..5");
-      const unsigned char* ga = sA + buf * (KP * RBG) + sub0 * (32 * RBG);
+      // (wave-uniform buffer offsets: one v_add with a scalar operand per address; sub-step and high-half offsets are immediates)
+      const uint32_t xbuf = (uint32_t)__builtin_amdgcn_readfirstlane(buf * (WR * RBX)), gbuf = (uint32_t)__builtin_amdgcn_readfirstlane(buf * (KP * RBG));
       s16x8 af[2][NFA], bj[3];
-#pragma unroll
-      for (int f = 0; f < NFA; ++f) af[0][f] = load_g(ga, wr * (BCO / 2) + f * 16);
+      auto read_g = [&](int sbi, int f) -> s16x8 {
+        const uint32_t a = go[f] + gbuf;
+        const s16x4 lo = lds_tr(a, sbi * (32 * RBG)), hi = lds_tr(a, sbi * (32 * RBG) + 16 * RBG);
+        return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      };
       auto stage_x = [&](int st) -> s16x8 {  // st = sub-step * SPS + ks * NFB + j
         const int sb = st / SPS, ks = (st % SPS) / NFB, j = st % NFB;
-        return load_x(xw, sub0 + sb, ks, wc * (16 * NFB) + j * 16, zm[sb][ks]);
+        const uint32_t off = xo[sb][ks][j];
+        const uint32_t xaddr = off + xbuf;
+        const uint32_t zaddr = z_base | ((off - lds_smem) & 255u);  // the lane's own bank position inside the zero block (z_base is a multiple of 256)
+        const uint32_t a0 = zb[sb][ks][0] ? zaddr : xaddr, a1 = zb[sb][ks][1] ? zaddr : xaddr;
+        const s16x4 lo = lds_tr(a0, 0), hi = lds_tr(a1, 16 * RBX);
+        return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       };
+#pragma unroll
+      for (int f = 0; f < NFA; ++f) af[0][f] = read_g(0, f);
       bj[0] = stage_x(0);
       bj[1] = stage_x(1);
 #pragma unroll
@@ -540,12 +627,10 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
         const int sb = st / SPS, ss = st % SPS, ks = ss / NFB, j = ss % NFB;
         if (st + 2 < NST) bj[(st + 2) % 3] = stage_x(st + 2);
         // the next sub-step's gy fragments, one per stage (its register set was last read by the previous sub-step's final stage)
-        if (sb + 1 < NSUBW && ss >= 2 && ss < 2 + NFA) af[(sb + 1) & 1][ss - 2] = load_g(ga + (sb + 1) * (32 * RBG), wr * (BCO / 2) + (ss - 2) * 16);
-        // the NEXT tile's border masks of sub-step sb: its current masks were last used by the read issued two stages ago
-        if (ss == 2) {
-          if (sb > 0) border(kb + KP, sub0 + sb - 1, zm[sb - 1]);
-        }
-        if (st == NST - 1) border(kb + KP, sub0 + NSUBW - 1, zm[NSUBW - 1]);
+        if (sb + 1 < NSUBW && ss >= 2 && ss < 2 + NFA) af[(sb + 1) & 1][ss - 2] = read_g(sb + 1, ss - 2);
+        // the NEXT tile's border masks of sub-step sb - 1: its current masks were last used by a read issued three stages ago
+        if (ss == 1 && sb > 0) advance_rem(sb - 1);
+        if (ss == 3 && sb > 0) masks_from_rem(sb - 1);
 #pragma unroll
         for (int f = 0; f < NFA; ++f)
           acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[sb & 1][f]), __builtin_bit_cast(bf16x8, bj[st % 3]), acc[ks][f][j], 0, 0, 0);
@@ -554,6 +639,16 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
         // lgkmcnt waits (it tracks the builtin reads) let each stage start as soon as ITS fragment has landed.
         __builtin_amdgcn_sched_barrier(0);
       }
+      advance_rem(NSUBW - 1);  // (after the last stage: the final sub-step's masks were in use until stage NST - 3)
+      masks_from_rem(NSUBW - 1);
+    }
+  };
+
+  auto compute = [&](int buf, int kb) {
+    const unsigned char* xw = sX + buf * (WR * RBX);
+    if constexpr (PIPE) {
+      (void)xw; (void)kb;
+      compute_pipe(buf);
     } else {
 #pragma unroll 1
       for (int sub = 0; sub < KSUB; ++sub) {
@@ -1047,7 +1142,7 @@ int launch_stem_wgrad(const WgradParams& p, hipStream_t stream) {
 template <int BCO, int BCI, int NW = 4>
 int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
   constexpr int KP = 32 * (((BCO == 64 && BCI == 64) || NW == 8) ? 4 : 2);
-  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * (KP + 8)) * BCI * 2 + 256;  // gy tiles, x windows, zero block
+  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * (KP + 8)) * BCI * 2 + kWgZeroBytes + kWgCodeBytes;  // gy tiles, x windows, zeros, border codes
   const size_t smem_epi = (BCO == 64 && BCI == 64) ? (size_t)2 * 64 * 64 * 4 : (size_t)BCO * BCI * 4;
   const size_t smem = smem_stage > smem_epi ? smem_stage : smem_epi;
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI, NW>), (size_t)smem);
@@ -1122,7 +1217,7 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
   // block per CU every block ends with 196 KB of f32 atomics (50 MB per launch against 25-28 MB) — off by default
   static const int use_win128 = [] { const char* e = getenv("VDQN_WGRAD_WIN128"); return e ? atoi(e) : 0; }();
   const bool win_geom = a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && a->pix_stride == a->ci && a->wo >= 2 &&
-                        a->hi == a->ho && a->wi == a->wo;
+                        a->hi == a->ho && a->wi == a->wo && a->ho * a->wo <= kWgCodeBytes;  // (border-code table of one image in LDS)
   if (use_win && use_win128 && use_win < 3 && win_geom && co_pad % 128 == 0 && a->ci % 128 == 0) {
     pl->variant = 4;
     pl->ci_tiles = a->ci / 128;
