@@ -580,7 +580,7 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_GROUPED_FWD": "1", "VDQN_GROUPED_LAUNCH": "0"},  # grouped forward, every layer through the internal two-launch fall-back
     {"VDQN_WIN9_MFMA32": "1"},        # nine-tap window kernel on 32x32x16 MFMAs (win9m.hip)
     {"VDQN_WIN9_MFMA32": "0"},        # ... on 16x16x32 MFMAs (win9.hip)
-    {"VDQN_WGRAD_WINDOW": "3"},       # 64x64 window weight-gradient tiles for every 3x3 / stride-1 layer (layer4 too)
+    {"VDQN_WGRAD_WINDOW": "1"},       # round 2's choice: 64x64 window weight-gradient tiles up to 256 channels, generic 128x128 tiles for layer4
     {"VDQN_WGRAD_WIN128": "1"},       # eight-wave 128x128 window weight-gradient tiles for the 128+ channel layers
     {"VDQN_WGRAD_TWO_STAGE": "1"},    # split-K partials as plain stores + ordered reduce kernels instead of f32 atomics
     {"VDQN_WGRAD_STREAMS": "2"},      # weight gradients alternate between the two side streams

@@ -32,6 +32,7 @@ struct WgradParams {
   // floats, plain stores), and wgrad_reduce_kernel sums the copies into dw in split order; nullptr = f32 atomics into dw
   float* ws;
   long long ws_stride;
+  void* stamps;  // -DVDQN_STAMP builds only (tools/stamp_wgrad.py): per-workgroup phase cycles of the window kernel's K loop
 };
 
 // partial-sum sink of a block: an atomic into dw, or a plain store into the block's split copy (uniform branch)
@@ -672,14 +673,30 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     }
   };
 
+#ifdef VDQN_STAMP
+  unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_comp = 0;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rt_begin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_t = st_begin;
+#define VDQN_WST(ACC) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ACC += n_ - st_t; st_t = n_; }
+#else
+#define VDQN_WST(ACC)
+#endif
   issue_tile(kbeg, 0);
+  VDQN_WST(st_issue)
   for (int k = 0; k < nk; ++k) {
     const int buf = k & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VDQN_WST(st_wait)
     __builtin_amdgcn_s_barrier();  // tile k landed for every wave; every wave is done with tile k-1
+    VDQN_WST(st_bar)
     if (k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
+    VDQN_WST(st_issue)
     compute(buf, kbeg + k * KP);
+    VDQN_WST(st_comp)
   }
+#ifdef VDQN_STAMP
+  const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- three tap tiles -> dw (f32 atomics, or plain stores into this split's copy; contiguous runs through LDS) ----
   const size_t row_len = (size_t)p.taps * p.ci;
@@ -722,6 +739,16 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
       }
     }
   }
+#ifdef VDQN_STAMP
+  if (p.stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 16;
+    o[0] = st_begin; o[1] = st_loop_end; o[2] = __builtin_amdgcn_s_memtime();
+    o[3] = st_wait; o[4] = st_bar; o[5] = st_issue; o[6] = st_comp; o[7] = (unsigned long long)nk;
+    o[8] = st_rt_begin; o[9] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+#undef VDQN_WST
 }
 
 // dbias[c] += sum_m gy[m][c]: 16-byte column groups x row stripes per block, stripes reduced through LDS,
@@ -1192,7 +1219,9 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
     if (splitk < 1) splitk = 1;
   }
   pl->variant = 3;
-  static const int use_win = [] { const char* e = getenv("VDQN_WGRAD_WINDOW"); return e ? atoi(e) : 1; }();
+  // (round 3: default 3 — with the K loop's vector instructions cut the 64 x 64 window tiles win on layer4 too: 0.91 + 0.13 against
+  // 0.70 + 0.40 ms per update for window + generic launches, profiles/r03f_ab_wgrad_valu_diet.txt)
+  static const int use_win = [] { const char* e = getenv("VDQN_WGRAD_WINDOW"); return e ? atoi(e) : 3; }();
   static const int use_stem = [] { const char* e = getenv("VDQN_WGRAD_STEM"); return e ? atoi(e) : 1; }();
   // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps.  64 x 64 window tiles win
   // on the 64-channel layers (672 vs 420 TFLOP/s) and on the 128- and 256-channel layers (layer2 / layer3: 705 vs 645) as
@@ -1277,6 +1306,10 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   // deterministic mode: the caller's workspace takes one partial copy of dw per split, summed in split order afterwards
   p.ws = nullptr;
   p.ws_stride = pl.copy_elems;
+  p.stamps = nullptr;
+#ifdef VDQN_STAMP
+  { extern void* g_stamp_buffer; p.stamps = g_stamp_buffer; }
+#endif
   if (a->workspace) {
     VDQN_CHECK(a->workspace_bytes >= (int64_t)pl.copies * pl.copy_elems * 4, "vdqn_conv2d_wgrad: workspace of %lld bytes, %lld needed",
                (long long)a->workspace_bytes, (long long)pl.copies * pl.copy_elems * 4);
