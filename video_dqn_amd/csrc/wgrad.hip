@@ -456,20 +456,23 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   static_assert((NT / CPRG) % 8 == 0 && (NT / CPRX) % 8 == 0, "swizzle keys repeat over the pieces of one thread");
   const int x_shift = (kr - 1) * p.wo - 1;  // window row j = pixel kb + j + x_shift
 
-  auto issue_tile = [&](int kb, int buf) {
-#pragma unroll
-    for (int i = 0; i < NLG; ++i) {
+  // one LDS-DMA piece of the tile at pixel kb: pieces 0 .. NLG - 1 = gy rows, NLG .. NLG + NLX - 1 = window rows
+  auto issue_piece = [&](int kb, int buf, int i) {
+    if (i < NLG) {
       const uint32_t vg = g_lane + (uint32_t)(kb + (NT / CPRG) * i) * ldg_b;
       const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RBG) + i * (NT * 16));
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vg), "s"(la), "s"(rs_g) : "memory");
-    }
-#pragma unroll
-    for (int i = 0; i < NLX; ++i) {
-      if (i == NLX - 1 && wave_u >= X_TAIL_WAVES) break;
-      const uint32_t vx = x_lane + (uint32_t)(kb + x_shift + (NT / CPRX) * i) * pix_b;  // may wrap below zero: out of range, zero-filled
-      const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RBG + buf * (WR * RBX) + i * (NT * 16));
+    } else {
+      const int ix = i - NLG;
+      if (ix == NLX - 1 && wave_u >= X_TAIL_WAVES) return;
+      const uint32_t vx = x_lane + (uint32_t)(kb + x_shift + (NT / CPRX) * ix) * pix_b;  // may wrap below zero: out of range, zero-filled
+      const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RBG + buf * (WR * RBX) + ix * (NT * 16));
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vx), "s"(lx), "s"(rs_x) : "memory");
     }
+  };
+  auto issue_tile = [&](int kb, int buf) {
+#pragma unroll
+    for (int i = 0; i < NLG + NLX; ++i) issue_piece(kb, buf, i);
   };
 
   f32x4 acc[3][NFA][NFB];
@@ -593,7 +596,11 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr) + imm / 8);
   };
 
-  auto compute_pipe = [&](int buf) {
+  // kb_next >= 0: the LDS-DMA pieces of the NEXT tile (into the other buffer pair, free since this tile's barrier) are issued one
+  // per stage BEHIND the stage's MFMAs instead of all in front of the tile's first fragment read: a piece holds the wave at
+  // issue for ~65 cycles (the stamps of tools/stamp_wgrad.py: 560-675 cycles per tile for nine pieces, the matrix pipe getting
+  // nothing from this wave meanwhile) — behind four MFMAs that time is covered by their 64 cycles of execution.
+  auto compute_pipe = [&](int buf, int kb_next) {
     if constexpr (PIPE) {
       // Software pipeline over the wave's NSUBW sub-steps: NSUBW x (3 taps x NFB channel fragments) stages of NFA MFMAs (one x
       // fragment against the NFA gy fragments).  The x fragment of stage s + 2 is read while stage s computes (three register
@@ -639,17 +646,24 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
         // lgkmcnt(0) there.  With a scheduling fence per stage the reads stay two stages ahead and the compiler's own counted
         // lgkmcnt waits (it tracks the builtin reads) let each stage start as soon as ITS fragment has landed.
         __builtin_amdgcn_sched_barrier(0);
+#ifndef VDQN_WGRAD_NO_TRICKLE
+        if (st < NLG + NLX && kb_next >= 0) {
+          issue_piece(kb_next, buf ^ 1, st);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
+      static_assert(NLG + NLX <= NST, "one LDS-DMA piece per stage");
       advance_rem(NSUBW - 1);  // (after the last stage: the final sub-step's masks were in use until stage NST - 3)
       masks_from_rem(NSUBW - 1);
     }
   };
 
-  auto compute = [&](int buf, int kb) {
+  auto compute = [&](int buf, int kb, int kb_next) {
     const unsigned char* xw = sX + buf * (WR * RBX);
     if constexpr (PIPE) {
       (void)xw; (void)kb;
-      compute_pipe(buf);
+      compute_pipe(buf, kb_next);
     } else {
 #pragma unroll 1
       for (int sub = 0; sub < KSUB; ++sub) {
@@ -689,9 +703,14 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     VDQN_WST(st_wait)
     __builtin_amdgcn_s_barrier();  // tile k landed for every wave; every wave is done with tile k-1
     VDQN_WST(st_bar)
-    if (k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
+#ifdef VDQN_WGRAD_NO_TRICKLE
+    constexpr bool kTrickle = false;
+#else
+    constexpr bool kTrickle = PIPE;
+#endif
+    if (!kTrickle && k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
     VDQN_WST(st_issue)
-    compute(buf, kbeg + k * KP);
+    compute(buf, kbeg + k * KP, (kTrickle && k + 1 < nk) ? kbeg + (k + 1) * KP : -1);
     VDQN_WST(st_comp)
   }
 #ifdef VDQN_STAMP
