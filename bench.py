@@ -312,6 +312,20 @@ def main():
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                         "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"]}
 
+    # the shader clock this device holds under a full-rate bf16 MFMA stream on random operands (in-kernel s_memtime /
+    # s_memrealtime): what the 2.5 PFLOP/s nominal peak of `roofline.peak` shrinks to on this box
+    mfma_clock = None
+    if rank == 0 and not args.no_profile:
+        try:
+            import ctypes as C
+            raw = C.CDLL(_lib.LIB_PATH)
+            ghz, tf = C.c_double(0.0), C.c_double(0.0)
+            if raw.vdqn_debug_mfma_clock(C.byref(ghz), C.byref(tf)) == 0:
+                mfma_clock = {"shader_clock_ghz": round(ghz.value, 3), "bare_mfma_tflops": round(tf.value, 1),
+                              "how": "~11 ms of back-to-back v_mfma_f32_32x32x16_bf16 on random bf16 operands after 45 ms of heat, one wave per SIMD; "
+                                     "clock = delta s_memtime / delta s_memrealtime x 100 MHz, median over waves"}
+        except Exception:
+            mfma_clock = None
     if rank == 0:
         tuples = B * world * args.steps
         value = tuples / elapsed
@@ -338,6 +352,7 @@ def main():
             "deterministic": bool(net.deterministic),
             "params_sha256": params_sha,
             "roofline": roofline,
+            "mfma_clock_under_load": mfma_clock,
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -128,3 +128,103 @@ extern "C" int vdqn_profile_collect(vdqn_prof_entry* out, int max_entries) {
   g_pool_next = 0;
   return n;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Diagnostic (not part of include/vdqn.h; bench.py reports it next to the roofline): the shader clock this device holds under a
+// full-rate bf16 MFMA stream on random operands, read in-kernel as delta s_memtime / delta s_memrealtime (x 100 MHz) —
+// tools/probes/clock_calib.hip shows that s_memtime counts shader cycles (1.017 ticks per MFMA cycle) and that the
+// GRBM_GUI_ACTIVE quotient of short dispatches reads high.  One workgroup of 256 threads per CU, operands in registers,
+// ~10 ms of back-to-back v_mfma_f32_32x32x16_bf16 after ~40 ms of the same as heat.  Allocates and frees 3 MB of device memory.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+typedef __attribute__((ext_vector_type(16))) float clk_f32x16;
+__global__ __launch_bounds__(256, 1) void mfma_clock_kernel(const uint32_t* __restrict__ data, unsigned long long* __restrict__ stamps, float* sink,
+                                                            int iters) {
+  const int tid = threadIdx.x;
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(data)[(blockIdx.x * 256 + tid) * 8 + i]);
+    b[i] = __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(data)[(blockIdx.x * 256 + tid) * 8 + 4 + i]);
+  }
+  clk_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a[i]), "+v"(b[i]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int k = 0; k < iters; ++k) {
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i + 2 * (rep & 1)], b[j + 2 * (rep >> 1)], acc[i][j], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][15];
+  asm volatile("" : "+v"(s));
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if ((tid & 63) == 0) {
+    unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 2;
+    o[0] = t1 - t0;
+    o[1] = r1 - r0;
+  }
+  if (s == 1.2345e33f) sink[blockIdx.x * 256 + tid] = s;
+}
+}  // namespace
+
+extern "C" int vdqn_debug_mfma_clock(double* ghz_out, double* tflops_out) {
+  const int blocks = vdqn_num_cus();
+  const size_t words = (size_t)blocks * 256 * 8 * 4;
+  uint32_t* d_data = nullptr;
+  unsigned long long* d_st = nullptr;
+  float* d_sink = nullptr;
+  if (hipMalloc(&d_data, words * 4) != hipSuccess || hipMalloc(&d_st, (size_t)blocks * 8 * 8) != hipSuccess || hipMalloc(&d_sink, (size_t)blocks * 256 * 4) != hipSuccess) {
+    vdqn_set_error("vdqn_debug_mfma_clock: hipMalloc failed");
+    return VDQN_ERR_LAUNCH;
+  }
+  std::vector<uint32_t> h(words);
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+  for (size_t i = 0; i < words; ++i) {  // two bf16 in [-1, 1) per word: random sign and mantissa, exponent 0x3f0 - {0..3}
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    const uint32_t lo = (uint32_t)(x & 0x807f) | (0x3f00 - (((uint32_t)(x >> 20) & 3) << 7));
+    const uint32_t hi = (uint32_t)((x >> 32) & 0x807f) | (0x3f00 - (((uint32_t)(x >> 52) & 3) << 7));
+    h[i] = lo | (hi << 16);
+  }
+  (void)hipMemcpy(d_data, h.data(), words * 4, hipMemcpyHostToDevice);
+  const int iters = 40000;  // 40000 x 512 cycles = ~11 ms at 1.8 GHz
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(mfma_clock_kernel, dim3(blocks), dim3(256), 0, nullptr, d_data, d_st, d_sink, iters);
+  (void)hipEventRecord(e0, nullptr);
+  hipLaunchKernelGGL(mfma_clock_kernel, dim3(blocks), dim3(256), 0, nullptr, d_data, d_st, d_sink, iters);
+  (void)hipEventRecord(e1, nullptr);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> st((size_t)blocks * 8);
+  (void)hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> ghz;
+  for (int w = 0; w < blocks * 4; ++w)
+    if (st[2 * w + 1] > 0) ghz.push_back((double)st[2 * w] / (double)st[2 * w + 1] * 0.1);
+  std::sort(ghz.begin(), ghz.end());
+  if (ghz_out) *ghz_out = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
+  if (tflops_out) *tflops_out = ms > 0.f ? (double)blocks * 4 * iters * 16 * (2.0 * 32 * 32 * 16) / ms / 1e9 : 0.0;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d_data);
+  (void)hipFree(d_st);
+  (void)hipFree(d_sink);
+  return VDQN_OK;
+}

@@ -596,10 +596,11 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr) + imm / 8);
   };
 
-  // kb_next >= 0: the LDS-DMA pieces of the NEXT tile (into the other buffer pair, free since this tile's barrier) are issued one
-  // per stage BEHIND the stage's MFMAs instead of all in front of the tile's first fragment read: a piece holds the wave at
-  // issue for ~65 cycles (the stamps of tools/stamp_wgrad.py: 560-675 cycles per tile for nine pieces, the matrix pipe getting
-  // nothing from this wave meanwhile) — behind four MFMAs that time is covered by their 64 cycles of execution.
+  // kb_next >= 0 (-DVDQN_WGRAD_TRICKLE builds only): the LDS-DMA pieces of the NEXT tile (into the other buffer pair, free since
+  // this tile's barrier) are issued one per stage BEHIND the stage's MFMAs instead of all in front of the tile's first fragment
+  // read: a piece holds the wave at issue for ~65 cycles (tools/stamp_wgrad.py: 560-675 cycles per tile for nine pieces).
+  // Measured: 1.00 against 0.93 ms per update for the window weight gradients — the pieces stall the MFMA stream more than
+  // they stall in front of it.  Not the default.
   auto compute_pipe = [&](int buf, int kb_next) {
     if constexpr (PIPE) {
       // Software pipeline over the wave's NSUBW sub-steps: NSUBW x (3 taps x NFB channel fragments) stages of NFA MFMAs (one x
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
         // lgkmcnt(0) there.  With a scheduling fence per stage the reads stay two stages ahead and the compiler's own counted
         // lgkmcnt waits (it tracks the builtin reads) let each stage start as soon as ITS fragment has landed.
         __builtin_amdgcn_sched_barrier(0);
-#ifndef VDQN_WGRAD_NO_TRICKLE
+#ifdef VDQN_WGRAD_TRICKLE
         if (st < NLG + NLX && kb_next >= 0) {
           issue_piece(kb_next, buf ^ 1, st);
           __builtin_amdgcn_sched_barrier(0);
@@ -703,10 +704,10 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     VDQN_WST(st_wait)
     __builtin_amdgcn_s_barrier();  // tile k landed for every wave; every wave is done with tile k-1
     VDQN_WST(st_bar)
-#ifdef VDQN_WGRAD_NO_TRICKLE
-    constexpr bool kTrickle = false;
-#else
+#ifdef VDQN_WGRAD_TRICKLE  // (build flag: measured 8 % slower per kernel, profiles/r03h_ab_wgrad_trickle.txt — off)
     constexpr bool kTrickle = PIPE;
+#else
+    constexpr bool kTrickle = false;
 #endif
     if (!kTrickle && k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
     VDQN_WST(st_issue)
