@@ -584,6 +584,7 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_WGRAD_WIN128": "1"},       # eight-wave 128x128 window weight-gradient tiles for the 128+ channel layers
     {"VDQN_WGRAD_TWO_STAGE": "1"},    # split-K partials as plain stores + ordered reduce kernels instead of f32 atomics
     {"VDQN_WGRAD_STREAMS": "2"},      # weight gradients alternate between the two side streams
+    {"VDQN_S2WIN": "0"},              # stride-2 3x3 forward convolutions on the generic kernel (no plane-window kernel)
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_non_default_kernel_selections(env):
     """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and

@@ -523,6 +523,28 @@ def test_nine_tap_window_kernel_persistent_tiles(n, co):
     assert relerr(got0.cpu().permute(0, 3, 1, 2), F.grad.conv2d_input((n, ci, h, h), w, gy, 1, 1)) < TOL_F32OUT[dtype]
 
 
+@pytest.mark.parametrize("case", [(3, 64, 128, 56), (2, 128, 256, 28), (2, 256, 512, 14), (5, 192, 128, 10), (1, 64, 128, 4), (7, 128, 128, 6), (9, 320, 256, 12)])
+def test_stride2_plane_window_kernel(case):
+    """3x3 / stride 2 / pad 1 forward over an even-sized input in bf16 runs win9s_kernel: one staged window per parity plane of the
+    input serves all taps of that plane.  One channel chunk (the 9-step block alone), two and four (the 18-step loop), three and five
+    (loop + block), images smaller than a tile, M not a multiple of the tile, the widest supported rows; bias + ReLU in bf16 and the
+    plain f32 result against torch on the same bf16 operands, and bit-equality with the generic kernel's K order is NOT claimed
+    (other K order: planes, not taps) — the f32 output is gated at the summation-order tolerance instead."""
+    from video_dqn_amd import ops
+    n, ci, co, h = case
+    dtype = torch.bfloat16
+    ho = h // 2
+    x = q(rnd(41, "x", (n, ci, h, h)), dtype)
+    w = q(rnd(42, "w", (co, ci, 3, 3), -0.1, 0.1), dtype)
+    b = rnd(43, "b", (co,))
+    ref = F.relu(F.conv2d(x, w, b, 2, 1))
+    out = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=ho, wo=ho, co=co, r=3, s=3, stride=2, pad=1, bias=b.to(DEV), relu=True)
+    _, out32 = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), ho=ho, wo=ho, co=co, r=3, s=3, stride=2, pad=1, want_f32=True)
+    torch.cuda.synchronize()
+    assert relerr(out.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    assert relerr(out32.cpu().permute(0, 3, 1, 2), F.conv2d(x, w, None, 2, 1)) < TOL_F32OUT[dtype]
+
+
 @pytest.mark.parametrize("geom", [(3, 10, 6), (2, 5, 17), (5, 28, 28)])
 def test_nine_tap_window_kernel_nonsquare(geom):
     """bf16 3x3 convs with 128-column tiles run igemm_win9 (one staged window per channel chunk for all nine taps): non-square

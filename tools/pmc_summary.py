@@ -26,7 +26,10 @@ def tag_of(kernel_name: str):
             return f"stem_conv_pool<{dt}>"
         size = "256x64" if bm == 256 else str(bn)
         return f"igemm<{dt},{size},{('fwd', 'dgrad', 'dgrad_s2')[mode]}>"
-    m = re.search(r"win9u_kernel<(\d+)(?:, \d+)?>", kernel_name)
+    m = re.search(r"win9s_kernel", kernel_name)
+    if m:  # plane-window kernel of the stride-2 3x3 forward convolutions
+        return "igemm_s2win<bf16,128,fwd>"
+    m = re.search(r"win9[um]_kernel<(\d+)(?:, \d+)?>", kernel_name)
     if m:  # the unrolled nine-tap kernel (bf16 only), same tag
         return f"igemm_win<bf16,128,{('fwd', 'dgrad')[int(m[1])]}>"
     m = re.search(r"igemm_win9_kernel<(unsigned short|float), (\d+)>", kernel_name)
@@ -35,6 +38,9 @@ def tag_of(kernel_name: str):
     m = re.search(r"igemm_win_kernel<(unsigned short|float), (\d+), (\d+)>", kernel_name)
     if m:
         return f"igemm_win<{'bf16' if m[1] == 'unsigned short' else 'f32'},{m[2]},{('fwd', 'dgrad')[int(m[3])]}>"
+    m = re.search(r"wgrad_win_kernel<(\d+), (\d+), (\d+)>", kernel_name)
+    if m:
+        return "wgrad_win<bf16,128>" if m[3] == "8" else ("wgrad_win<bf16,128x64>" if m[1] == "128" else "wgrad_win<bf16,64>")
     m = re.search(r"wgrad_win_kernel<(\d+)(?:, \d+)?>", kernel_name)
     if m:
         return f"wgrad_win<bf16,{m[1]}>"
