@@ -141,7 +141,11 @@ def test_conv_fused_downsample_forward(case, dtype):
     sep1 = ops.conv2d(xd, krsc(w1, dtype), **kw)
     sep2 = ops.conv2d(xd, krsc(w2, dtype), ho=ho, wo=ho, co=co, r=1, s=1, stride=2, pad=0, bias=b2.to(DEV), relu=False)
     torch.cuda.synchronize()
-    assert torch.equal(out, sep1) and torch.equal(out2, sep2)
+    # the sibling's output: same tiles, same K order as its own launch -> bit-identical.  The 3x3's: bit-identical to the generic
+    # kernel's launch; the default separate launch of an even-sized bf16 input runs the plane-window kernel (win9s.hip), whose K
+    # order is by parity plane — equal up to the rounding of a different summation order there
+    assert torch.equal(out2, sep2)
+    assert torch.equal(out, sep1) or (dtype == torch.bfloat16 and h % 2 == 0 and relerr(out, sep1) < 1e-2)
     assert relerr(out.float().cpu().permute(0, 3, 1, 2), F.relu(F.conv2d(x, w1, b1, 2, 1))) < TOL[dtype]
     assert relerr(out2.float().cpu().permute(0, 3, 1, 2), F.conv2d(x, w2, b2, 2, 0)) < TOL[dtype]
 

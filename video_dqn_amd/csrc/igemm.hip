@@ -1544,10 +1544,12 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
   // 3x3 / stride 2 / pad 1 forward over an even-sized input (conv1 of layer2.0 / layer3.0 / layer4.0), bf16, 128-column tiles: the
   // plane-window kernel (win9s.hip; VDQN_S2WIN=0 keeps the generic kernel).  No grouped form, no fused sibling.
   static const int use_s2win = [] { const char* e = getenv("VDQN_S2WIN"); return e ? atoi(e) : 1; }();
-  if (use_s2win && mode == 0 && group_rows <= 0 && !has_sib && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 2 && a->pad == 1 &&
+  if (use_s2win && mode == 0 && !has_sib && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 2 && a->pad == 1 &&
       bn == 128 && a->co % 128 == 0 && a->hi == 2 * a->ho && a->wi == 2 * a->wo && a->wo >= 2 && a->wo <= 28 && a->pix_stride == a->ci && a->ci % 64 == 0 &&
-      p.in_bytes < 0x7fffffffLL && !a->colsum_part && !a->mask)
+      p.in_bytes < 0x7fffffffLL && !a->colsum_part && !a->mask) {
+    if (group_rows > 0) return VDQN_OK;  // no grouped form: the caller runs the two row ranges as two launches of THIS kernel (same bits as two passes)
     return vdqn_launch_win9s(&p, st);
+  }
   static const long long min256 = [] { const char* e = getenv("VDQN_BM256_MIN_ROWS"); return e ? atoll(e) : 256ll * 1024; }();
   if (bn == 64 && mode != 2 && p.M >= min256 && !has_sib) {
     if (!grp(256)) return VDQN_OK;

@@ -35,8 +35,6 @@ struct WgradParams {
   void* stamps;  // -DVDQN_STAMP builds only (tools/stamp_wgrad.py): per-workgroup phase cycles of the window kernel's K loop
 };
 
-constexpr int kWgTabEntries = 3200;  // wgrad_kernel: tap-offset table in LDS, images up to 56 x 56
-
 // partial-sum sink of a block: an atomic into dw, or a plain store into the block's split copy (uniform branch)
 __device__ __forceinline__ void wg_emit(float* dst, bool det, float v) {
   if (det) *dst = v;
@@ -73,11 +71,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;                 // [2][KP*RB]
   unsigned char* sB = smem + 2 * KP * RB;   // [2][KP*RB]
-  // [kWgTabEntries] u32 (images up to 56 x 56): byte offset, inside its image, of the x pixel THIS block's tap (kr, ks) reads for
-  // output position rem = oh * Wo + ow, or kOobW where the tap leaves the image — built once per block, so that a K-step's
-  // staging addresses are a table read + adds instead of two divisions and two multiplications per DMA piece (the generic loop
-  // issued 5.6-11 vector instructions per MFMA, profiles/r03d_pmc_mfma.json)
-  uint32_t* sTab = reinterpret_cast<uint32_t*>(smem + 4 * KP * RB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, XCD-aware: the blocks of one pixel range (all taps / channel tiles of one split) get consecutive
@@ -124,51 +117,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const uint32_t lds_wave = lds_base + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
   const uint32_t ldg_b = (uint32_t)p.ldg * (uint32_t)sizeof(T);
   const uint32_t pix_b = (uint32_t)p.pix_stride * (uint32_t)sizeof(T);
-  const uint32_t howo_u = p.d_howo.div;
-  const bool use_tab = howo_u <= (uint32_t)kWgTabEntries;  // (uniform; larger images keep the per-piece arithmetic)
-  const uint32_t img_b = (uint32_t)p.hi * (uint32_t)p.wi * pix_b;  // bytes of one input image (operands are < 2 GiB)
-  uint32_t t_rem[NL], t_img[NL];  // position inside its image / image byte offset of the thread's rows in the NEXT tile to stage
-  const uint32_t kp_img = (uint32_t)KP / howo_u, kp_rem = (uint32_t)KP - kp_img * howo_u;
-  if (use_tab) {
-    for (uint32_t e = (uint32_t)tid; e < howo_u; e += 256u) {
-      const uint32_t oh = fastdiv(e, p.d_wo), ow = e - oh * p.d_wo.div;
-      const int h = (int)oh * p.stride - p.pad + kr, w = (int)ow * p.stride - p.pad + ks;
-      sTab[e] = ((unsigned)h < (unsigned)p.hi && (unsigned)w < (unsigned)p.wi) ? ((uint32_t)h * (uint32_t)p.wi + (uint32_t)w) * pix_b : kOobW;
-    }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const uint32_t pm = (uint32_t)(kbeg + l_row[i]);
-      const uint32_t img = fastdiv(pm, p.d_howo);
-      t_rem[i] = pm - img * howo_u;
-      t_img[i] = img * img_b;
-    }
-    __syncthreads();
-  }
 
   auto issue_tile = [&](int kb, int buf) {
-    if (use_tab) {  // tiles are staged in order kbeg, kbeg + KP, ...: the per-row state just advances
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const int pm = kb + l_row[i];
-        const bool ok = pm < kend;
-        const uint32_t t = sTab[t_rem[i]];
-        const uint32_t vg = ok ? (uint32_t)pm * ldg_b + l_goff[i] : kOobW;
-        const uint32_t vx = (ok && t != kOobW) ? t_img[i] + t + l_xoff[i] : kOobW;
-        uint32_t r = t_rem[i] + kp_rem;
-        const bool wrap = r >= howo_u;
-        t_rem[i] = wrap ? r - howo_u : r;
-        t_img[i] += (kp_img + (wrap ? 1u : 0u)) * img_b;
-        const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RB) + i * 4096);
-        const uint32_t lb = la + (uint32_t)(2 * KP * RB);
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %4, 0 offen lds\n\t"
-            "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds"
-            ::"v"(vg), "v"(vx), "s"(la), "s"(lb), "s"(rs_g), "s"(rs_x)
-            : "memory");
-      }
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int pm = kb + l_row[i];
@@ -858,7 +808,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ gy, f
 
 template <typename T, int BT>
 int launch_wgrad(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
-  const size_t smem = 4 * 32 * wg_ksub<T, BT>() * BT * sizeof(T) + (size_t)kWgTabEntries * 4;  // two operands x two buffers, tap-offset table
+  const size_t smem = 4 * 32 * wg_ksub<T, BT>() * BT * sizeof(T);
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_kernel<T, BT>), (size_t)smem);
   const double esz = sizeof(T);
   vdqn_prof_begin(sizeof(T) == 2 ? (BT == 128 ? "wgrad<bf16,128>" : "wgrad<bf16,64>") : (BT == 128 ? "wgrad<f32,128>" : "wgrad<f32,64>"),
