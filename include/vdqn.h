@@ -186,9 +186,15 @@ int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, flo
  * weights [64][4][1][64] with BatchNorm folded, f32 bias[64]) + ReLU + MaxPool2d(3, 2, 1)
  * (torchvision resnet.py conv1/bn1/relu/maxpool; archs/HabitatDQNMultiAction.py:30).  Writes pool [n][56][56][64] and
  * the argmax codes idx (as vdqn_maxpool_fwd); the 112x112x64 convolution output is never stored.  Results are
- * bit-identical to vdqn_conv2d followed by vdqn_maxpool_fwd. */
+ * bit-identical to vdqn_conv2d followed by vdqn_maxpool_fwd.  idx may be NULL for frames that never see a backward pass
+ * (the torch.no_grad() target pass and the s' rows of the online pass, train_q_network.py:138-142): pool is the same,
+ * the arg-max bytes are not computed. */
 int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img,
                         int32_t dtype, void* stream);
+/* The same with arg-max bytes for the first n_idx_img images only (0 <= n_idx_img <= n_img; idx may be NULL when it is 0): one
+ * launch over [s; s'] of the online pass, where only the s rows see loss.backward() (train_q_network.py:131,142,226). */
+int vdqn_stem_conv_pool_n(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img,
+                          int32_t n_idx_img, int32_t dtype, void* stream);
 
 /* conv1's weight gradient straight from the POOLED gradient (the extra_capacity stem in bf16): what vdqn_maxpool_bwd(g_pool, idx)
  * followed by vdqn_conv2d_wgrad on the packed stem geometry computes, without the 112 x 112 x 64 gradient of conv1's output

@@ -585,6 +585,7 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_WGRAD_TWO_STAGE": "1"},    # split-K partials as plain stores + ordered reduce kernels instead of f32 atomics
     {"VDQN_WGRAD_STREAMS": "2"},      # weight gradients alternate between the two side streams
     {"VDQN_S2WIN": "0"},              # stride-2 3x3 forward convolutions on the generic kernel (no plane-window kernel)
+    {"VDQN_STEM_NOIDX": "0"},         # the stem writes the max-pool arg-max bytes of the no-grad frames too
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_non_default_kernel_selections(env):
     """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and

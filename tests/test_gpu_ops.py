@@ -293,6 +293,13 @@ def test_stem_pack_conv1_maxpool(dtype, src_kind):
     pool_f, idx_f = ops.stem_conv_pool(packed, s2d_weights(w7, dtype), b.to(DEV))
     torch.cuda.synchronize()
     assert torch.equal(pool_f, pool) and torch.equal(idx_f, idx)
+    # ... and without the arg-max bytes (frames under torch.no_grad(), train_q_network.py:138-142) the pooled values are the same
+    pool_n, idx_n = ops.stem_conv_pool(packed, s2d_weights(w7, dtype), b.to(DEV), want_idx=False)
+    torch.cuda.synchronize()
+    assert idx_n is None and torch.equal(pool_n, pool)
+    pool_p, idx_p = ops.stem_conv_pool(packed, s2d_weights(w7, dtype), b.to(DEV), n_idx=1)  # [s; s'] in one launch: arg-max for s only
+    torch.cuda.synchronize()
+    assert torch.equal(pool_p, pool) and torch.equal(idx_p[:1], idx[:1]) and int(idx_p[1:].max()) == 0
     # backward: gx = relu'(c1) * unpool(gy)
     gy = q(rnd(9, "gy", tuple(pref.shape)), dtype)
     pref.backward(gy)

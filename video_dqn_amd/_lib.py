@@ -85,6 +85,7 @@ _SIGS = {
     "vdqn_maxpool_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_maxpool_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_stem_conv_pool": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "vdqn_stem_conv_pool_n": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "vdqn_td_loss": (C.c_int, [C.POINTER(TdArgs), c_vp]),
     "vdqn_gt_loss": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
     "vdqn_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_vp]),

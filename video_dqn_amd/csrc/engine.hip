@@ -988,21 +988,27 @@ int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const voi
 // (the online network on [s; s'] and the target network on s' of one TD update as ONE chain of launches; t_in_b = packed frames of
 // the second range).  The stem runs once per range (its weights live in registers), every later layer is one vdqn_conv2d call.
 int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t_in, int n_samples, unsigned char* acts, const ActLayout& A,
-                 hipStream_t st, bool trunk_only = false, const unsigned char* packed_b = nullptr, int split_samples = 0, const void* t_in_b = nullptr) {
+                 hipStream_t st, bool trunk_only = false, const unsigned char* packed_b = nullptr, int split_samples = 0, const void* t_in_b = nullptr,
+                 int grad_samples = -1) {
   const int n = n_samples * net->cfg.num_frames;
   const int dt = net->cfg.dtype;
   const int n_a = packed_b ? split_samples * net->cfg.num_frames : n;  // frames of the first range
+  // grad_samples >= 0: only the first grad_samples samples will see a backward pass — the stem skips the arg-max bytes of the
+  // max-pool for the rest (the s' rows and the target pass of a TD update: 2/3 of its frames; VDQN_STEM_NOIDX=0 writes them all)
+  static const bool stem_noidx = [] { const char* e = getenv("VDQN_STEM_NOIDX"); return !(e && e[0] == '0'); }();
+  const int n_idx = (grad_samples >= 0 && stem_noidx) ? (grad_samples * net->cfg.num_frames < n_a ? grad_samples * net->cfg.num_frames : n_a) : n_a;
   if (A.c1 >= 0) {  // 'basic' eval path keeps the separate kernels (its train path needs the raw conv output anyway)
     RC(run_conv(net, net->layers[net->l_conv1], packed, t_in, acts + A.c1, n, nullptr, 1, nullptr, st));
     RC(vdqn_maxpool_fwd(acts + A.c1, acts + A.pool, acts + A.idx, n, 112, 112, 64, dt, st));
   } else {
     const Layer& L1 = net->layers[net->l_conv1];
+    const int64_t frame_pool = (int64_t)56 * 56 * 64;
     prof_layer(L1, n_a);
-    RC(vdqn_stem_conv_pool(t_in, packed + L1.wf_off, reinterpret_cast<const float*>(packed + L1.bias_off), acts + A.pool, acts + A.idx, n_a, dt, st));
+    RC(vdqn_stem_conv_pool_n(t_in, packed + L1.wf_off, reinterpret_cast<const float*>(packed + L1.bias_off), acts + A.pool, acts + A.idx, n_a, n_idx, dt, st));
     if (packed_b) {
       prof_layer(L1, n - n_a);
       RC(vdqn_stem_conv_pool(t_in_b, packed_b + L1.wf_off, reinterpret_cast<const float*>(packed_b + L1.bias_off),
-                             acts + A.pool + (int64_t)n_a * 56 * 56 * 64 * net->esz, acts + A.idx + (int64_t)n_a * 56 * 56 * 64, n - n_a, dt, st));
+                             acts + A.pool + n_a * frame_pool * net->esz, (grad_samples >= 0 && stem_noidx) ? nullptr : acts + A.idx + n_a * frame_pool, n - n_a, dt, st));
     }
   }
   const unsigned char* x = acts + A.pool;
@@ -1312,10 +1318,11 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     // [s; s'] with the online weights and s' with the target's, one chain of launches on the caller's stream (the side stream
     // carries nothing during the forward); the target range's stem reads the packed s' frames of the online range
     RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, 3 * B, ao, A, st, false, (const unsigned char*)a->packed_target, 2 * B,
-                    ao + A.t_in + (int64_t)B * F * frame_bytes));
+                    ao + A.t_in + (int64_t)B * F * frame_bytes, B));
   } else if (!gtb) {
     const ActLayout T = act_layout(net, B);
-    RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst));
+    RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst, false,
+                    nullptr, 0, nullptr, 0));
   }
   if (grouped) {
     // (done above)
@@ -1331,11 +1338,11 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     hipStream_t s2 = (split && !gtb) ? fork_side2(net, st) : st;
     if (s2 != st) {
       const ActLayout A2 = shift_layout(net, A, B);
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A2.t_in, B, ao, A2, s2));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A2.t_in, B, ao, A2, s2, false, nullptr, 0, nullptr, 0));
       RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, B, ao, A, st));
       join_side2(net, st);
     } else {
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st, false, nullptr, 0, nullptr, B));
     }
   }
   if (tst != st) join_side(net, st);

@@ -27,7 +27,7 @@
 
 #include "common.h"
 
-int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, hipStream_t st);  // stem.hip
+int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, int n_idx_img, hipStream_t st);  // stem.hip
 int vdqn_launch_win9s(const void* igemm_params, hipStream_t stream);                                                              // win9s.hip
 int vdqn_launch_win9m(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9m.hip
 int vdqn_launch_win9u(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9.hip
@@ -531,8 +531,10 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
 #pragma unroll
       for (int e = 0; e < E16; ++e) ov[e] = from_f32<T>(best[e]);
       *reinterpret_cast<uint4*>(pool + o) = *reinterpret_cast<const uint4*>(ov);
-      if constexpr (E16 == 8) *reinterpret_cast<uint2*>(p.pool_idx + o) = *reinterpret_cast<const uint2*>(bi);
-      else *reinterpret_cast<uint32_t*>(p.pool_idx + o) = *reinterpret_cast<const uint32_t*>(bi);
+      if (st_img < p.n_idx_img) {  // the other images: pooled values only (vdqn_stem_conv_pool_n)
+        if constexpr (E16 == 8) *reinterpret_cast<uint2*>(p.pool_idx + o) = *reinterpret_cast<const uint2*>(bi);
+        else *reinterpret_cast<uint32_t*>(p.pool_idx + o) = *reinterpret_cast<const uint32_t*>(bi);
+      }
     }
     return;
   }
@@ -1594,16 +1596,16 @@ extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
   return conv2d_impl(&hi, stream, 0, nullptr);
 }
 
-extern "C" int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img, int32_t dtype,
-                                   void* stream) {
-  VDQN_CHECK(t_in && wt && bias && pool && idx && n_img > 0, "vdqn_stem_conv_pool: bad args");
+extern "C" int vdqn_stem_conv_pool_n(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img, int32_t n_idx_img,
+                                     int32_t dtype, void* stream) {
+  VDQN_CHECK(t_in && wt && bias && pool && n_img > 0 && n_idx_img >= 0 && n_idx_img <= n_img && (idx || n_idx_img == 0), "vdqn_stem_conv_pool: bad args");
   VDQN_CHECK(dtype == VDQN_F32 || dtype == VDQN_BF16, "vdqn_stem_conv_pool: bad dtype %d", dtype);
   VDQN_CHECK((((uintptr_t)t_in | (uintptr_t)wt | (uintptr_t)pool | (uintptr_t)idx) & 15) == 0, "vdqn_stem_conv_pool: tensors must be 16-byte aligned");
   const int esz = dtype == VDQN_BF16 ? 2 : 4;
   VDQN_CHECK((long long)n_img * 64 < (1ll << 31) / 256, "vdqn_stem_conv_pool: too many images");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
-  p.in = t_in; p.wt = wt; p.bias = bias; p.pool_out = pool; p.pool_idx = (uint8_t*)idx;
+  p.in = t_in; p.wt = wt; p.bias = bias; p.pool_out = pool; p.pool_idx = (uint8_t*)idx; p.n_idx_img = n_idx_img;
   p.n_img = n_img; p.hi = 115; p.wi = 115; p.ci = 64; p.pix_stride = 16;  // one K-step = 4 packed pixels x 16 = one kernel row
   p.ho = 112; p.wo = 112; p.co = 64; p.ldo = 64; p.r = 4; p.s = 1; p.stride = 1; p.pad = 0; p.relu = 1;
   p.howo = 112 * 112;
@@ -1619,6 +1621,11 @@ extern "C" int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float
   // bf16: the persistent kernel of stem.hip (weights in registers, double-buffered windows; 0.62 vs 0.70 ms per step for the
   // one-tile-per-workgroup MODE 3 path below, which f32 uses and VDQN_STEM_PERSISTENT=0 selects)
   static const bool persistent = [] { const char* e = getenv("VDQN_STEM_PERSISTENT"); return !(e && e[0] == '0'); }();
-  if (dtype == VDQN_BF16 && persistent) return vdqn_stem_bf16(t_in, wt, bias, pool, idx, n_img, st);
+  if (dtype == VDQN_BF16 && persistent) return vdqn_stem_bf16(t_in, wt, bias, pool, idx, n_img, n_idx_img, st);
   return dtype == VDQN_BF16 ? launch_igemm<bf16raw, 256, 64, 3>(p, st) : launch_igemm<float, 256, 64, 3>(p, st);
+}
+
+extern "C" int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img, int32_t dtype,
+                                   void* stream) {
+  return vdqn_stem_conv_pool_n(t_in, wt, bias, pool, idx, n_img, idx ? n_img : 0, dtype, stream);
 }

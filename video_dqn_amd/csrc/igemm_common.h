@@ -21,6 +21,7 @@ struct IgemmParams {
   float* colsum_part;
   void* pool_out;      // MODE 3 (stem): max-pooled output [n][56][56][64] and its argmax codes
   uint8_t* pool_idx;
+  int n_idx_img;  // MODE 3: arg-max bytes for images [0, n_idx_img) only
   int n_img, hi, wi, ci, pix_stride, ho, wo, co, ldo, r, s, stride, pad, relu;
   int M, howo, ktot, nk, tiles_m, tiles_n;
   int cls_tile0[5], cls_h[2], cls_w[2];  // MODE 2: first tile of each output-parity class; class heights / widths

@@ -21,6 +21,7 @@ namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 struct StemParams {
   const bf16raw* t_in;   // [n][115][115][16]
@@ -29,6 +30,7 @@ struct StemParams {
   bf16raw* pool;         // [n][56][56][64]
   uint8_t* idx;          // [n][56][56][64]
   int n_img, n_tiles;
+  int n_idx_img;         // images [0, n_idx_img) get arg-max bytes
 };
 
 constexpr int kWRows = 320;                    // 19 * 16 = 304 window rows, rounded up to the 32-row staging pass
@@ -36,6 +38,8 @@ constexpr int kWBytes = kWRows * 128;          // one window buffer
 constexpr int kSmem = 2 * kWBytes;  // two windows = 80 KiB: two workgroups per CU (the weights live in registers)
 constexpr unsigned kOobS = 0x80000000u;
 
+// Images from p.n_idx_img on get no arg-max bytes (frames that never see a backward pass: the s' half of the online pass and the
+// whole target pass of a TD update): their pooling is a plain packed 16-bit maximum, a quarter of the vector instructions.
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sW = smem;                    // [2][320 rows][128 B]
@@ -169,6 +173,30 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     for (int item = tid; item < 49 * 8; item += 256) {
       const int pp = item >> 3, cg = item & 7;
       const int pi = pp / 7, pj = pp - pi * 7;
+      const size_t o = (((size_t)img * 56 + 7 * ty + pi) * 56 + 7 * tx + pj) * 64 + cg * 8;
+      if (img >= p.n_idx_img) {  // (uniform over the workgroup)
+        // no arg-max: post-ReLU bf16 bit patterns order like SIGNED 16-bit integers, and the -0.0 the ReLU may leave (0x8000, the
+        // smallest of them) loses against the initial +0.0 exactly as the arg-max path's sign mask drops it
+        const bool r0 = ty == 0 && pi == 0, c0 = tx == 0 && pj == 0;
+        i16x2 m[4] = {i16x2{0, 0}, i16x2{0, 0}, i16x2{0, 0}, i16x2{0, 0}};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const bool out = (kh == 0 && r0) || (kw == 0 && c0);  // such a tap re-reads the centre tap instead (always inside)
+            const int r = out ? (2 * pi + 1) * 16 + 2 * pj + 1 : (2 * pi + kh) * 16 + 2 * pj + kw;
+            const uint4 v = *reinterpret_cast<const uint4*>(sT + (size_t)r * 64 + ((cg ^ (r & 7)) * 8));
+            m[0] = __builtin_elementwise_max(m[0], __builtin_bit_cast(i16x2, v.x));
+            m[1] = __builtin_elementwise_max(m[1], __builtin_bit_cast(i16x2, v.y));
+            m[2] = __builtin_elementwise_max(m[2], __builtin_bit_cast(i16x2, v.z));
+            m[3] = __builtin_elementwise_max(m[3], __builtin_bit_cast(i16x2, v.w));
+          }
+        uint4 ov;
+        ov.x = __builtin_bit_cast(uint32_t, m[0]); ov.y = __builtin_bit_cast(uint32_t, m[1]);
+        ov.z = __builtin_bit_cast(uint32_t, m[2]); ov.w = __builtin_bit_cast(uint32_t, m[3]);
+        *reinterpret_cast<uint4*>(p.pool + o) = ov;
+        continue;
+      }
       // Straight-line: all nine taps are read up front (one exposed LDS latency per item instead of nine).  Only the taps of
       // conv row / column -1 can be outside the image (first tile row / column, first pooled row / column): they are read too
       // (the patch row exists) and masked out of the maximum.  The centre tap is always valid, so every key ends up tagged.
@@ -207,7 +235,6 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
       ov.w = (key[6] >> 4) | ((key[7] << 12) & 0xffff0000u);
       bi.x = (8u - (key[0] & 15u)) | ((8u - (key[1] & 15u)) << 8) | ((8u - (key[2] & 15u)) << 16) | ((8u - (key[3] & 15u)) << 24);
       bi.y = (8u - (key[4] & 15u)) | ((8u - (key[5] & 15u)) << 8) | ((8u - (key[6] & 15u)) << 16) | ((8u - (key[7] & 15u)) << 24);
-      const size_t o = (((size_t)img * 56 + 7 * ty + pi) * 56 + 7 * tx + pj) * 64 + cg * 8;
       *reinterpret_cast<uint4*>(p.pool + o) = ov;
       *reinterpret_cast<uint2*>(p.idx + o) = bi;
     }
@@ -216,17 +243,19 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 
 }  // namespace
 
-// bf16 entry used by vdqn_stem_conv_pool (igemm.hip); returns VDQN_OK or an error code
-int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, hipStream_t st) {
+// bf16 entry used by vdqn_stem_conv_pool / vdqn_stem_conv_pool_n (igemm.hip); arg-max bytes for the first n_idx_img images only
+// (idx == nullptr: none); returns VDQN_OK or an error code
+int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, int n_idx_img, hipStream_t st) {
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&stem_kernel), (size_t)kSmem);
   const int n_cu = vdqn_num_cus();
   StemParams p;
   p.t_in = (const bf16raw*)t_in; p.wt = (const bf16raw*)wt; p.bias = bias; p.pool = (bf16raw*)pool; p.idx = (uint8_t*)idx;
   p.n_img = n_img;
+  p.n_idx_img = idx ? n_idx_img : 0;
   p.n_tiles = n_img * 64;
   const int grid = p.n_tiles < 2 * n_cu ? p.n_tiles : 2 * n_cu;
   vdqn_prof_begin("stem_conv_pool<bf16>", 2.0 * n_img * 112 * 112 * 64 * 147,
-                  2.0 * ((double)n_img * 115 * 115 * 16 + 64.0 * 256 + (double)n_img * 56 * 56 * 64) + (double)n_img * 56 * 56 * 64, st);
+                  2.0 * ((double)n_img * 115 * 115 * 16 + 64.0 * 256 + (double)n_img * 56 * 56 * 64) + (double)p.n_idx_img * 56 * 56 * 64, st);
   hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), kSmem, st, p);
   vdqn_prof_end(st);
   VDQN_LAUNCH_CHECK();

@@ -243,12 +243,20 @@ def avgpool_bwd(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return gx
 
 
-def stem_conv_pool(t_in: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor):
-    """t_in [n,115,115,16] (pack_input), wt [64,4,1,64], bias f32 [64] -> (pool [n,56,56,64], idx uint8)."""
+def stem_conv_pool(t_in: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor, want_idx: bool = True, n_idx: int = None):
+    """t_in [n,115,115,16] (pack_input), wt [64,4,1,64], bias f32 [64] -> (pool [n,56,56,64], idx uint8).
+
+    want_idx=False: frames that never see a backward pass — idx is None and the arg-max bytes are not computed.
+    n_idx: arg-max bytes for the first n_idx images only (vdqn_stem_conv_pool_n); the other rows of idx stay as allocated."""
     lib = _lib.load()
     n = t_in.shape[0]
     pool = torch.empty((n, 56, 56, 64), dtype=t_in.dtype, device=t_in.device)
-    idx = torch.empty((n, 56, 56, 64), dtype=torch.uint8, device=t_in.device)
-    _lib.check(lib.vdqn_stem_conv_pool(_ptr(t_in), _ptr(wt), _ptr(bias), _ptr(pool), _ptr(idx), n, dtype_code(t_in), _stream()),
+    if n_idx is not None:
+        idx = torch.zeros((n, 56, 56, 64), dtype=torch.uint8, device=t_in.device)
+        _lib.check(lib.vdqn_stem_conv_pool_n(_ptr(t_in), _ptr(wt), _ptr(bias), _ptr(pool), _ptr(idx), n, int(n_idx), dtype_code(t_in), _stream()),
+                   "vdqn_stem_conv_pool_n")
+        return pool, idx
+    idx = torch.empty((n, 56, 56, 64), dtype=torch.uint8, device=t_in.device) if want_idx else None
+    _lib.check(lib.vdqn_stem_conv_pool(_ptr(t_in), _ptr(wt), _ptr(bias), _ptr(pool), _ptr(idx) if want_idx else None, n, dtype_code(t_in), _stream()),
                "vdqn_stem_conv_pool")
     return pool, idx
