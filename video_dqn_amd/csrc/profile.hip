@@ -15,6 +15,7 @@ struct Rec {
   int tag;
   hipEvent_t e0, e1;
   double flops, bytes;
+  hipStream_t st;
 };
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -85,7 +86,7 @@ void vdqn_prof_begin(const char* tag, double flops, double bytes, hipStream_t st
   } else {
     id = it->second;
   }
-  g_recs.push_back(Rec{id, g_pool[g_pool_next].first, g_pool[g_pool_next].second, flops, bytes});
+  g_recs.push_back(Rec{id, g_pool[g_pool_next].first, g_pool[g_pool_next].second, flops, bytes, st});
   ++g_pool_next;
   g_open = &g_recs.back();
   (void)hipEventRecord(g_open->e0, st);
@@ -126,6 +127,33 @@ extern "C" int vdqn_profile_collect(vdqn_prof_entry* out, int max_entries) {
     if (a.launches > 0 && n < max_entries) out[n++] = a;
   g_recs.clear();
   g_pool_next = 0;
+  return n;
+}
+
+// Diagnostic (not part of include/vdqn.h; tools/timeline_live.py): the recorded launches as spans on a common time axis — e0 / e1
+// of every launch relative to the first launch's e0, and a small integer per stream in order of first use.  With the side stream
+// on this is the update's real timeline (rocprofv3's kernel trace serialises the dispatches): what overlaps, where the device idles.
+// Leaves the records in place (vdqn_profile_collect clears them).
+struct vdqn_prof_span {
+  char name[48];
+  float t0_ms, t1_ms;
+  int stream;
+};
+extern "C" int vdqn_debug_profile_timeline(vdqn_prof_span* out, int max_entries) {
+  if (!out || max_entries <= 0 || g_recs.empty()) return 0;
+  std::vector<hipStream_t> streams;
+  int n = 0;
+  for (auto& r : g_recs) {
+    if (n >= max_entries) break;
+    if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, g_recs[0].e0, r.e0) != hipSuccess || hipEventElapsedTime(&b, g_recs[0].e0, r.e1) != hipSuccess) continue;
+    size_t si = std::find(streams.begin(), streams.end(), r.st) - streams.begin();
+    if (si == streams.size()) streams.push_back(r.st);
+    snprintf(out[n].name, sizeof(out[n].name), "%s", g_tags[r.tag].c_str());
+    out[n].t0_ms = a; out[n].t1_ms = b; out[n].stream = (int)si;
+    ++n;
+  }
   return n;
 }
 
