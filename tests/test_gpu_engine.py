@@ -18,9 +18,9 @@ from video_dqn_amd import synth  # noqa: E402
 DEV = "cuda"
 
 
-def make_engine(dtype, seed=7, num_frames=1, max_batch=32):
+def make_engine(dtype, seed=7, num_frames=1, max_batch=32, deterministic=None):
     from video_dqn_amd.engine import NetEngine
-    net = NetEngine(3, 5, num_frames, True, dtype, max_batch)
+    net = NetEngine(3, 5, num_frames, True, dtype, max_batch, deterministic=deterministic)
     net.load_tensors(synth.make_state_dict(seed, num_frames=num_frames))
     return net
 
@@ -325,6 +325,37 @@ def test_target_sync_timing():
     assert snaps[2][2]  # at step 3 the target equals the online weights *before* step 3's update
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_early_adam_is_the_same_update(dtype):
+    """`TDStepper.step` queues Adam for stage 0 / stage 1 behind that stage's gradient unpack (on the gradient stream, under the
+    rest of the backward pass) and the remainder at the end; `forward_backward` + `optimizer_step` is one launch at the end
+    (loss.backward(); optimizer.step(), train_q_network.py:226-227).  Deterministic mode: the parameters and both moment
+    buffers agree bit for bit after three updates."""
+    from video_dqn_amd.engine import TDStepper
+    B = 4
+    (tup, _) = synth.make_batch(5, B, 1, structured=True, reward_p=0.3)
+    args = (tup[0].contiguous().to(DEV), tup[1].contiguous().to(DEV), 1, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV))
+    out = []
+    for early in (True, False):
+        net = make_engine(dtype, seed=7, max_batch=2 * B, deterministic=True)
+        stp = TDStepper(net, B, lr=1e-3, gamma=0.99, clip_rect=True, target_update_interval=2)
+        for _ in range(3):
+            if early:
+                stp.step(*args)
+            else:
+                stp.sample_number += 1
+                if stp.sample_number % stp.tui == 0:
+                    stp.sync_target()
+                stp.forward_backward(*args)
+                stp.optimizer_step()
+        torch.cuda.synchronize()
+        assert stp.adam_step == 3
+        out.append((net.params.clone(), stp.exp_avg.clone(), stp.exp_avg_sq.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert not torch.equal(out[0][0], make_engine(dtype, seed=7, max_batch=2 * B).params)
+
+
 def _act(net, buf, n_samples, name, shape):
     """View of a named activation inside the engine's workspace (vdqn_net_act_offset)."""
     off = net.lib.vdqn_net_act_offset(net.handle, n_samples, name.encode())
@@ -586,6 +617,9 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_WGRAD_STREAMS": "2"},      # weight gradients alternate between the two side streams
     {"VDQN_S2WIN": "0"},              # stride-2 3x3 forward convolutions on the generic kernel (no plane-window kernel)
     {"VDQN_STEM_NOIDX": "0"},         # the stem writes the max-pool arg-max bytes of the no-grad frames too
+    {"VDQN_EARLY_ADAM": "0"},         # TDStepper.step: one Adam launch behind the whole backward pass
+    {"VDQN_FOLD_SPLIT": "1"},         # weight fold of stage 2's layers first, the rest on the side stream beside the stem
+    {"VDQN_STEM_WGRAD_MAIN": "0"},    # conv1's weight gradient on the side stream behind block 0's instead of beside them
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_non_default_kernel_selections(env):
     """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and

@@ -52,13 +52,13 @@ def main():
     _lib.profile_collect()
     _lib.profile_enable(False)
     spans = [(buf[i].t0 * 1e3, buf[i].t1 * 1e3, buf[i].stream, buf[i].name.decode()) for i in range(n)]
-    adam = [i for i, s in enumerate(spans) if s[3].startswith("adam")]
-    if len(adam) < 2:
+    marks = [i for i, s in enumerate(spans) if s[3].startswith("td_loss")]  # exactly one launch per update
+    if len(marks) < 2:
         raise SystemExit("fewer than two updates recorded")
-    lo, hi = adam[-2], adam[-1]
-    upd = spans[lo + 1:hi + 1]
-    t0, t1 = spans[lo][1], spans[hi][1]
-    print(f"update (end of adam to end of the next adam): {t1 - t0:.1f} us, {len(upd)} launches")
+    lo, hi = marks[-2], marks[-1]
+    upd = spans[lo:hi]
+    t0, t1 = spans[lo][0], spans[hi][0]
+    print(f"update (td_loss to the next update's td_loss: backward, Adam, the next forward): {t1 - t0:.1f} us, {len(upd)} launches")
     bys = defaultdict(list)
     for s in upd:
         bys[s[2]].append(s)

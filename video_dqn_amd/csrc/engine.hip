@@ -232,8 +232,8 @@ __device__ __forceinline__ float fold_scale(const FoldDesc& d, const float* para
 // (train-mode BatchNorm of ARCHITECTURE='basic': the convs produce the raw output, bias 0)
 template <typename T>
 __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const float* __restrict__ params, const float* __restrict__ bnstats,
-                                                   unsigned char* __restrict__ packed, int with_dgrad, int raw) {
-  const FoldDesc& d = tab.d[blockIdx.y];
+                                                   unsigned char* __restrict__ packed, int with_dgrad, int raw, int first_layer) {
+  const FoldDesc& d = tab.d[first_layer + blockIdx.y];
   const int which = blockIdx.z;
   if (d.tiled) return;  // fold_tile_kernel's layers
   if (which == 1 && (!with_dgrad || d.wd_off < 0)) return;
@@ -321,45 +321,50 @@ __device__ __forceinline__ void fold_tile_body(const FoldDesc& d, const float* _
     dst[0] = v.x * sc; dst[1] = v.y * sc; dst[2] = v.z * sc; dst[3] = v.w * sc;
   }
   __syncthreads();
-  // Wf rows [co][tap][c]: a thread writes two consecutive channels (a wave: 128 contiguous channels' worth of one or two runs)
+  // Wf rows [co][tap][c]: a thread writes EIGHT consecutive channels (16 bytes of bf16; eight lanes = the 64-channel run of one tap)
   T* wf = reinterpret_cast<T*>(packed + d.wf_off);
-#pragma unroll 6
-  for (int i = threadIdx.x; i < COT * RUN / 2; i += 256) {
-    const int co_l = i / (RUN / 2), rem = i - co_l * (RUN / 2);
-    const int tap = rem >> 5, c_l = (rem & 31) * 2;
+  constexpr int V16 = (int)(8 * sizeof(T) / 16);  // 16-byte stores per eight elements
+#pragma unroll 3
+  for (int i = threadIdx.x; i < COT * TAPS * 8; i += 256) {
+    const int co_l = i / (TAPS * 8), rem = i - co_l * (TAPS * 8);
+    const int tap = rem >> 3, c_l = (rem & 7) * 8;
     const float* src = sW + co_l * PITCH + c_l * TAPS + tap;
-    T o2[2] = {from_f32<T>(src[0]), from_f32<T>(src[TAPS])};
+    T o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = from_f32<T>(src[e * TAPS]);
     T* dst = wf + (long)(co0 + co_l) * d.kf + tap * d.ci + c0 + c_l;
-    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(o2);
-    else *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(o2);
+#pragma unroll
+    for (int v = 0; v < V16; ++v) reinterpret_cast<uint4*>(dst)[v] = reinterpret_cast<const uint4*>(o8)[v];
   }
   if (with_dgrad && d.wd_off >= 0) {
-    // Wd rows [c][tap][co]: a thread writes two consecutive output channels
+    // Wd rows [c][tap][co]: a thread writes eight consecutive output channels (four lanes = this block's 32 of them)
     T* wd = reinterpret_cast<T*>(packed + d.wd_off);
-#pragma unroll 6
-    for (int i = threadIdx.x; i < COT * RUN / 2; i += 256) {
-      const int co_l = (i % (COT / 2)) * 2, rem = i / (COT / 2);
+#pragma unroll 3
+    for (int i = threadIdx.x; i < 64 * TAPS * (COT / 8); i += 256) {
+      const int co_l = (i % (COT / 8)) * 8, rem = i / (COT / 8);
       const int tap = rem % TAPS, c_l = rem / TAPS;
       const float* src = sW + co_l * PITCH + c_l * TAPS + tap;
-      T o2[2] = {from_f32<T>(src[0]), from_f32<T>(src[PITCH])};
+      T o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = from_f32<T>(src[e * PITCH]);
       T* dst = wd + (long)(c0 + c_l) * d.kd + tap * d.co_pad + co0 + co_l;
-      if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(o2);
-      else *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(o2);
+#pragma unroll
+      for (int v = 0; v < V16; ++v) reinterpret_cast<uint4*>(dst)[v] = reinterpret_cast<const uint4*>(o8)[v];
     }
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void fold_tile_kernel(const FoldTable tab, const float* __restrict__ params, const float* __restrict__ bnstats,
-                                                        unsigned char* __restrict__ packed, int with_dgrad, int raw) {
+                                                        unsigned char* __restrict__ packed, int with_dgrad, int raw, int tile_first) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fold_smem[];
   float* sW = reinterpret_cast<float*>(fold_smem);  // [32][64 * taps + 1] f32, source order
   __shared__ float s_scale[32];
   int li = 0;
   for (int i = 0; i < tab.n; ++i)
-    if (tab.d[i].tiled && (int)blockIdx.x >= tab.d[i].tile_begin) li = i;
+    if (tab.d[i].tiled && tile_first + (int)blockIdx.x >= tab.d[i].tile_begin) li = i;
   const FoldDesc& d = tab.d[li];
-  const int t = (int)blockIdx.x - d.tile_begin;
+  const int t = tile_first + (int)blockIdx.x - d.tile_begin;
   if (d.r * d.s == 9) fold_tile_body<T, 9>(d, params, bnstats, packed, with_dgrad, raw, sW, s_scale, t, (int)blockIdx.y);
   else fold_tile_body<T, 1>(d, params, bnstats, packed, with_dgrad, raw, sW, s_scale, t, (int)blockIdx.y);
 }
@@ -392,19 +397,37 @@ __global__ __launch_bounds__(256) void unfold_kernel(const FoldTable tab, const 
     sc = params[d.g_off + co] * rstd;
   }
   float dot = 0.f;
-  __shared__ float s_row[4608];  // one packed-layout dW' row of a plain convolution (<= 9 taps x 512 channels)
+  __shared__ __attribute__((aligned(16))) float s_row[4608];  // one packed-layout dW' row of a plain convolution (<= 9 taps x 512 channels)
   if (d.tiled && d.kf <= 4608) {
     // packed row -> LDS (coalesced), then the OIHW row of the gradient and of the master weights is walked in ITS order
     // (coalesced global accesses; the [tap][c] -> [c][tap] permutation happens on the LDS read)
-    for (int k = threadIdx.x; k < d.kf; k += 256) s_row[k] = dw[k];
-    __syncthreads();
     const int taps = d.r * d.s;
     const long base = d.w_off + (long)co * d.kf;
-    for (int i = threadIdx.x; i < d.kf; i += 256) {
-      const int c = i / taps, tap = i - c * taps;
-      const float g = s_row[tap * d.ci + c];
-      grads[base + i] = g * sc;
-      dot += g * params[base + i];
+    if ((((uintptr_t)dw | (uintptr_t)(params + base) | (uintptr_t)(grads + base)) & 15) == 0 && (d.kf & 3) == 0) {
+      // 16-byte accesses on both sides of the permutation (a stage's unfold moves up to 100 MB)
+      for (int k = threadIdx.x; k < d.kf / 4; k += 256) reinterpret_cast<float4*>(s_row)[k] = reinterpret_cast<const float4*>(dw)[k];
+      __syncthreads();
+      for (int i4 = threadIdx.x; i4 < d.kf / 4; i4 += 256) {
+        float g[4];
+        int c = (4 * i4) / taps, tap = 4 * i4 - c * taps;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          g[e] = s_row[tap * d.ci + c];
+          if (++tap == taps) { tap = 0; ++c; }
+        }
+        const float4 w = reinterpret_cast<const float4*>(params + base)[i4];
+        reinterpret_cast<float4*>(grads + base)[i4] = make_float4(g[0] * sc, g[1] * sc, g[2] * sc, g[3] * sc);
+        dot += g[0] * w.x + g[1] * w.y + g[2] * w.z + g[3] * w.w;
+      }
+    } else {
+      for (int k = threadIdx.x; k < d.kf; k += 256) s_row[k] = dw[k];
+      __syncthreads();
+      for (int i = threadIdx.x; i < d.kf; i += 256) {
+        const int c = i / taps, tap = i - c * taps;
+        const float g = s_row[tap * d.ci + c];
+        grads[base + i] = g * sc;
+        dot += g * params[base + i];
+      }
     }
   } else {
     for (int k = threadIdx.x; k < d.kf; k += 256) {
@@ -989,7 +1012,9 @@ int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const voi
 // the second range).  The stem runs once per range (its weights live in registers), every later layer is one vdqn_conv2d call.
 int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t_in, int n_samples, unsigned char* acts, const ActLayout& A,
                  hipStream_t st, bool trunk_only = false, const unsigned char* packed_b = nullptr, int split_samples = 0, const void* t_in_b = nullptr,
-                 int grad_samples = -1) {
+                 int grad_samples = -1, hipEvent_t late_weights = nullptr) {
+  // late_weights: the packed weights of the layers outside backward stage 2 (layer3, layer4, head) are being written on another
+  // stream; `st` waits for that event in front of the first such layer (vdqn_net_td_forward folds them beside the stem)
   const int n = n_samples * net->cfg.num_frames;
   const int dt = net->cfg.dtype;
   const int n_a = packed_b ? split_samples * net->cfg.num_frames : n;  // frames of the first range
@@ -1016,6 +1041,10 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
     const Layer& c1 = net->layers[net->l_b_conv1[b]];
     const Layer& c2 = net->layers[net->l_b_conv2[b]];
     const void* identity = x;
+    if (late_weights && net->l_b_conv1[b] < net->layer_stage_first[2]) {
+      (void)hipStreamWaitEvent(st, late_weights, 0);
+      late_weights = nullptr;
+    }
     if (net->l_b_ds[b] >= 0 && fuse_ds_fwd() && !packed_b) {  // stride-2 block: conv1 and the downsample read the same pixels — one launch
       RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st, &net->layers[net->l_b_ds[b]], acts + A.ds[b]));
       identity = acts + A.ds[b];
@@ -1212,25 +1241,43 @@ extern "C" int64_t vdqn_net_bwd_offset(const vdqn_net* net, int32_t n_samples, c
   return -1;
 }
 
-extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad, void* stream) {
-  VDQN_CHECK(net && params && bnstats && packed, "vdqn_net_pack_weights: null arg");
-  dim3 grid(256, (unsigned)net->layers.size(), 2);
+// BatchNorm fold + layout packs of layers [first_layer, first_layer + n_layers) of the table (stored by backward stage: head +
+// layer4, layer3, then stem + layer1 + layer2)
+static int pack_weights_layers(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad, int first_layer,
+                               int n_layers, hipStream_t stream) {
+  if (n_layers <= 0) return VDQN_OK;
+  dim3 grid(256, (unsigned)n_layers, 2);
   const int dgrad = with_dgrad & 1, raw = (with_dgrad >> 1) & 1;
-  ProfScope ps_("fold_weights", 0.0, (double)net->trainable_numel * 4.0 + (double)net->packed_bytes * (dgrad ? 1.0 : 0.5), (hipStream_t)stream);
+  int tile_first = -1, tile_end = 0;
+  for (int i = first_layer; i < first_layer + n_layers; ++i) {
+    const FoldDesc& d = net->fold.d[i];
+    if (!d.tiled) continue;
+    if (tile_first < 0) tile_first = d.tile_begin;
+    tile_end = d.tile_begin + (d.co_pad / 64) * (d.ci / 64);
+  }
+  const double share = (double)n_layers / (double)net->layers.size();
+  ProfScope ps_("fold_weights", 0.0, ((double)net->trainable_numel * 4.0 + (double)net->packed_bytes * (dgrad ? 1.0 : 0.5)) * share, stream);
   const size_t tile_smem = 32 * (64 * 9 + 1) * 4;  // [32 output channels][64 * taps + 1] f32
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&fold_tile_kernel<bf16raw>), (size_t)tile_smem);
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&fold_tile_kernel<float>), (size_t)tile_smem);
   if (net->cfg.dtype == VDQN_BF16) {
-    hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw);
-    hipLaunchKernelGGL((fold_tile_kernel<bf16raw>), dim3(net->fold.n_tiles, 2), dim3(256), tile_smem, (hipStream_t)stream, net->fold, params, bnstats,
-                       (unsigned char*)packed, dgrad, raw);
+    hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw, first_layer);
+    if (tile_first >= 0)
+      hipLaunchKernelGGL((fold_tile_kernel<bf16raw>), dim3(tile_end - tile_first, 2), dim3(256), tile_smem, stream, net->fold, params, bnstats,
+                         (unsigned char*)packed, dgrad, raw, tile_first);
   } else {
-    hipLaunchKernelGGL((fold_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw);
-    hipLaunchKernelGGL((fold_tile_kernel<float>), dim3(net->fold.n_tiles, 2), dim3(256), tile_smem, (hipStream_t)stream, net->fold, params, bnstats,
-                       (unsigned char*)packed, dgrad, raw);
+    hipLaunchKernelGGL((fold_kernel<float>), grid, dim3(256), 0, stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw, first_layer);
+    if (tile_first >= 0)
+      hipLaunchKernelGGL((fold_tile_kernel<float>), dim3(tile_end - tile_first, 2), dim3(256), tile_smem, stream, net->fold, params, bnstats,
+                         (unsigned char*)packed, dgrad, raw, tile_first);
   }
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
+}
+
+extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad, void* stream) {
+  VDQN_CHECK(net && params && bnstats && packed, "vdqn_net_pack_weights: null arg");
+  return pack_weights_layers(net, params, bnstats, packed, with_dgrad, 0, (int)net->layers.size(), (hipStream_t)stream);
 }
 
 extern "C" int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples, void* acts,
@@ -1312,13 +1359,29 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   hipStream_t tst = fork_side(net, st);  // == st when the overlap is off
   RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, tst));
   if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
-  RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
+  // VDQN_FOLD_SPLIT=1 (off by default): only stage 2's layers (stem, layer1, layer2: 0.7 M of the 12.4 M parameters) are folded in
+  // front of the online pass; the rest (layer3, layer4, head) on the side stream beside the stem and layer1, and the caller's stream
+  // waits for it in front of layer3.  Measured on alternating runs it is 0.03 ms per update SLOWER than the one fold in front of
+  // everything (5.785 vs 5.757 ms, profiles/r03q_ab_fold_split.txt): the side stream's target pass starts that much later.
+  static const bool fold_split_on = [] { const char* e = getenv("VDQN_FOLD_SPLIT"); return e && e[0] == '1'; }();
+  const bool fold_split = fold_split_on && tst != st && !net->basic() && net->layer_stage_first[2] > 0;
+  hipEvent_t late_weights = nullptr;
+  if (fold_split) {
+    RC(pack_weights_layers(net, a->params, a->bnstats, a->packed_online, 1, net->layer_stage_first[2], net->layer_stage_count[2], st));
+  } else {
+    RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
+  }
   if (tst != st) join_side(net, st);  // packed input ready for the online pass
+  if (fold_split) {
+    RC(pack_weights_layers(net, a->params, a->bnstats, a->packed_online, 1, 0, net->layer_stage_first[2], tst));
+    late_weights = next_event(net);
+    (void)hipEventRecord(late_weights, tst);
+  }
   if (grouped) {
     // [s; s'] with the online weights and s' with the target's, one chain of launches on the caller's stream (the side stream
     // carries nothing during the forward); the target range's stem reads the packed s' frames of the online range
     RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, 3 * B, ao, A, st, false, (const unsigned char*)a->packed_target, 2 * B,
-                    ao + A.t_in + (int64_t)B * F * frame_bytes, B));
+                    ao + A.t_in + (int64_t)B * F * frame_bytes, B, late_weights));
   } else if (!gtb) {
     const ActLayout T = act_layout(net, B);
     RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst, false,
@@ -1338,11 +1401,11 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     hipStream_t s2 = (split && !gtb) ? fork_side2(net, st) : st;
     if (s2 != st) {
       const ActLayout A2 = shift_layout(net, A, B);
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A2.t_in, B, ao, A2, s2, false, nullptr, 0, nullptr, 0));
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, B, ao, A, st));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A2.t_in, B, ao, A2, s2, false, nullptr, 0, nullptr, 0, late_weights));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, B, ao, A, st, false, nullptr, 0, nullptr, -1, late_weights));
       join_side2(net, st);
     } else {
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st, false, nullptr, 0, nullptr, B));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st, false, nullptr, 0, nullptr, B, late_weights));
     }
   }
   if (tst != st) join_side(net, st);
@@ -1560,8 +1623,13 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     const int64_t det_need = net->cfg.deterministic ? vdqn_stem_wgrad_pool_workspace_bytes(n) : 0;
     if (fuse_pool && dt == VDQN_BF16 && (int64_t)n * 115 * 115 * 32 < (1ll << 31) && det_need <= W.det_ws_bytes) {
       prof_layer(L1, n);
+      // Which stream: the side stream still holds block 0's last two weight gradients when the data-gradient chain ends, so in
+      // the default mode this kernel runs on the CALLER's stream beside them (the update's tail on two streams instead of one;
+      // its unfold below waits for it).  Deterministic mode keeps it on the side stream: the partial copies share one workspace.
+      static const bool on_main = [] { const char* e = getenv("VDQN_STEM_WGRAD_MAIN"); return !(e && e[0] == '0'); }();
+      const bool main_st = on_main && split_conv1 && !net->cfg.deterministic;
       return vdqn_stem_wgrad_pool(bw + W.g_pool, ao + A.idx, ao + A.t_in, reinterpret_cast<float*>(bw + L1.dw_off), n,
-                                  net->cfg.deterministic ? bw + W.det_ws : nullptr, W.det_ws_bytes, fork_side(net, st));
+                                  net->cfg.deterministic ? bw + W.det_ws : nullptr, W.det_ws_bytes, main_st ? st : fork_side(net, st));
     }
     // max-pool backward on the caller's stream, the weight gradient behind it on the side stream
     RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
@@ -1584,6 +1652,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     }
     RC(conv1_chain());
     join_wgrad_streams(net);
+    (void)fork_side(net, st);  // conv1's weight gradient may have run on the caller's stream
     ProfScope ps_("unfold_grads", 0.0, 0.0, net->side);
     hipLaunchKernelGGL(unfold_kernel, dim3(net->layers[net->l_conv1].co, 1), dim3(256), 0, net->side, net->fold, pt, net->l_conv1, a->params, a->bnstats,
                        (const unsigned char*)bw, a->grads, 0);

@@ -25,6 +25,10 @@ DTYPES = {"f32": _lib.VDQN_F32, "fp32": _lib.VDQN_F32, "float32": _lib.VDQN_F32,
           "bf16": _lib.VDQN_BF16, "bfloat16": _lib.VDQN_BF16}
 
 
+# VDQN_EARLY_ADAM=0: `TDStepper.step` runs the whole optimiser update behind the backward pass (one launch)
+_EARLY_ADAM = os.environ.get("VDQN_EARLY_ADAM", "1") != "0"
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -277,6 +281,8 @@ class TDStepper:
         self.adam_step = 0
         self.sample_number = 0
         self._grad_stream = None  # torch view of the engine's side stream (vdqn_net_grad_stream)
+        self._adam_done, self._opt_stream, self._opt_used = [], None, False
+        self._comm_finish_stage = getattr(getattr(allreduce, "__self__", None), "finish_stage", None)
         self.stage_ranges = [net.stage_range(s) for s in range(3)]
         self.sync_target()
 
@@ -302,9 +308,15 @@ class TDStepper:
         a.loss_kind = LOSS_KINDS[self.loss_kind]
         return a
 
-    def forward_backward(self, before, after, src_kind, act, rew, term, valid=None, gt=None):
-        """Everything of one update up to (and including) the gradient all-reduce; no optimiser step."""
+    def forward_backward(self, before, after, src_kind, act, rew, term, valid=None, gt=None, early_adam: bool = False):
+        """Everything of one update up to (and including) the gradient all-reduce; no optimiser step.
+
+        early_adam (only `step` passes it, single process, eval-mode BatchNorm): the optimiser update of stage 0 and stage 1 is
+        queued on the engine's gradient stream right behind that stage's gradient unpack, so it runs under the remaining data /
+        weight gradients instead of behind them (nothing later in the update reads those master parameters: the kernels work on
+        the packed copies); `optimizer_step` then only covers what is left.  Same arithmetic, same results."""
         n = self.net
+        self._adam_done = []
         keep = (before, after, act, rew, term, valid, gt)  # keep inputs alive until the launches are queued
         with torch.cuda.device(n.device):
             a = self._args(before, after, src_kind, act, rew, term, valid if valid is not None else self._ones, gt)
@@ -321,6 +333,24 @@ class TDStepper:
                     b, e = self.stage_ranges[stage]
                     with self._grad_stream_ctx():
                         self.allreduce(self.grads[b:e], stage)
+                    if early_adam and stage < 2 and self._comm_finish_stage is not None:
+                        b, e = (b + 3) // 4 * 4, e // 4 * 4
+                        if e > b:
+                            # behind THIS bucket's collective only, on a stream of its own (the gradient stream must not wait for RCCL)
+                            if self._opt_stream is None:
+                                self._opt_stream = torch.cuda.Stream(device=n.device)
+                            with torch.cuda.stream(self._opt_stream):
+                                self._comm_finish_stage(stage)
+                                self._adam_range(b, e, self.adam_step + 1)
+                            self._adam_done.append((b, e))
+                            self._opt_used = True
+                elif early_adam and stage < 2:
+                    b, e = self.stage_ranges[stage]
+                    b, e = (b + 3) // 4 * 4, e // 4 * 4  # vdqn_adam wants 16-byte aligned ranges; the rest is left to optimizer_step
+                    if e > b:
+                        with self._grad_stream_ctx():
+                            self._adam_range(b, e, self.adam_step + 1)
+                        self._adam_done.append((b, e))
         del keep
 
     def _grad_stream_ctx(self):
@@ -331,13 +361,27 @@ class TDStepper:
             self._grad_stream = torch.cuda.ExternalStream(ptr, device=self.net.device)
         return torch.cuda.stream(self._grad_stream)
 
+    def _adam_range(self, b: int, e: int, step: int):
+        """Adam (train_q_network.py:227) over the flat element range [b, e) on the current stream."""
+        n = self.net
+        _lib.check(self.lib.vdqn_adam(n.params.data_ptr() + 4 * b, self.grads.data_ptr() + 4 * b, self.exp_avg.data_ptr() + 4 * b,
+                                      self.exp_avg_sq.data_ptr() + 4 * b, e - b, step, self.lr, self.betas[0], self.betas[1],
+                                      self.eps, _stream()), "vdqn_adam")
+
     def optimizer_step(self):
         n = self.net
         self.adam_step += 1
+        done = sorted(getattr(self, "_adam_done", []))
+        self._adam_done = []
         with torch.cuda.device(n.device):
-            _lib.check(self.lib.vdqn_adam(_ptr(n.params), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                          n.trainable_numel, self.adam_step, self.lr, self.betas[0], self.betas[1],
-                                          self.eps, _stream()), "vdqn_adam")
+            if self._opt_used:
+                torch.cuda.current_stream().wait_stream(self._opt_stream)
+                self._opt_used = False
+            pos = 0  # everything of [0, trainable_numel) that `forward_backward(early_adam=True)` has not updated already
+            for b, e in done + [(n.trainable_numel, n.trainable_numel)]:
+                if b > pos:
+                    self._adam_range(pos, b, self.adam_step)
+                pos = max(pos, e)
         n.mark_dirty()
 
     def step(self, before, after, src_kind, act, rew, term, valid=None, gt=None, finish_allreduce=None) -> torch.Tensor:
@@ -346,7 +390,10 @@ class TDStepper:
         self.sample_number += 1
         if self.sample_number % self.tui == 0:
             self.sync_target()
-        self.forward_backward(before, after, src_kind, act, rew, term, valid, gt)
+        # (with an exchange: only when its owner can wait for ONE bucket, BucketAllReduce.finish_stage)
+        early = _EARLY_ADAM and self.net.extra_capacity and (
+            (self.allreduce is None and finish_allreduce is None) or (self.allreduce is not None and self._comm_finish_stage is not None))
+        self.forward_backward(before, after, src_kind, act, rew, term, valid, gt, early_adam=early)
         if finish_allreduce is not None:
             finish_allreduce()
         self.optimizer_step()
