@@ -618,6 +618,7 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_S2WIN": "0"},              # stride-2 3x3 forward convolutions on the generic kernel (no plane-window kernel)
     {"VDQN_STEM_NOIDX": "0"},         # the stem writes the max-pool arg-max bytes of the no-grad frames too
     {"VDQN_EARLY_ADAM": "0"},         # TDStepper.step: one Adam launch behind the whole backward pass
+    {"VDQN_PACK_AFTER_FIRST": "1"},   # the s' frames packed first and the target pass right behind them, the s frames on the caller's stream
     {"VDQN_FOLD_SPLIT": "1"},         # weight fold of stage 2's layers first, the rest on the side stream beside the stem
     {"VDQN_STEM_WGRAD_MAIN": "0"},    # conv1's weight gradient on the side stream behind block 0's instead of beside them
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))

@@ -1357,8 +1357,22 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   // pass then simply continues on the side stream: it only reads the packed input and its own weights
   const int64_t frame_bytes = (int64_t)115 * 115 * 16 * net->esz;
   hipStream_t tst = fork_side(net, st);  // == st when the overlap is off
-  RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, tst));
-  if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
+  // VDQN_PACK_AFTER_FIRST=1 (off by default): the s' frames are packed FIRST, on the side stream, and the target pass follows them at
+  // once, so that its stem (matrix work) runs beside the caller's stream packing the s frames and folding the weights (HBM work)
+  // instead of behind both packs.  Measured on alternating runs: 5.88 vs 5.75-5.77 ms per update — slower
+  // (profiles/r03s_ab_pack_after_first.txt); the default keeps both packs on the side stream and the fold beside them.
+  static const bool after_first_on = [] { const char* e = getenv("VDQN_PACK_AFTER_FIRST"); return e && e[0] == '1'; }();
+  const bool after_first = after_first_on && tst != st && !gtb && !grouped;
+  hipEvent_t e_after = nullptr;
+  if (after_first) {
+    RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
+    e_after = next_event(net);
+    (void)hipEventRecord(e_after, tst);
+    RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, st));
+  } else {
+    RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, tst));
+    if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
+  }
   // VDQN_FOLD_SPLIT=1 (off by default): only stage 2's layers (stem, layer1, layer2: 0.7 M of the 12.4 M parameters) are folded in
   // front of the online pass; the rest (layer3, layer4, head) on the side stream beside the stem and layer1, and the caller's stream
   // waits for it in front of layer3.  Measured on alternating runs it is 0.03 ms per update SLOWER than the one fold in front of
@@ -1371,7 +1385,8 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   } else {
     RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
   }
-  if (tst != st) join_side(net, st);  // packed input ready for the online pass
+  if (after_first) (void)hipStreamWaitEvent(st, e_after, 0);  // the s' half of the packed input
+  else if (tst != st) join_side(net, st);                      // packed input ready for the online pass
   if (fold_split) {
     RC(pack_weights_layers(net, a->params, a->bnstats, a->packed_online, 1, 0, net->layer_stage_first[2], tst));
     late_weights = next_event(net);

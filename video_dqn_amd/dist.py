@@ -34,11 +34,6 @@ class BucketAllReduce:
         self.bucket_bytes.append(grad_slice.numel() * grad_slice.element_size())
         self._works.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish_stage(self, i: int) -> None:
-        """The current stream waits for the i-th bucket launched in this update only (TDStepper: that stage's Adam goes behind it)."""
-        if i < len(self._works):
-            self._works[i].wait()
-
     def finish(self) -> None:
         for w in self._works:
             w.wait()
@@ -91,10 +86,6 @@ class CAbiBucketAllReduce:
         ev = torch.cuda.Event()
         ev.record(st)
         self._events.append(ev)
-
-    def finish_stage(self, i: int) -> None:
-        if i < len(self._events):
-            torch.cuda.current_stream().wait_event(self._events[i])
 
     def finish(self) -> None:
         cur = torch.cuda.current_stream()

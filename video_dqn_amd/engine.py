@@ -281,8 +281,7 @@ class TDStepper:
         self.adam_step = 0
         self.sample_number = 0
         self._grad_stream = None  # torch view of the engine's side stream (vdqn_net_grad_stream)
-        self._adam_done, self._opt_stream, self._opt_used = [], None, False
-        self._comm_finish_stage = getattr(getattr(allreduce, "__self__", None), "finish_stage", None)
+        self._adam_done = []
         self.stage_ranges = [net.stage_range(s) for s in range(3)]
         self.sync_target()
 
@@ -311,7 +310,7 @@ class TDStepper:
     def forward_backward(self, before, after, src_kind, act, rew, term, valid=None, gt=None, early_adam: bool = False):
         """Everything of one update up to (and including) the gradient all-reduce; no optimiser step.
 
-        early_adam (only `step` passes it, single process, eval-mode BatchNorm): the optimiser update of stage 0 and stage 1 is
+        early_adam (only `step` passes it: single process, no exchange, eval-mode BatchNorm): the optimiser update of stage 0 and stage 1 is
         queued on the engine's gradient stream right behind that stage's gradient unpack, so it runs under the remaining data /
         weight gradients instead of behind them (nothing later in the update reads those master parameters: the kernels work on
         the packed copies); `optimizer_step` then only covers what is left.  Same arithmetic, same results."""
@@ -333,17 +332,6 @@ class TDStepper:
                     b, e = self.stage_ranges[stage]
                     with self._grad_stream_ctx():
                         self.allreduce(self.grads[b:e], stage)
-                    if early_adam and stage < 2 and self._comm_finish_stage is not None:
-                        b, e = (b + 3) // 4 * 4, e // 4 * 4
-                        if e > b:
-                            # behind THIS bucket's collective only, on a stream of its own (the gradient stream must not wait for RCCL)
-                            if self._opt_stream is None:
-                                self._opt_stream = torch.cuda.Stream(device=n.device)
-                            with torch.cuda.stream(self._opt_stream):
-                                self._comm_finish_stage(stage)
-                                self._adam_range(b, e, self.adam_step + 1)
-                            self._adam_done.append((b, e))
-                            self._opt_used = True
                 elif early_adam and stage < 2:
                     b, e = self.stage_ranges[stage]
                     b, e = (b + 3) // 4 * 4, e // 4 * 4  # vdqn_adam wants 16-byte aligned ranges; the rest is left to optimizer_step
@@ -374,9 +362,6 @@ class TDStepper:
         done = sorted(getattr(self, "_adam_done", []))
         self._adam_done = []
         with torch.cuda.device(n.device):
-            if self._opt_used:
-                torch.cuda.current_stream().wait_stream(self._opt_stream)
-                self._opt_used = False
             pos = 0  # everything of [0, trainable_numel) that `forward_backward(early_adam=True)` has not updated already
             for b, e in done + [(n.trainable_numel, n.trainable_numel)]:
                 if b > pos:
@@ -390,9 +375,9 @@ class TDStepper:
         self.sample_number += 1
         if self.sample_number % self.tui == 0:
             self.sync_target()
-        # (with an exchange: only when its owner can wait for ONE bucket, BucketAllReduce.finish_stage)
-        early = _EARLY_ADAM and self.net.extra_capacity and (
-            (self.allreduce is None and finish_allreduce is None) or (self.allreduce is not None and self._comm_finish_stage is not None))
+        # (single process only: behind each RCCL bucket on a stream of its own it measured 7.22 vs 5.96 ms per update with one rank,
+        # profiles/r03s_ab_rccl_early_adam.txt — with an exchange the whole optimiser update stays behind `finish_allreduce`)
+        early = _EARLY_ADAM and self.net.extra_capacity and self.allreduce is None and finish_allreduce is None
         self.forward_backward(before, after, src_kind, act, rew, term, valid, gt, early_adam=early)
         if finish_allreduce is not None:
             finish_allreduce()
