@@ -1097,7 +1097,10 @@ constexpr int kC64LoadTap = 4;                   // K-loop tap in front of which
 constexpr int kC64RegTaps = 7;                   // taps whose weight fragments live in registers; the rest are read from LDS
 constexpr int kC64Smem = 2 * kC64WinBytes + 256 + 512 + 256 + (9 - kC64RegTaps) * 8192;  // windows, zero pair, column-sum scratch, bias, LDS taps
 
-template <int MODE>
+// HAS_RES / HAS_MSK: whether a residual / a ReLU-mask operand exists is a TEMPLATE parameter — their 16 + 16 registers (loaded in the
+// middle of the K loop for the epilogue) otherwise stay reserved in every instance, and with all 256 VGPRs taken the compiler
+// serialises the second half of the K loop into read / wait / two MFMAs
+template <int MODE, bool HAS_RES, bool HAS_MSK>
 __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, const int n_tiles, const FastDiv d_wo, const FastDiv d_howo, const int grp_a_blocks) {
   using T = bf16raw;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1161,6 +1164,10 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
 #pragma unroll
         for (int j = 0; j < 2; ++j) fw[t][h][j] = *reinterpret_cast<const u32x4*>(wbase + (size_t)j * 4 * (576 * 2) + t * 128 + h * 64);
   }
+  // The weight loads are complete HERE, in a form the compiler's wait-count pass sees (it does not read inline asm): without this
+  // it keeps one `s_waitcnt vmcnt(N)` per weight fragment inside the tile loop (needed in the first iteration only), and in the
+  // steady state those waits stall the K loop on the window DMA of the NEXT tile and on the held stores issued at the tile's top.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
 
   const unsigned long long a_ptr = (unsigned long long)p.in;
   const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
@@ -1213,14 +1220,14 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b128(held[f], r_out, (int)held_off[f], 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(held_cs), r_cs, (int)held_cs_off, 0, 0);
 
-    // edge bits of this lane's four pixels: 1 top row, 2 bottom row, 4 left column, 8 right column
-    uint32_t edge[4];
+    // edge bits of this lane's four pixels (one nibble each, one register): 1 top row, 2 bottom row, 4 left column, 8 right column
+    uint32_t edge = 0u;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const uint32_t m = (uint32_t)(m0 + wr * 64 + f * 16 + i16);
       const uint32_t rem = m - fastdiv(m, d_howo) * d_howo.div;
       const uint32_t oh = fastdiv(rem, d_wo), ow = rem - oh * d_wo.div;
-      edge[f] = (oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u);
+      edge |= ((oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u)) << (4 * f);
     }
     f32x4 acc[4][2];
 #pragma unroll
@@ -1238,48 +1245,79 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
       off[f] = m < p.M ? (uint32_t)(m * p.ldo + ncol) * 2u : kOob;
     }
     u32x4 rv[4], mv[4];
-    // 18 steps (tap, K half); the forward reads input pixel m + (kr-1) W + (ks-1), the data gradient m + (1-kr) W + (1-ks)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap == kC64LoadTap) {
-        if (p.resid) {
-#pragma unroll
-          for (int f = 0; f < 4; ++f) rv[f] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)off[f], 0, 0);
-        }
-        if (p.mask) {
-#pragma unroll
-          for (int f = 0; f < 4; ++f) mv[f] = __builtin_amdgcn_raw_buffer_load_b128(r_msk, (int)off[f], 0, 0);
-        }
-      }
-      const int kr = tap / 3, ks = tap % 3;
-      const int ky = MODE == 0 ? kr : 2 - kr, kx = MODE == 0 ? ks : 2 - ks;  // window offsets
-      const uint32_t tapbits = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u);
-      const int off = W * ky + kx;           // wave-uniform window row offset of this tap
-      const int key = (i16 + off) & 7;
-      const int par = ((i16 + off) & 1) << 7;  // (window buffers start at multiples of 256 bytes: row parity = address bit 7)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int coff = ((g + 4 * h) ^ key) << 4;
-        const unsigned char* z_rd = sZ + par + coff;  // the lane's own position inside the zero pair
-        u32x4 fa[4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          const bool z = (edge[f] & tapbits) != 0u;
-          fa[f] = *reinterpret_cast<const u32x4*>(z ? z_rd : a_rd + (f * 16 + off) * 128 + coff);
-        }
-        u32x4 wj[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (tap < kC64RegTaps) wj[j] = fw[tap < kC64RegTaps ? tap : 0][h][j];
-          else wj[j] = *reinterpret_cast<const u32x4*>(sWt + (tap - kC64RegTaps) * 8192 + (wrow0 + j * 4) * 128 + (((g + 4 * h) ^ ((wrow0 + j * 4) & 7)) << 4));
-        }
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wj[j]), __builtin_bit_cast(bf16x8, fa[f]), acc[f][j], 0, 0, 0);
-      }
-    }
+    // 18 half-steps (tap, K half); the forward reads input pixel m + (kr-1) W + (ks-1), the data gradient m + (1-kr) W + (1-ks).
+    // Software-pipelined by hand: the fragment reads of half-step hs + 1 are issued among the MFMAs of half-step hs (two register
+    // sets, sched_group_barrier pattern) — left to itself the compiler emits read / s_waitcnt lgkmcnt(0) / two MFMAs, i.e. one
+    // exposed LDS latency per pair of MFMAs (round 3: ISA inspection).
+    // (the instance with BOTH epilogue operands has no registers for a second set — it spills 13 of them, and every reload waits
+    // vmcnt(0), i.e. for the next tile's window: it keeps one set and the compiler's order)
+    constexpr int NSET = (HAS_RES && HAS_MSK) ? 1 : 2;
+    u32x4 fa[NSET][4], wl[NSET][2];
+#define VDQN_C64_LOAD(HS, SET)                                                                                              \
+  {                                                                                                                         \
+    constexpr int tap_ = (HS) >> 1, h_ = (HS) & 1;                                                                          \
+    constexpr int kr_ = tap_ / 3, ks_ = tap_ % 3;                                                                           \
+    constexpr int ky_ = MODE == 0 ? kr_ : 2 - kr_, kx_ = MODE == 0 ? ks_ : 2 - ks_; /* window offsets */                    \
+    constexpr uint32_t tapbits_ = (ky_ == 0 ? 1u : 0u) | (ky_ == 2 ? 2u : 0u) | (kx_ == 0 ? 4u : 0u) | (kx_ == 2 ? 8u : 0u); \
+    const int off_ = W * ky_ + kx_; /* wave-uniform window row offset of this tap */                                        \
+    const int key_ = (i16 + off_) & 7;                                                                                      \
+    const int par_ = ((i16 + off_) & 1) << 7; /* (window buffers start at multiples of 256 bytes: row parity = address bit 7) */ \
+    const int coff_ = ((g + 4 * h_) ^ key_) << 4;                                                                           \
+    const unsigned char* z_rd_ = sZ + par_ + coff_; /* the lane's own position inside the zero pair */                      \
+    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                                                      \
+      const bool z_ = (edge & (tapbits_ << (4 * f_))) != 0u;                                                                \
+      fa[SET][f_] = *reinterpret_cast<const u32x4*>(z_ ? z_rd_ : a_rd + (f_ * 16 + off_) * 128 + coff_);                    \
+    }                                                                                                                       \
+    if constexpr (tap_ >= kC64RegTaps) {                                                                                    \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                      \
+          wl[SET][j_] = *reinterpret_cast<const u32x4*>(sWt + (tap_ - kC64RegTaps) * 8192 + (wrow0 + j_ * 4) * 128 +        \
+                                                        (((g + 4 * h_) ^ ((wrow0 + j_ * 4) & 7)) << 4));                    \
+    }                                                                                                                       \
+  }
+#define VDQN_C64_MMA(HS, SET)                                                                                               \
+  {                                                                                                                         \
+    constexpr int tap_ = (HS) >> 1, h_ = (HS) & 1;                                                                          \
+    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                     \
+      u32x4 w_;                                                                                                             \
+      if constexpr (tap_ < kC64RegTaps) w_ = fw[tap_ < kC64RegTaps ? tap_ : 0][h_][j_];                                     \
+      else w_ = wl[SET][j_];                                                                                                \
+      acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w_), __builtin_bit_cast(bf16x8, fa[SET][f_]), acc[f_][j_], 0, 0, 0); \
+    }                                                                                                                       \
+  }
+    // one pipelined half-step: reads of HS + 1 (4, or 6 with LDS weights) spread over the 8 MFMAs of HS
+#define VDQN_C64_STEP(HS)                                                                                                   \
+  {                                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    if constexpr ((HS) == 2 * kC64LoadTap) {                                                                                \
+      if constexpr (HAS_RES) {                                                                                              \
+        _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) rv[f_] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)off[f_], 0, 0); \
+      }                                                                                                                     \
+      if constexpr (HAS_MSK) {                                                                                              \
+        _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) mv[f_] = __builtin_amdgcn_raw_buffer_load_b128(r_msk, (int)off[f_], 0, 0); \
+      }                                                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    }                                                                                                                       \
+    if constexpr (NSET == 2) {                                                                                              \
+      if constexpr ((HS) + 1 < 18) VDQN_C64_LOAD((HS) + 1, ((HS) + 1) & 1)                                                  \
+      VDQN_C64_MMA(HS, (HS) & 1)                                                                                            \
+      _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                  \
+      }                                                                                                                     \
+    } else {                                                                                                                \
+      if constexpr ((HS) > 0) VDQN_C64_LOAD(HS, 0)                                                                          \
+      VDQN_C64_MMA(HS, 0)                                                                                                   \
+    }                                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  }
+    VDQN_C64_LOAD(0, 0)
+    VDQN_C64_STEP(0) VDQN_C64_STEP(1) VDQN_C64_STEP(2) VDQN_C64_STEP(3) VDQN_C64_STEP(4) VDQN_C64_STEP(5)
+    VDQN_C64_STEP(6) VDQN_C64_STEP(7) VDQN_C64_STEP(8) VDQN_C64_STEP(9) VDQN_C64_STEP(10) VDQN_C64_STEP(11)
+    VDQN_C64_STEP(12) VDQN_C64_STEP(13) VDQN_C64_STEP(14) VDQN_C64_STEP(15) VDQN_C64_STEP(16) VDQN_C64_STEP(17)
+#undef VDQN_C64_STEP
+#undef VDQN_C64_MMA
+#undef VDQN_C64_LOAD
     // ---- epilogue (the arithmetic of igemm_epilogue, CPL = 8): lane (i16, g) owns channels ncol .. ncol + 7 of pixels f*16 + i16 ----
     {
       float bv[8];
@@ -1295,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + bv[j * 4 + r];
-        if (p.resid) {
+        if constexpr (HAS_RES) {
           const bf16raw* pr = reinterpret_cast<const bf16raw*>(&rv[f]);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32(pr[e]);
@@ -1304,7 +1342,7 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.mask) {
+        if constexpr (HAS_MSK) {
           const bf16raw* pm = reinterpret_cast<const bf16raw*>(&mv[f]);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (bf16_to_f32(pm[e]) > 0.f) ? v[e] : 0.f;
@@ -1352,7 +1390,10 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
 
 template <int MODE>
 int launch_conv64(const IgemmParams& p, hipStream_t stream) {
-  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&conv64_kernel<MODE>), (size_t)kC64Smem);
+  const bool has_res = p.resid != nullptr, has_msk = p.mask != nullptr;
+  auto kern = has_res ? (has_msk ? &conv64_kernel<MODE, true, true> : &conv64_kernel<MODE, true, false>)
+                      : (has_msk ? &conv64_kernel<MODE, false, true> : &conv64_kernel<MODE, false, false>);
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(kern), (size_t)kC64Smem);
   const int n_cu = vdqn_num_cus();
   const int n_tiles = (p.M + 127) / 128;
   int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
@@ -1370,7 +1411,7 @@ int launch_conv64(const IgemmParams& p, hipStream_t stream) {
   }
   vdqn_prof_begin(MODE == 0 ? "conv64<bf16,fwd>" : "conv64<bf16,dgrad>", 2.0 * p.M * p.co * p.ktot,
                   2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
-  hipLaunchKernelGGL((conv64_kernel<MODE>), dim3(grid), dim3(256), kC64Smem, stream, p, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), grp_a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kC64Smem, stream, p, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), grp_a);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
