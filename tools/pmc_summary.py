@@ -15,7 +15,7 @@ import sys
 
 
 def tag_of(kernel_name: str):
-    m = re.search(r"conv64_kernel<(\d+)>", kernel_name)
+    m = re.search(r"conv64_kernel<(\d+)[,>]", kernel_name)
     if m:
         return f"conv64<bf16,{('fwd', 'dgrad')[int(m[1])]}>"
     m = re.search(r"igemm_kernel<(unsigned short|float), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>", kernel_name)
