@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="skip the event-profiled steps (roofline = null)")
+    ap.add_argument("--pack-ahead", action="store_true",
+                    help="pack the next minibatch's frames under the current update's backward pass (default: every update packs its own frames at its start)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--pool", type=int, default=4,
                     help="distinct synthetic minibatches resident in HBM, used round-robin (4 x 77 MB of frames at batch 256 do "
@@ -218,7 +220,14 @@ def main():
             return stp.step(b, a, 0, act, rew, term, finish_allreduce=(comm.finish if comm else None))
         b_, a_, act_, rew_, term_ = pool[pool_i["i"] % n_pool]
         pool_i["i"] += 1
-        return stp.step(b_, a_, 0, act_, rew_, term_, finish_allreduce=(comm.finish if comm else None))
+        # --pack-ahead: the next minibatch's frames are packed under this update's backward pass instead of at the start of the next
+        # update (TDStepper.step, next_frames).  Measured 5.806 against 5.739 ms per update (profiles/r03w_ab_pack_ahead.txt): the
+        # HBM-bound pack beside layer4 and the head costs more than the start of the update gains.  Off by default.
+        nxt = None
+        if args.pack_ahead or os.environ.get("VDQN_BENCH_PACK_AHEAD") == "1":
+            nb_, na_ = pool[pool_i["i"] % n_pool][:2]
+            nxt = (nb_, na_, 0)
+        return stp.step(b_, a_, 0, act_, rew_, term_, finish_allreduce=(comm.finish if comm else None), next_frames=nxt)
 
     # device ramp (untimed, before the W warm-up steps): a box that sat idle takes longer than 20 updates (0.13 s) to reach the
     # clocks it then holds; the same updates are repeated for --ramp-seconds so that short runs (--steps 20) are not timed on
@@ -340,7 +349,10 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "frames_per_sample": F, "frame": "224x224x3 uint8 (normalise fused)",
                        "parallelism": f"dp{world}", "target_update_interval": args.target_update_interval,
                        "gamma": 0.99, "loss_clip": "rect", "lr": 1e-4, "loss_kind": args.loss_kind,
-                       "minibatch_pool": n_pool},
+                       "minibatch_pool": n_pool,
+                       "frame_pack": ("the next minibatch's frames are packed under the current update's backward pass (inside the timed region)"
+                                      if ((args.pack_ahead or os.environ.get("VDQN_BENCH_PACK_AHEAD") == "1") and args.h2d == "none")
+                                      else "at the start of every update")},
             "per_rank_ms_per_step": per_rank_ms,
             "target_refreshes_in_window": refreshes,
             "allreduce": ({"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "buckets_bytes": comm.bucket_bytes,

@@ -382,6 +382,13 @@ typedef struct vdqn_step_args {
   float* loss;                /* f32 scalar (device) */
   float* q_before;            /* optional f32 [B][15] copy of Q(s) */
   int32_t loss_kind;          /* vdqn_td_args.loss_kind (TD branch only) */
+  const void* packed_frames;  /* optional: the update's frames ALREADY packed by the caller — vdqn_pack_input's output for `before`
+                                 ([B*F][115][115][16]) followed by the one for `after` (TD branch), in the network's dtype, complete
+                                 on `stream` when vdqn_net_td_forward is called and untouched until the update's last
+                                 vdqn_net_backward_stage has run.  `before` / `after` are then not read.  For loops whose frames
+                                 arrive packed (or that pack the NEXT minibatch during this update: the loader of
+                                 train_q_network.py:213 has it a step ahead — measured slower on one GPU).
+                                 NULL: the update packs them itself. */
 } vdqn_step_args;
 int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream);
 /* Stage s of the backward pass (0: head + layer4, 1: layer3, 2: layer2, layer1, stem).  With the overlap on, the stage's weight

@@ -356,6 +356,37 @@ def test_early_adam_is_the_same_update(dtype):
     assert not torch.equal(out[0][0], make_engine(dtype, seed=7, max_batch=2 * B).params)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_frames_packed_one_update_ahead_is_the_same_update(dtype):
+    """`TDStepper.step(next_frames=...)` packs the NEXT call's frames on the gradient stream during this update
+    (vdqn_step_args.packed_frames) — the reference's loop has the next batch a step ahead too (DataLoader prefetch,
+    train_q_network.py:213).  Deterministic mode: parameters and loss bit-equal to packing at the start of every update, also when
+    an announced batch is NOT the one that arrives (that call packs its own)."""
+    from video_dqn_amd.engine import TDStepper
+    B = 4
+    batches = []
+    for seed in (5, 6, 7, 8):
+        (tup, _) = synth.make_batch(seed, B, 1, structured=True, reward_p=0.3)
+        batches.append((tup[0].contiguous().to(DEV), tup[1].contiguous().to(DEV), 1, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV)))
+    out = []
+    for mode in ("ahead", "plain", "wrong_announcement"):
+        net = make_engine(dtype, seed=7, max_batch=2 * B, deterministic=True)
+        stp = TDStepper(net, B, lr=1e-3, gamma=0.99, clip_rect=True, target_update_interval=3)
+        losses = []
+        for i, b in enumerate(batches):
+            nxt = None
+            if mode == "ahead" and i + 1 < len(batches):
+                nxt = batches[i + 1][:3]
+            if mode == "wrong_announcement":
+                nxt = batches[(i + 2) % len(batches)][:3]
+            losses.append(stp.step(*b, next_frames=nxt).clone())
+        torch.cuda.synchronize()
+        out.append((net.params.clone(), torch.cat(losses)))
+    for k in (1, 2):
+        assert torch.equal(out[0][0], out[k][0]) and torch.equal(out[0][1], out[k][1])
+    assert stp._packed_bufs[0] is not None  # the wrong announcements were packed (and discarded)
+
+
 def _act(net, buf, n_samples, name, shape):
     """View of a named activation inside the engine's workspace (vdqn_net_act_offset)."""
     off = net.lib.vdqn_net_act_offset(net.handle, n_samples, name.encode())

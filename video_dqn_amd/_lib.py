@@ -68,7 +68,7 @@ class StepArgs(C.Structure):
                 ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("train_on_ground_truth", c_i32),
                 ("value_learning", c_i32),
                 ("acts_online", c_vp), ("acts_target", c_vp), ("bwd", c_vp), ("grads", c_vp), ("loss", c_vp),
-                ("q_before", c_vp), ("loss_kind", c_i32)]
+                ("q_before", c_vp), ("loss_kind", c_i32), ("packed_frames", c_vp)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, c_vp, c_vp, c_i64, c_vp)  # vdqn_allreduce_fn(user, buf, count, stream)

@@ -1357,14 +1357,19 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   // pass then simply continues on the side stream: it only reads the packed input and its own weights
   const int64_t frame_bytes = (int64_t)115 * 115 * 16 * net->esz;
   hipStream_t tst = fork_side(net, st);  // == st when the overlap is off
+  // the packed frames of this update: the engine's own buffer, or the caller's (vdqn_step_args.packed_frames: packed ahead of time)
+  const unsigned char* tin = a->packed_frames ? (const unsigned char*)a->packed_frames : ao + A.t_in;
+  const bool prepacked = a->packed_frames != nullptr;
   // VDQN_PACK_AFTER_FIRST=1 (off by default): the s' frames are packed FIRST, on the side stream, and the target pass follows them at
   // once, so that its stem (matrix work) runs beside the caller's stream packing the s frames and folding the weights (HBM work)
   // instead of behind both packs.  Measured on alternating runs: 5.88 vs 5.75-5.77 ms per update — slower
   // (profiles/r03s_ab_pack_after_first.txt); the default keeps both packs on the side stream and the fold beside them.
   static const bool after_first_on = [] { const char* e = getenv("VDQN_PACK_AFTER_FIRST"); return e && e[0] == '1'; }();
-  const bool after_first = after_first_on && tst != st && !gtb && !grouped;
+  const bool after_first = after_first_on && tst != st && !gtb && !grouped && a->packed_frames == nullptr;
   hipEvent_t e_after = nullptr;
-  if (after_first) {
+  if (prepacked) {
+    // nothing to pack
+  } else if (after_first) {
     RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
     e_after = next_event(net);
     (void)hipEventRecord(e_after, tst);
@@ -1395,17 +1400,17 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   if (grouped) {
     // [s; s'] with the online weights and s' with the target's, one chain of launches on the caller's stream (the side stream
     // carries nothing during the forward); the target range's stem reads the packed s' frames of the online range
-    RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, 3 * B, ao, A, st, false, (const unsigned char*)a->packed_target, 2 * B,
-                    ao + A.t_in + (int64_t)B * F * frame_bytes, B, late_weights));
+    RC(forward_impl(net, (const unsigned char*)a->packed_online, tin, 3 * B, ao, A, st, false, (const unsigned char*)a->packed_target, 2 * B,
+                    tin + (int64_t)B * F * frame_bytes, B, late_weights));
   } else if (!gtb) {
     const ActLayout T = act_layout(net, B);
-    RC(forward_impl(net, (const unsigned char*)a->packed_target, ao + A.t_in + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst, false,
+    RC(forward_impl(net, (const unsigned char*)a->packed_target, tin + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst, false,
                     nullptr, 0, nullptr, 0));
   }
   if (grouped) {
     // (done above)
   } else if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
-    RC(forward_train_impl(net, (const unsigned char*)a->packed_online, a->params, a->bnstats, ao + A.t_in, ns_online, gtb ? 1 : 2, ao, A, st));
+    RC(forward_train_impl(net, (const unsigned char*)a->packed_online, a->params, a->bnstats, tin, ns_online, gtb ? 1 : 2, ao, A, st));
   else {
     // VDQN_SPLIT_ONLINE=1: the online pass over [before; after] as two independent half-batch passes on two streams (BatchNorm in
     // eval mode: samples are independent, each half is bit-identical to its part of the 2B pass); with the target pass that
@@ -1416,11 +1421,11 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     hipStream_t s2 = (split && !gtb) ? fork_side2(net, st) : st;
     if (s2 != st) {
       const ActLayout A2 = shift_layout(net, A, B);
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A2.t_in, B, ao, A2, s2, false, nullptr, 0, nullptr, 0, late_weights));
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, B, ao, A, st, false, nullptr, 0, nullptr, -1, late_weights));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, tin + (A2.t_in - A.t_in), B, ao, A2, s2, false, nullptr, 0, nullptr, 0, late_weights));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, tin, B, ao, A, st, false, nullptr, 0, nullptr, -1, late_weights));
       join_side2(net, st);
     } else {
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, ao + A.t_in, ns_online, ao, A, st, false, nullptr, 0, nullptr, B, late_weights));
+      RC(forward_impl(net, (const unsigned char*)a->packed_online, tin, ns_online, ao, A, st, false, nullptr, 0, nullptr, B, late_weights));
     }
   }
   if (tst != st) join_side(net, st);
@@ -1574,7 +1579,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
       for (int b = 3; b >= 0; --b) RC(block_backward_train(net, a, b, A, W, n, st));
       RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
       RC(run_bn_bwd(net, a, net->l_conv1, A, bw + W.g_c1, ao + A.r_c1, bw + W.g_c1, n, st));
-      RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, ao + A.t_in, n, wgrad_stream(net, st)));
+      RC(run_wgrad(net, net->layers[net->l_conv1], bw, bw + W.g_c1, a->packed_frames ? a->packed_frames : ao + A.t_in, n, wgrad_stream(net, st)));
     }
   } else if (stage == 0) {
     const Layer& t4 = net->layers[net->l_top4];
@@ -1643,12 +1648,12 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
       // its unfold below waits for it).  Deterministic mode keeps it on the side stream: the partial copies share one workspace.
       static const bool on_main = [] { const char* e = getenv("VDQN_STEM_WGRAD_MAIN"); return !(e && e[0] == '0'); }();
       const bool main_st = on_main && split_conv1 && !net->cfg.deterministic;
-      return vdqn_stem_wgrad_pool(bw + W.g_pool, ao + A.idx, ao + A.t_in, reinterpret_cast<float*>(bw + L1.dw_off), n,
+      return vdqn_stem_wgrad_pool(bw + W.g_pool, ao + A.idx, a->packed_frames ? a->packed_frames : ao + A.t_in, reinterpret_cast<float*>(bw + L1.dw_off), n,
                                   net->cfg.deterministic ? bw + W.det_ws : nullptr, W.det_ws_bytes, main_st ? st : fork_side(net, st));
     }
     // max-pool backward on the caller's stream, the weight gradient behind it on the side stream
     RC(vdqn_maxpool_bwd(bw + W.g_pool, ao + A.idx, nullptr, bw + W.g_c1, n, 112, 112, 64, dt, st));
-    RC(run_wgrad(net, L1, bw, bw + W.g_c1, ao + A.t_in, n, wgrad_stream(net, st)));
+    RC(run_wgrad(net, L1, bw, bw + W.g_c1, a->packed_frames ? a->packed_frames : ao + A.t_in, n, wgrad_stream(net, st)));
     return VDQN_OK;
   };
   if (stem_tail && !split_conv1) RC(conv1_chain());

@@ -282,6 +282,7 @@ class TDStepper:
         self.sample_number = 0
         self._grad_stream = None  # torch view of the engine's side stream (vdqn_net_grad_stream)
         self._adam_done = []
+        self._packed_bufs, self._ahead = [None, None], None
         self.stage_ranges = [net.stage_range(s) for s in range(3)]
         self.sync_target()
 
@@ -305,9 +306,41 @@ class TDStepper:
         a.acts_online, a.acts_target, a.bwd = _ptr(self.acts_online), _ptr(self.acts_target), _ptr(self.bwd)
         a.grads, a.loss, a.q_before = _ptr(self.grads), _ptr(self.loss), _ptr(self.q_before)
         a.loss_kind = LOSS_KINDS[self.loss_kind]
+        a.packed_frames = None
         return a
 
-    def forward_backward(self, before, after, src_kind, act, rew, term, valid=None, gt=None, early_adam: bool = False):
+    # ---- frames packed one update ahead (vdqn_step_args.packed_frames) -----------------------------------------------------
+    @staticmethod
+    def _frames_key(before, after, src_kind):
+        return (before.data_ptr(), None if after is None else after.data_ptr(), int(src_kind), tuple(before.shape), before.dtype)
+
+    def _packed_buffer(self, slot: int) -> torch.Tensor:
+        if self._packed_bufs[slot] is None:
+            n = self.net
+            esz = 2 if n.dtype_name == "bf16" else 4
+            nbytes = 2 * self.B * n.num_frames * 115 * 115 * 16 * esz
+            self._packed_bufs[slot] = torch.empty(nbytes, dtype=torch.uint8, device=n.device)
+        return self._packed_bufs[slot]
+
+    def _pack_ahead(self, next_frames, slot: int):
+        """Queue vdqn_pack_input for the NEXT update's frames on the engine's gradient stream — behind this update's target pass,
+        i.e. under its head and backward pass — into packed-frame buffer `slot` (the other one is being read by this update)."""
+        nb, na, nk = next_frames
+        n = self.net
+        buf = self._packed_buffer(slot)
+        nf = self.B * n.num_frames
+        half = buf.numel() // 2
+        dt = _lib.VDQN_BF16 if n.dtype_name == "bf16" else _lib.VDQN_F32
+        main = torch.cuda.current_stream()
+        with self._grad_stream_ctx():
+            # the announced tensors may have been produced on the caller's stream a moment ago (a host-to-device copy, a gather)
+            torch.cuda.current_stream().wait_stream(main)
+            _lib.check(self.lib.vdqn_pack_input(_ptr(nb), int(nk), buf.data_ptr(), nf, dt, _stream()), "vdqn_pack_input")
+            if na is not None and not self.gtb:
+                _lib.check(self.lib.vdqn_pack_input(_ptr(na), int(nk), buf.data_ptr() + half, nf, dt, _stream()), "vdqn_pack_input")
+        self._ahead = (self._frames_key(nb, na, nk), slot, (nb, na))  # (the tensors are kept alive until they are consumed)
+
+    def forward_backward(self, before, after, src_kind, act, rew, term, valid=None, gt=None, early_adam: bool = False, next_frames=None):
         """Everything of one update up to (and including) the gradient all-reduce; no optimiser step.
 
         early_adam (only `step` passes it: single process, no exchange, eval-mode BatchNorm): the optimiser update of stage 0 and stage 1 is
@@ -320,7 +353,14 @@ class TDStepper:
         with torch.cuda.device(n.device):
             a = self._args(before, after, src_kind, act, rew, term, valid if valid is not None else self._ones, gt)
             st = _stream()
+            ahead, self._ahead = self._ahead, None
+            slot = None
+            if ahead is not None and ahead[0] == self._frames_key(before, after, src_kind):
+                slot = ahead[1]  # these frames were packed during the previous update (ordered in front of `st` by its last stage)
+                a.packed_frames = self._packed_buffer(slot).data_ptr()
             _lib.check(self.lib.vdqn_net_td_forward(n.handle, C.byref(a), st), "vdqn_net_td_forward")
+            if next_frames is not None:
+                self._pack_ahead(next_frames, 1 if slot == 0 else 0)
             if not n.extra_capacity:  # train-mode BatchNorm: model(before) [+ model(after)], F feature calls each
                 n.num_batches_tracked += (1 if self.gtb else 2) * n.num_frames
                 n.mark_dirty()  # the running statistics changed: eval-mode packed weights are stale
@@ -369,16 +409,24 @@ class TDStepper:
                 pos = max(pos, e)
         n.mark_dirty()
 
-    def step(self, before, after, src_kind, act, rew, term, valid=None, gt=None, finish_allreduce=None) -> torch.Tensor:
+    def step(self, before, after, src_kind, act, rew, term, valid=None, gt=None, finish_allreduce=None, next_frames=None) -> torch.Tensor:
         """One iteration of the reference loop body (train_q_network.py:213-227).  Returns the device loss scalar
-        (no host sync)."""
+        (no host sync).
+
+        next_frames = (before, after, src_kind) of the NEXT call, if the loop already has them (the reference's DataLoader does: it
+        prefetches): they are normalised and packed for the stem while this update's head and backward pass run, instead of at
+        the start of the next update.  The tensors must not change until that call; a call whose frames are not the ones
+        announced packs its own, as always.  Same arithmetic, same results — and, measured, a SLOWER update (5.81 against 5.74 ms,
+        profiles/r03w_ab_pack_ahead.txt: the HBM-bound pack beside layer4 and the head costs more than the start of the update
+        gains), so neither bench.py nor the trainer uses it by default; it stays for callers whose frames arrive packed
+        (vdqn_step_args.packed_frames)."""
         self.sample_number += 1
         if self.sample_number % self.tui == 0:
             self.sync_target()
         # (single process only: behind each RCCL bucket on a stream of its own it measured 7.22 vs 5.96 ms per update with one rank,
         # profiles/r03s_ab_rccl_early_adam.txt — with an exchange the whole optimiser update stays behind `finish_allreduce`)
         early = _EARLY_ADAM and self.net.extra_capacity and self.allreduce is None and finish_allreduce is None
-        self.forward_backward(before, after, src_kind, act, rew, term, valid, gt, early_adam=early)
+        self.forward_backward(before, after, src_kind, act, rew, term, valid, gt, early_adam=early, next_frames=next_frames)
         if finish_allreduce is not None:
             finish_allreduce()
         self.optimizer_step()
