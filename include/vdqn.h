@@ -187,7 +187,7 @@ int vdqn_gt_loss(const float* q_before, const int64_t* act, const float* gt, flo
  * (torchvision resnet.py conv1/bn1/relu/maxpool; archs/HabitatDQNMultiAction.py:30).  Writes pool [n][56][56][64] and
  * the argmax codes idx (as vdqn_maxpool_fwd); the 112x112x64 convolution output is never stored.  Results are
  * bit-identical to vdqn_conv2d followed by vdqn_maxpool_fwd.  idx may be NULL for frames that never see a backward pass
- * (the torch.no_grad() target pass and the s' rows of the online pass, train_q_network.py:138-142): pool is the same,
+ * (the target pass, whose result is `.detach()`ed, and the s' rows of the online pass, which only feed an argmax: train_q_network.py:140-142,148,155-156 — the reference builds their graphs and never back-propagates through them): pool is the same,
  * the arg-max bytes are not computed. */
 int vdqn_stem_conv_pool(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img,
                         int32_t dtype, void* stream);
@@ -389,6 +389,9 @@ typedef struct vdqn_step_args {
                                  arrive packed (or that pack the NEXT minibatch during this update: the loader of
                                  train_q_network.py:213 has it a step ahead — measured slower on one GPU).
                                  NULL: the update packs them itself. */
+  int32_t acts_samples;       /* 0: `acts_online` is laid out as vdqn_net_td_forward leaves it (2B samples, 3B grouped, B on the
+                                 ground-truth branch).  > 0: `acts_online` is the workspace of ONE vdqn_net_forward call over that
+                                 many samples (== batch) — the backward of a single model call, vdqn_net_backward_begin below. */
 } vdqn_step_args;
 int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream);
 /* Stage s of the backward pass (0: head + layer4, 1: layer3, 2: layer2, layer1, stem).  With the overlap on, the stage's weight
@@ -397,6 +400,15 @@ int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream);
  * for stage 2 makes `stream` wait for the side stream, so vdqn_adam on `stream` sees every gradient.  A consumer of one stage's
  * gradients (the data-parallel all-reduce) orders itself behind vdqn_net_grad_stream. */
 int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream);
+/* Backward of ONE earlier vdqn_net_forward(net, packed, frames, .., B, acts, ..) call from a caller-supplied dL/dQ: what
+ * torch.autograd runs for `before_values = model(before)` when the reference's own loop calls loss.backward()
+ * (train_q_network.py:131,226) on the HIP-backed module (video_dqn_amd/model.py).  `a` carries params, bnstats, packed_online
+ * (the SAME packed weights the forward used, packed with the data-gradient operands: vdqn_net_pack_weights bit 0),
+ * acts_online = that call's `acts`, batch = acts_samples = B, bwd, grads; the loss fields are not read.  dq_f32 is
+ * f32 [B][num_classes*action_dim].  This call clears the weight-gradient accumulators and converts dq; the caller then runs
+ * vdqn_net_backward_stage(net, a, 0..2) as after vdqn_net_td_forward.  extra_capacity only (eval-mode BatchNorm: the three
+ * model calls of process_batch are independent, so each has its own backward). */
+int vdqn_net_backward_begin(vdqn_net* net, const vdqn_step_args* a, const float* dq_f32, void* stream);
 /* The HIP stream (hipStream_t) on which a stage's gradients become complete; NULL when the overlap is off (then it is the
  * stream passed to vdqn_net_backward_stage). */
 void* vdqn_net_grad_stream(vdqn_net* net);

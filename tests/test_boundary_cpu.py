@@ -138,6 +138,15 @@ def test_pretrained_weights_land_in_the_trunk(tmp_path):
     # wrapped forms: {'state_dict': ...} with DataParallel's 'module.' prefix (the Places365 release format)
     assert load_torchvision_resnet18(m.engine, {"state_dict": {"module." + k: v for k, v in sd.items()}}) == 102
     assert torch.equal(m.state_dict()["resnet.layer3.1.conv2.weight"], sd["layer3.1.conv2.weight"])
+    # a Places365 ResNet-18 (365-way classifier): every tensor the Q-network computes with is loaded, the off-path fc is skipped
+    m2 = HabitatDQNMultiAction(3, 5, extra_capacity=True, panorama=False, device="cpu")
+    fc_before = m2.state_dict()["resnet.fc.weight"].clone()
+    places = {"state_dict": {"module." + k: v for k, v in sd.items()}}
+    places["state_dict"]["module.fc.weight"], places["state_dict"]["module.fc.bias"] = torch.zeros(365, 512), torch.zeros(365)
+    with pytest.warns(UserWarning, match="classifier fc"):
+        assert load_torchvision_resnet18(m2.engine, places) == 100
+    assert torch.equal(m2.state_dict()["resnet.layer4.1.bn2.running_var"], sd["layer4.1.bn2.running_var"])
+    assert torch.equal(m2.state_dict()["resnet.fc.weight"], fc_before)
 
 
 def test_checkpoint_roundtrip_into_oracle_and_adam(tmp_path):

@@ -256,7 +256,7 @@ def test_basic_td_steps_match_reference_golden_f32(golden_basic, tag, pano, F, B
             assert np.concatenate(tight).mean() >= 0.99
 
 
-@pytest.mark.parametrize("F,B", [(1, 6), (4, 3)])
+@pytest.mark.parametrize("F,B", [(1, 6), (4, 3), (1, 32)])
 def test_basic_td_step_all_elements_vs_oracle_f32(F, B):
     """Every gradient element of one update against the oracle run live in float64 and float32 on the host: the engine's
     distance to the float64 gradients must be within 1e-3 (L2) / 5e-3 (max) or within 1.5x the fp32 oracle's own distance.
@@ -292,6 +292,9 @@ def test_basic_td_step_all_elements_vs_oracle_f32(F, B):
         worst["ref_max"] = max(worst["ref_max"], ((g32 - r).abs().max() / r.abs().max()).item())
         worst["ref_l2"] = max(worst["ref_l2"], ((g32 - r).norm() / r.norm()).item())
     print("worst gradient error vs float64:", worst)
+    import warnings  # (B = 32: does the chaos of batch statistics condition with the batch?  the numbers land in the -q log)
+    warnings.warn(f"basic f32 gate F={F} B={B}: engine vs float64 max {worst['eng_max']:.3g} L2 {worst['eng_l2']:.3g}; fp32 oracle's own "
+                  f"max {worst['ref_max']:.3g} L2 {worst['ref_l2']:.3g}; plain 1e-3 L2 line {'holds' if worst['eng_l2'] <= 1e-3 else 'does not hold'}")
     assert worst["eng_max"] <= max(5e-3, 1.5 * worst["ref_max"]), worst
     assert worst["eng_l2"] <= max(1e-3, 1.5 * worst["ref_l2"]), worst
     # the default (atomic-sum) mode: same loss, and as close to float64 as twice the fp32 oracle (run-to-run spread, see above)

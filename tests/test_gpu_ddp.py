@@ -40,13 +40,13 @@ def _run(net_stepper, tup, lo, hi, finish=None):
 def _make(B, world, hook=None):
     from video_dqn_amd import synth
     from video_dqn_amd.engine import NetEngine, TDStepper
-    net = NetEngine(3, 5, 1, True, "f32", 2 * B)
+    net = NetEngine(3, 5, 1, True, "f32", 2 * B, deterministic=True)
     net.load_tensors(synth.make_state_dict(7))
     stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, world_size=world, allreduce=hook)
     return net, stp
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, per_rank=4):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -59,24 +59,29 @@ def _worker(rank, world, port, out_dir):
         dist.all_reduce(h)
         grad_slice.copy_(h)
 
-    ns = _make(4, world, hook)
+    ns = _make(per_rank, world, hook)
     for step in (1, 2):
-        tup = _batch(200 + step, 8)
-        _run(ns, tup, rank * 4, rank * 4 + 4)
+        tup = _batch(200 + step, per_rank * world)
+        _run(ns, tup, rank * per_rank, (rank + 1) * per_rank)
     torch.save({"params": ns[0].params.cpu(), "loss": ns[1].loss.cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_big_batch(tmp_path):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    r0 = torch.load(tmp_path / "rank0.pt")
-    r1 = torch.load(tmp_path / "rank1.pt")
-    assert torch.equal(r0["params"], r1["params"])  # replicas stay bit-identical: same reduced gradient, same Adam
-    ns = _make(8, 1)
+@pytest.mark.parametrize("world,per_rank", [(2, 4), (4, 2), (8, 2)], ids=["world2", "world4", "world8"])
+def test_n_ranks_equal_one_big_batch(tmp_path, world, per_rank):
+    """N ranks x per_rank samples == ONE process on the N * per_rank samples (the reference is one process,
+    train_q_network.py:255-259,275): after two updates every replica holds bit-identical parameters (same reduced gradient,
+    same Adam), and they equal the big-batch run's up to the summation order of the gradient (f32, deterministic mode).
+    Arithmetic, not plumbing: world 4 and 8 run the same bound as world 2."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), per_rank), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    r0 = ranks[0]
+    for r in ranks[1:]:
+        assert torch.equal(r0["params"], r["params"])  # replicas stay bit-identical: same reduced gradient, same Adam
+    ns = _make(per_rank * world, 1)
     for step in (1, 2):
-        _run(ns, _batch(200 + step, 8), 0, 8)
+        _run(ns, _batch(200 + step, per_rank * world), 0, per_rank * world)
     big = ns[0].params.cpu()
     nt = ns[0].trainable_numel
     delta = (big[:nt] - r0["params"][:nt]).abs().max().item()
@@ -84,7 +89,7 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
     # 2 Adam steps of lr 1e-4 move weights by <= 2e-4; the two runs must agree to a small fraction of that
     assert delta <= 2.5e-4 and (big[:nt] - r0["params"][:nt]).abs().mean().item() < 2e-6
     # the per-rank partial losses sum to the big-batch loss
-    assert abs((r0["loss"] + r1["loss"]).item() - ns[1].loss.item()) < 1e-5 * abs(ns[1].loss.item()) + 1e-7
+    assert abs(sum(r["loss"] for r in ranks).item() - ns[1].loss.item()) < 1e-5 * abs(ns[1].loss.item()) + 1e-7
 
 
 # ---- ARCHITECTURE='basic': train-mode BatchNorm needs global statistics (SyncBN) for N ranks == one big batch ----

@@ -605,6 +605,37 @@ def test_deterministic_mode_is_bit_identical_run_to_run(dtype, B):
     assert abs(a[2][0] - c[2][0]) <= 1e-6 * abs(c[2][0])
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("bf16", 1e-4)])
+def test_default_schedule_gradients_equal_deterministic_per_tensor(dtype, tol):
+    """The DEFAULT placement (atomic split-K sums, weight gradients on the side stream, conv1's weight gradient on the caller's
+    stream beside block 0's: VDQN_STEM_WGRAD_MAIN, early Adam off here) against deterministic mode (one weight-gradient stream,
+    ordered sums) and against the serialised schedule, ONE update, per gradient tensor: relative L2 within f32 summation order.
+    The data-gradient chain is the same arithmetic in all three, only the order of the weight-gradient partial sums differs — a
+    kernel reading a buffer before its producer on another stream has finished would show as an O(1) tensor error here."""
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    B = 16
+    (tup, raw) = synth.make_batch(811, B, 1, structured=True, reward_p=0.3)
+    args = (torch.from_numpy(raw[0]).to(DEV), torch.from_numpy(raw[1]).to(DEV), 0, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV))
+
+    def run(det, overlap):
+        net = NetEngine(3, 5, 1, True, dtype, 2 * B, deterministic=det)
+        net.load_tensors(synth.make_state_dict(7))
+        stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True)
+        net.lib.vdqn_net_set_overlap(net.handle, overlap)
+        stp.forward_backward(*args)
+        torch.cuda.synchronize()
+        return net, stp.grads.clone(), stp.loss.item()
+
+    net, g_det, l_det = run(True, 1)
+    for rep in range(3):
+        for overlap in (1, 0):
+            _, g, l = run(False, overlap)
+            assert abs(l - l_det) <= 1e-6 * abs(l_det)
+            for name, s in net.slots.items():
+                if s.kind == 0:
+                    assert l2err(g[s.offset:s.offset + s.numel], g_det[s.offset:s.offset + s.numel]) <= tol, (name, overlap, rep)
+
+
 def test_deterministic_wgrad_operator_matches_atomic_mode():
     """vdqn_conv2d_wgrad with a workspace (ordered two-stage reduction) against the atomic mode, every kernel variant:
     window 64x64 (layer1-3 geometry), generic 128 (layer4, stride 2), generic 64 (1x1 / stride 2), the stem kernel."""

@@ -64,7 +64,11 @@ def test_bench_single_rank_through_rccl():
     # and the throughput mode (bf16, atomic sums): same data, same updates, not bit-equal
     a = _bench(["--gpus", "1", "--force-dist"] + SMALL)
     b = _bench(["--gpus", "1"] + SMALL)
-    assert a["loss"] == pytest.approx(b["loss"], rel=0.1)  # (atomic sums + bf16: two runs of the SAME command differ by up to ~3 % after three updates)
+    # (atomic sums + bf16 at batch 4: Adam turns rounding-level gradient elements into +-lr steps, two runs of the SAME command differ by
+    # up to ~3 % in the loss after three updates.  The per-update statement is tests/test_gpu_engine.py::
+    # test_default_schedule_gradients_equal_deterministic_per_tensor: one update of the default schedule equals deterministic mode to
+    # 1e-5 (f32) / 1e-4 (bf16) relative L2 in every gradient tensor.)
+    assert a["loss"] == pytest.approx(b["loss"], rel=0.1)
 
 
 def test_bench_eight_ranks_on_one_device_gloo():

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", f"libvdqn{'_' + os.environ['VDQN_LIB'] if os.environ.get('VDQN_LIB') else ''}.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -68,7 +68,7 @@ class StepArgs(C.Structure):
                 ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("train_on_ground_truth", c_i32),
                 ("value_learning", c_i32),
                 ("acts_online", c_vp), ("acts_target", c_vp), ("bwd", c_vp), ("grads", c_vp), ("loss", c_vp),
-                ("q_before", c_vp), ("loss_kind", c_i32), ("packed_frames", c_vp)]
+                ("q_before", c_vp), ("loss_kind", c_i32), ("packed_frames", c_vp), ("acts_samples", c_i32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, c_vp, c_vp, c_i64, c_vp)  # vdqn_allreduce_fn(user, buf, count, stream)
@@ -123,6 +123,7 @@ _SIGS = {
     "vdqn_net_forward_train": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vdqn_net_td_forward": (C.c_int, [c_vp, C.POINTER(StepArgs), c_vp]),
     "vdqn_net_backward_stage": (C.c_int, [c_vp, C.POINTER(StepArgs), c_i32, c_vp]),
+    "vdqn_net_backward_begin": (C.c_int, [c_vp, C.POINTER(StepArgs), c_vp, c_vp]),
     "vdqn_comm_unique_id": (C.c_int, [c_vp]),
     "vdqn_comm_init": (C.c_int, [c_i32, c_i32, c_vp, C.POINTER(c_vp)]),
     "vdqn_allreduce_bucket": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),

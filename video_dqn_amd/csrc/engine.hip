@@ -29,7 +29,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 9; }
+extern "C" int vdqn_abi_version(void) { return 10; }
 
 namespace {
 
@@ -1329,6 +1329,7 @@ static bool step_grouped(const vdqn_net* net, const vdqn_step_args* a) {
 }
 // samples the `acts_online` workspace of this update is laid out for
 static int step_layout_samples(const vdqn_net* net, const vdqn_step_args* a) {
+  if (a->acts_samples > 0) return a->acts_samples;  // the workspace of one vdqn_net_forward call (vdqn_net_backward_begin)
   if (a->train_on_ground_truth) return a->batch;
   return step_grouped(net, a) ? 3 * a->batch : 2 * a->batch;
 }
@@ -1545,6 +1546,38 @@ int block_backward_train(vdqn_net* net, const vdqn_step_args* a, int b, const Ac
 }
 
 }  // namespace
+
+// dL/dQ f32 [B][nq] -> the engine's [B][64] operand of the head's backward (zero padded)
+template <typename T>
+__global__ __launch_bounds__(256) void dq_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int nq) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * 64) return;
+  const int b = i >> 6, c = i & 63;
+  dst[i] = from_f32<T>(c < nq ? src[(long)b * nq + c] : 0.f);
+}
+
+extern "C" int vdqn_net_backward_begin(vdqn_net* net, const vdqn_step_args* a, const float* dq_f32, void* stream) {
+  VDQN_CHECK(net && a && dq_f32, "vdqn_net_backward_begin: null arg");
+  VDQN_CHECK(!net->basic(), "vdqn_net_backward_begin: only extra_capacity (eval-mode BatchNorm) has a per-call backward; ARCHITECTURE='basic' trains through vdqn_net_td_forward");
+  VDQN_CHECK(a->params && a->bnstats && a->packed_online && a->acts_online && a->bwd && a->grads, "vdqn_net_backward_begin: null buffer");
+  VDQN_CHECK(a->batch >= 1 && a->batch <= net->cfg.max_batch && a->acts_samples == a->batch,
+             "vdqn_net_backward_begin: acts_samples (%d) must equal batch (%d) <= max_batch", a->acts_samples, a->batch);
+  hipStream_t st = (hipStream_t)stream;
+  const int B = a->batch;
+  const BwdLayout W = bwd_layout(net, B);
+  net->bwd_samples = B;
+  unsigned char* bw = (unsigned char*)a->bwd;
+  hipError_t e = hipMemsetAsync(bw + W.zero_begin, 0, (size_t)W.zero_bytes, st);
+  VDQN_CHECK(e == hipSuccess, "vdqn_net_backward_begin: memset failed: %s", hipGetErrorString(e));
+  const int nq = net->cfg.action_dim * net->cfg.num_classes;
+  const int blocks = (B * 64 + 255) / 256;
+  if (net->cfg.dtype == VDQN_BF16)
+    hipLaunchKernelGGL((dq_pad_kernel<bf16raw>), dim3(blocks), dim3(256), 0, st, dq_f32, reinterpret_cast<bf16raw*>(bw + W.dq), B, nq);
+  else
+    hipLaunchKernelGGL((dq_pad_kernel<float>), dim3(blocks), dim3(256), 0, st, dq_f32, reinterpret_cast<float*>(bw + W.dq), B, nq);
+  VDQN_LAUNCH_CHECK();
+  return VDQN_OK;
+}
 
 extern "C" void* vdqn_net_grad_stream(vdqn_net* net) {
   if (!net || !side_ready(net)) return nullptr;

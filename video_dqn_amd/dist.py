@@ -25,6 +25,29 @@ class BucketAllReduce:
         self.force = force  # issue the collectives even at world size 1 (exercises RCCL + the stream ordering on one GPU)
         self._works: List = []
         self.bucket_bytes: List[int] = []  # sizes of the buckets reduced in the last update, in launch order
+        self._loss_bufs = [None, None]     # launch_loss: two device scalars used in turn
+        self._loss_slot = 0
+        self._loss_pending = None
+
+    def launch_loss(self, loss: torch.Tensor) -> None:
+        """SUM the ranks' shares of the global-batch mean loss (train_q_network.py:180,228-231) WITHOUT the compute stream ever
+        waiting for it: called behind the last gradient bucket (the stream on which that bucket was launched is current), the
+        4-byte collective goes into a buffer of its own and only `take_loss`'s consumer — the trainer's loss read-back stream,
+        one update late — waits for it."""
+        if self.world_size == 1 and not self.force:
+            return
+        self._loss_slot ^= 1
+        buf = self._loss_bufs[self._loss_slot]
+        if buf is None or buf.device != loss.device:
+            buf = self._loss_bufs[self._loss_slot] = torch.zeros(1, dtype=torch.float32, device=loss.device)
+        buf.copy_(loss.reshape(1))
+        self._loss_pending = (buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def take_loss(self):
+        """-> (device scalar, async work) of the last `launch_loss`, or None.  work.wait() orders the CURRENT stream behind the
+        collective: call it on the stream that reads the value, not on the compute stream."""
+        p, self._loss_pending = self._loss_pending, None
+        return p
 
     def launch(self, grad_slice: torch.Tensor, stage: int) -> None:
         if self.world_size == 1 and not self.force:
@@ -43,7 +66,9 @@ class BucketAllReduce:
 class CAbiBucketAllReduce:
     """The same exchange through the C ABI's own RCCL entries (include/vdqn.h: vdqn_comm_init / vdqn_allreduce_bucket) instead
     of torch.distributed — what a caller that binds the header without PyTorch's process group does.  The 128-byte
-    rendezvous id travels through a file (`uid_path`: rank 0 writes it, the others wait for it).  Same contract as
+    rendezvous id travels through a file (`uid_path` + a per-job nonce — MASTER_PORT / VDQN_JOB_NONCE, so an id left behind by an
+    earlier or crashed job at the same path is never picked up; rank 0 writes it, the others wait for it, rank 0 removes it once
+    every rank has joined).  Same contract as
     BucketAllReduce: ``launch`` is called with the stream current on which the stage's gradients are complete and queues the
     collective there; ``finish`` makes the then-current stream wait for all queued collectives."""
 
@@ -57,7 +82,11 @@ class CAbiBucketAllReduce:
         self.world_size, self.force = world_size, force
         self.bucket_bytes: List[int] = []
         self._events: List = []
+        self._loss_bufs, self._loss_slot, self._loss_pending = [None, None], 0, None
         uid = C.create_string_buffer(_lib.COMM_UID_BYTES)
+        nonce = os.environ.get("VDQN_JOB_NONCE") or os.environ.get("MASTER_PORT") or os.environ.get("VDQN_LAUNCHER_PID") or "0"
+        uid_path = f"{uid_path}.{nonce}"
+        self._uid_path = uid_path if rank == 0 else None
         if rank == 0:
             _lib.check(self.lib.vdqn_comm_unique_id(uid), "vdqn_comm_unique_id")
             tmp = uid_path + ".tmp"
@@ -73,6 +102,11 @@ class CAbiBucketAllReduce:
             uid.raw = open(uid_path, "rb").read()
         self.handle = C.c_void_p()
         _lib.check(self.lib.vdqn_comm_init(rank, world_size, uid, C.byref(self.handle)), "vdqn_comm_init")
+        if self._uid_path:  # ncclCommInitRank returns once every rank has joined: the id has served its purpose
+            try:
+                os.unlink(self._uid_path)
+            except OSError:
+                pass
 
     def launch(self, grad_slice: torch.Tensor, stage: int) -> None:
         if self.world_size == 1 and not self.force:
@@ -92,6 +126,32 @@ class CAbiBucketAllReduce:
         for ev in self._events:
             cur.wait_event(ev)
         self._events.clear()
+
+    class _EventWork:  # the `work` of take_loss(): wait() orders the current stream behind the collective
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def launch_loss(self, loss: torch.Tensor) -> None:
+        """As BucketAllReduce.launch_loss: the loss shares are summed on the gradient stream behind the last bucket."""
+        if self.world_size == 1 and not self.force:
+            return
+        self._loss_slot ^= 1
+        buf = self._loss_bufs[self._loss_slot]
+        if buf is None:
+            buf = self._loss_bufs[self._loss_slot] = torch.zeros(1, dtype=torch.float32, device=loss.device)
+        buf.copy_(loss.reshape(1))
+        st = torch.cuda.current_stream()
+        self._lib.check(self.lib.vdqn_allreduce_bucket(self.handle, buf.data_ptr(), 1, self._lib.VDQN_F32, st.cuda_stream), "vdqn_allreduce_bucket")
+        ev = torch.cuda.Event()
+        ev.record(st)
+        self._loss_pending = (buf, self._EventWork(ev))
+
+    def take_loss(self):
+        p, self._loss_pending = self._loss_pending, None
+        return p
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -95,7 +95,7 @@ class NetEngine:
         # whose BatchNorm layers run in train mode)
         self.num_batches_tracked = torch.zeros(20, dtype=torch.long, device=self.device)
         self.packed = None if self.storage_only else torch.zeros(self.packed_bytes, dtype=torch.uint8, device=self.device)
-        self._packed_version = -1
+        self._packed_version = None
         self._version = 0
         self._acts: Dict[int, torch.Tensor] = {}
 
@@ -126,8 +126,14 @@ class NetEngine:
         self.mark_dirty()
 
     def mark_dirty(self):
-        """Call after the master parameters changed (load_state_dict, optimiser step)."""
+        """Call after the master parameters changed through raw pointers (the Adam kernel, a broadcast)."""
         self._version += 1
+
+    def version_key(self):
+        """Identifies the parameter values the packed weights were made from: the explicit counter above plus the autograd
+        version counters of the flat arrays, which every in-place torch op on a view of them (the module's Parameters under a
+        torch optimiser, load_state_dict) advances."""
+        return (self._version, self.params._version, self.bnstats._version)
 
     # ---- packing + forward -----------------------------------------------------------------------
     def _need_gpu(self):
@@ -161,14 +167,50 @@ class NetEngine:
         if n_samples > self.max_batch:
             raise _lib.VdqnError(f"batch {n_samples} exceeds max_batch {self.max_batch}")
         with torch.cuda.device(self.device):
-            if self._packed_version != self._version:
+            if self._packed_version != self.version_key():
                 self.pack_weights()
-                self._packed_version = self._version
+                self._packed_version = self.version_key()
             q = torch.empty((n_samples, self.num_classes * self.action_dim), dtype=torch.float32, device=self.device)
             acts = self._acts_for(n_samples)
             _lib.check(self.lib.vdqn_net_forward(self.handle, _ptr(self.packed), _ptr(frames), src_kind, n_samples,
                                                  _ptr(acts), _ptr(q), _stream()), "vdqn_net_forward")
         return q
+
+    # ---- one model call with its own backward (torch.autograd over the module, model.py) ----------------------------
+    def forward_saved(self, frames: torch.Tensor, src_kind: int, n_samples: int, packed: torch.Tensor):
+        """`vdqn_net_forward` into a workspace of its own that the caller keeps for `backward_from_dq`: -> (q, acts).
+        `packed` must hold this network's weights packed WITH the data-gradient operands (`pack_weights(.., with_dgrad=True)`)."""
+        self._need_gpu()
+        if n_samples > self.max_batch:
+            raise _lib.VdqnError(f"batch {n_samples} exceeds max_batch {self.max_batch}")
+        with torch.cuda.device(self.device):
+            q = torch.empty((n_samples, self.num_classes * self.action_dim), dtype=torch.float32, device=self.device)
+            acts = torch.empty(self.acts_bytes(n_samples), dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.vdqn_net_forward(self.handle, _ptr(packed), _ptr(frames), src_kind, n_samples, _ptr(acts), _ptr(q),
+                                                 _stream()), "vdqn_net_forward")
+        return q, acts
+
+    def backward_from_dq(self, acts: torch.Tensor, packed: torch.Tensor, dq: torch.Tensor, n_samples: int) -> torch.Tensor:
+        """Backward of one `forward_saved` call from dL/dQ (f32 [n_samples, num_classes*action_dim]): the flat f32 gradient
+        over the trainable range, complete on the current stream (loss.backward() through `model(before)`,
+        train_q_network.py:131,226).  extra_capacity only."""
+        self._need_gpu()
+        with torch.cuda.device(self.device):
+            bwd = getattr(self, "_bwd_ws", None)
+            if bwd is None or bwd[0] != n_samples:
+                bwd = self._bwd_ws = (n_samples, torch.empty(self.bwd_bytes(n_samples), dtype=torch.uint8, device=self.device))
+            grads = torch.zeros(self.trainable_numel, dtype=torch.float32, device=self.device)
+            dq = dq.to(device=self.device, dtype=torch.float32).contiguous()
+            a = _lib.StepArgs()
+            a.params, a.bnstats, a.packed_online = _ptr(self.params), _ptr(self.bnstats), _ptr(packed)
+            a.batch = a.acts_samples = n_samples
+            a.acts_online, a.bwd, a.grads = _ptr(acts), _ptr(bwd[1]), _ptr(grads)
+            st = _stream()
+            _lib.check(self.lib.vdqn_net_backward_begin(self.handle, C.byref(a), _ptr(dq), st), "vdqn_net_backward_begin")
+            for stage in range(3):  # stage 2 joins the engine's gradient stream back into `st`
+                _lib.check(self.lib.vdqn_net_backward_stage(self.handle, C.byref(a), stage, st), "vdqn_net_backward_stage")
+            dq.record_stream(torch.cuda.current_stream())
+        return grads
 
     # ---- SyncBN (ARCHITECTURE='basic' under data parallelism) ----------------------------------------
     def set_bn_sync(self, world_size: int, allreduce=None) -> None:
@@ -221,7 +263,7 @@ class NetEngine:
             q = torch.empty((n_samples, self.num_classes * self.action_dim), dtype=torch.float32, device=self.device)
             acts = self._acts_for(n_samples)
             self.register_sync_buffer(acts)
-            self._packed_version = -1  # self.packed now holds the un-folded weights
+            self._packed_version = None  # self.packed now holds the un-folded weights
             _lib.check(self.lib.vdqn_net_forward_train(self.handle, _ptr(self.params), _ptr(self.bnstats), _ptr(self.packed),
                                                        _ptr(frames), src_kind, n_samples, _ptr(acts), _ptr(q), _stream()),
                        "vdqn_net_forward_train")
@@ -238,7 +280,7 @@ class TDStepper:
     def __init__(self, net: NetEngine, batch: int, lr: float, gamma: float, clip_rect: bool, linear: bool = False,
                  remove_before_reward: bool = False, train_on_ground_truth: bool = False, value_learning: bool = False,
                  target_update_interval: int = 8000, betas=(0.9, 0.999), eps: float = 1e-8, world_size: int = 1,
-                 allreduce=None, loss_kind: str = "l2", grouped_forward: Optional[bool] = None):
+                 allreduce=None, loss_kind: str = "l2", grouped_forward: Optional[bool] = None, allreduce_loss=None):
         net._need_gpu()
         self.net, self.B = net, batch
         self.lib = net.lib
@@ -253,6 +295,9 @@ class TDStepper:
         self.tui = target_update_interval
         self.world_size = world_size
         self.allreduce = allreduce  # callable(tensor_slice, stage) or None
+        # callable(loss) or None: called once per update behind the LAST gradient bucket, on the gradient stream — the exchange
+        # sums the ranks' loss shares there, so the compute stream never waits for a 4-byte collective (dist.launch_loss)
+        self.allreduce_loss = allreduce_loss
         dev = net.device
         nt = net.trainable_numel
         with torch.cuda.device(dev):
@@ -312,7 +357,10 @@ class TDStepper:
     # ---- frames packed one update ahead (vdqn_step_args.packed_frames) -----------------------------------------------------
     @staticmethod
     def _frames_key(before, after, src_kind):
-        return (before.data_ptr(), None if after is None else after.data_ptr(), int(src_kind), tuple(before.shape), before.dtype)
+        # identity AND content version: a loop that refills fixed staging buffers in place (copy_ advances `_version`) announces
+        # a different key than the one that arrives, so the stale pack is discarded and the call packs its own frames
+        return (before.data_ptr(), None if after is None else after.data_ptr(), int(src_kind), tuple(before.shape), before.dtype,
+                before._version, None if after is None else after._version)
 
     def _packed_buffer(self, slot: int) -> torch.Tensor:
         if self._packed_bufs[slot] is None:
@@ -360,6 +408,10 @@ class TDStepper:
                 a.packed_frames = self._packed_buffer(slot).data_ptr()
             _lib.check(self.lib.vdqn_net_td_forward(n.handle, C.byref(a), st), "vdqn_net_td_forward")
             if next_frames is not None:
+                mine = {before.data_ptr(), None if after is None else after.data_ptr()} - {None}
+                if next_frames[0].data_ptr() in mine or (next_frames[1] is not None and next_frames[1].data_ptr() in mine):
+                    raise _lib.VdqnError("next_frames alias this call's before/after tensors: a buffer that is refilled for the next "
+                                         "call cannot be packed ahead (it still holds THIS call's frames) — pass distinct tensors")
                 self._pack_ahead(next_frames, 1 if slot == 0 else 0)
             if not n.extra_capacity:  # train-mode BatchNorm: model(before) [+ model(after)], F feature calls each
                 n.num_batches_tracked += (1 if self.gtb else 2) * n.num_frames
@@ -372,6 +424,8 @@ class TDStepper:
                     b, e = self.stage_ranges[stage]
                     with self._grad_stream_ctx():
                         self.allreduce(self.grads[b:e], stage)
+                        if stage == 2 and self.allreduce_loss is not None:
+                            self.allreduce_loss(self.loss)
                 elif early_adam and stage < 2:
                     b, e = self.stage_ranges[stage]
                     b, e = (b + 3) // 4 * 4, e // 4 * 4  # vdqn_adam wants 16-byte aligned ranges; the rest is left to optimizer_step

@@ -138,9 +138,9 @@ class InverseActionModel(nn.Module):
             return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         frames = frames.to(eng.device).contiguous()
         with torch.cuda.device(eng.device):
-            if eng._packed_version != eng._version:
+            if eng._packed_version != eng.version_key():
                 eng.pack_weights()
-                eng._packed_version = eng._version
+                eng._packed_version = eng.version_key()
             if self._packed_head is None:
                 self._pack_head()
             acts = eng._acts_for(2 * B)

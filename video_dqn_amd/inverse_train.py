@@ -79,9 +79,9 @@ class InverseTrainer:
         frames = (torch.cat([k, k_plus_one], 0) if src_kind == 0 else torch.cat([k.float(), k_plus_one.float()], 0)).to(eng.device).contiguous()
         h = self.views
         with torch.cuda.device(eng.device):
-            if eng._packed_version != eng._version:
+            if eng._packed_version != eng.version_key():
                 eng.pack_weights()
-                eng._packed_version = eng._version
+                eng._packed_version = eng.version_key()
             acts = eng._acts_for(2 * B)
             _lib.check(eng.lib.vdqn_net_trunk_forward(eng.handle, _ptr(eng.packed), _ptr(frames), src_kind, 2 * B, _ptr(acts), _stream()),
                        "vdqn_net_trunk_forward")

@@ -14,8 +14,15 @@ Mirrors ``archs/HabitatDQNMultiAction.py:8-54`` and the factory/loader of ``trai
     per frame slot and updates ``running_mean/var`` and ``num_batches_tracked`` like torch's BatchNorm2d.
 
 The module's parameters and BatchNorm buffers are *views* into the engine's flat device arrays, so
-``load_state_dict`` writes straight into what the kernels read; there is no autograd graph — gradients come
-from the engine's explicit backward (``video_dqn_amd.engine.TDStepper``).  No arithmetic happens on the CPU.
+``load_state_dict`` writes straight into what the kernels read.  The fast training path is the engine's fused update
+(``video_dqn_amd.engine.TDStepper``: one 2B-frame online pass, early Adam, no autograd).  The module is ALSO
+differentiable for ``extra_capacity`` (the shipped configuration): with grad mode on, ``forward`` runs as a
+``torch.autograd.Function`` whose backward is the engine's staged backward of that one call
+(``vdqn_net_backward_begin`` + ``vdqn_net_backward_stage``), parameters have ``requires_grad=True`` and receive
+``.grad``, so the reference's own loop — ``model(before)``, ``target_net(after)``, ``model(after)``,
+``loss.backward()``, ``optim.Adam(model.parameters()).step()`` (train_q_network.py:124,131,140-142,226-227) — runs
+unmodified on the HIP kernels (three separate passes and torch's Adam: slower than ``TDStepper``, same numbers).
+No arithmetic happens on the CPU.
 """
 from __future__ import annotations
 
@@ -26,6 +33,28 @@ import torch
 import torch.nn as nn
 
 from .engine import NetEngine
+
+
+class _QFunction(torch.autograd.Function):
+    """`model(x)` for autograd: forward = vdqn_net_forward into a workspace this call owns, backward = the engine's staged
+    backward of that call from dL/dQ.  `params` are the module's trainable Parameters (slot order); their gradients are slices
+    of one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, module, frames, src_kind, n_samples, *params):
+        eng = module.engine
+        packed = module._packed_with_dgrad()
+        q, acts = eng.forward_saved(frames, src_kind, n_samples, packed)
+        ctx.module, ctx.acts, ctx.packed, ctx.n = module, acts, packed, n_samples
+        return q
+
+    @staticmethod
+    def backward(ctx, gq):
+        module, eng = ctx.module, ctx.module.engine
+        flat = eng.backward_from_dq(ctx.acts, ctx.packed, gq, ctx.n)
+        ctx.acts = ctx.packed = None
+        grads = tuple(flat[s.offset:s.offset + s.numel].view(s.shape) for s in module._trainable_slots)
+        return (None, None, None, None) + grads
 
 
 class _Holder(nn.Module):
@@ -76,18 +105,28 @@ def _init_like_reference(engine: NetEngine, seed=None):
 
 def load_torchvision_resnet18(engine: NetEngine, sd, source: str = "state_dict") -> int:
     """`models.resnet18(pretrained=True)` (archs/HabitatDQNMultiAction.py:11) from a file: copy a torchvision-keyed ResNet-18
-    state_dict ('conv1.weight', 'layer1.0.bn1.running_mean', ..., 'fc.bias') into the engine's `resnet.*` tensors.  Strict, as
-    torchvision's own load_state_dict is: EVERY trunk tensor the engine holds (20 convolutions, 20 BatchNorm layers with their
-    running statistics, the frozen fc) must be present with its exact shape; a file that covers only part of the trunk, or a
-    tensor of the wrong shape (a ResNet-34 / a different width), is an error and nothing is copied.  `num_batches_tracked`
-    entries are accepted and ignored (eval-mode statistics do not use them); any other unknown key is an error.  Returns the
-    number of tensors copied."""
+    state_dict ('conv1.weight', 'layer1.0.bn1.running_mean', ..., 'fc.bias') into the engine's `resnet.*` tensors.  Strict on
+    everything the network computes with, as torchvision's own load_state_dict is: EVERY convolution and BatchNorm tensor of the
+    trunk (20 convolutions, 20 BatchNorm layers with their running statistics) must be present with its exact shape; a file that
+    covers only part of the trunk, or a tensor of the wrong shape (a ResNet-34 / a different width), is an error and nothing is
+    copied.  The classifier `fc` is never on the path (archs/HabitatDQNMultiAction.py:30 cuts it off; it only rides along in the
+    checkpoint): an ImageNet file's [1000, 512] fc is copied, a differently sized one — the 365-way fc of a Places365 ResNet-18,
+    also wrapped as {'state_dict': ..., 'module.' prefixes} — is skipped with a warning and the engine keeps its own.
+    `num_batches_tracked` entries are accepted and ignored (eval-mode statistics do not use them); any other unknown key is an
+    error.  Returns the number of tensors copied."""
     if hasattr(sd, "state_dict"):
         sd = sd.state_dict()
     if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
-        sd = sd["state_dict"]  # the Places365 checkpoints the paper's footnote points at wrap the tensors this way
+        sd = sd["state_dict"]  # (Places365 checkpoints wrap the tensors this way)
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
     want = {name[len("resnet."):]: s for name, s in engine.slots.items() if name.startswith("resnet.")}
+    skip_fc = [k for k in ("fc.weight", "fc.bias") if k in sd and tuple(sd[k].shape) != tuple(want[k].shape)]
+    if skip_fc or any(k not in sd for k in ("fc.weight", "fc.bias")):
+        import warnings
+        warnings.warn(f"{source}: the classifier fc ({[tuple(sd[k].shape) for k in skip_fc] or 'absent'}) does not match resnet.fc [1000, 512]; "
+                      "it is not on the Q-network's path and is left at the engine's own values")
+        want = {k: v for k, v in want.items() if not k.startswith("fc.")}
+        sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
     missing = sorted(k for k in want if k not in sd)
     unknown = sorted(k for k in sd if k not in want and not k.endswith("num_batches_tracked"))
     wrong = sorted(f"{k}: {tuple(sd[k].shape)} != {tuple(want[k].shape)}" for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k].shape))
@@ -134,8 +173,10 @@ class HabitatDQNMultiAction(nn.Module):
         bn_count = [0]
 
         def P(name):
+            # requires_grad as in the reference (every nn.Parameter, the never-used resnet.fc included: it simply never
+            # receives a .grad, train_q_network.py:124); the Parameters share storage AND version counter with eng.params
             if name not in cache:
-                cache[name] = nn.Parameter(eng.view(name), requires_grad=False)
+                cache[name] = nn.Parameter(eng.view(name), requires_grad=True)
             return cache[name]
 
         def bn(name):
@@ -173,6 +214,10 @@ class HabitatDQNMultiAction(nn.Module):
         resnet.avgpool = _Stateless()
         resnet.fc = _conv(P, "resnet.fc", has_bias=True)
         self.resnet = resnet
+        # what torch.autograd differentiates `forward` with respect to: the trainable slots, in the engine's flat order
+        self._trainable_slots = [s for s in eng.slots.values() if s.kind == 0]
+        self._trainable_params = None  # filled after the tree is complete (below)
+        self._cache = cache
         if self.extra_capacity:  # archs/HabitatDQNMultiAction.py:30-31
             self.features = nn.Sequential(*list(self.resnet.children())[:-2], _conv(P, "features.8", has_bias=True),
                                           _Stateless(), _Stateless())
@@ -181,6 +226,24 @@ class HabitatDQNMultiAction(nn.Module):
         else:  # :33-34
             self.features = nn.Sequential(*list(self.resnet.children())[:-1])
             self.top = _conv(P, "top", True)
+        object.__setattr__(self, "_trainable_params", [cache[s.name] for s in self._trainable_slots])
+        del self._cache
+        self._packed_grad = None      # packed weights incl. the data-gradient operands, for differentiable forwards
+        self._packed_grad_key = None  # (engine version, version counter of the flat parameter array) they were packed from
+
+    def _packed_with_dgrad(self):
+        """The packed weights (BatchNorm folded, forward AND data-gradient operands) of the CURRENT parameters.  In-place
+        updates by torch optimisers are seen through the version counter the Parameters share with the flat array; a new
+        buffer is used whenever the parameters changed, so a graph that still holds the old one differentiates the weights
+        its forward ran with."""
+        eng = self.engine
+        key = eng.version_key()
+        if self._packed_grad is None or self._packed_grad_key != key:
+            with torch.cuda.device(eng.device):
+                self._packed_grad = torch.empty(eng.packed_bytes, dtype=torch.uint8, device=eng.device)
+                eng.pack_weights(self._packed_grad, with_dgrad=True)
+            self._packed_grad_key = key
+        return self._packed_grad
 
     # ---- reference surface ----------------------------------------------------------------------------
     def set_train(self):  # :37-40
@@ -225,7 +288,9 @@ class HabitatDQNMultiAction(nn.Module):
             outs = [self.forward(inp[i:i + eng.max_batch]) for i in range(0, b, eng.max_batch)]
             return torch.cat(outs, 0)
         if self.training and not self.extra_capacity:  # the ResNet's BatchNorm layers are in train mode (:37-40)
-            q = eng.forward_train(inp, src_kind, b)
+            q = eng.forward_train(inp, src_kind, b)  # (no autograd graph: 'basic' trains through TDStepper)
+        elif self.extra_capacity and torch.is_grad_enabled() and any(p.requires_grad for p in self._trainable_params):
+            q = _QFunction.apply(self, inp, src_kind, b, *self._trainable_params)
         else:
             q = eng.forward(inp, src_kind, b)
         return q.view((-1, self.num_classes, self.action_dim))

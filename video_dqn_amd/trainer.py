@@ -185,7 +185,8 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                         remove_before_reward=config.REMOVE_BEFORE_REWARD,
                         train_on_ground_truth=config.TRAIN_ON_GROUND_TRUTH, value_learning=config.VALUE_LEARNING,
                         target_update_interval=config.TARGET_UPDATE_INTERVAL, world_size=world_size,
-                        allreduce=(comm.launch if comm else None), loss_kind=getattr(config, "LOSS_KIND", "l2"))
+                        allreduce=(comm.launch if comm else None), loss_kind=getattr(config, "LOSS_KIND", "l2"),
+                        allreduce_loss=(comm.launch_loss if comm else None))
     if world_size > 1 and config.ARCHITECTURE != "extra_capacity" and getattr(config, "SYNC_BN", True):
         model.engine.set_bn_sync(world_size)  # train-mode BatchNorm over the global batch, as the single-GPU reference sees it
     if store is not None:  # minibatches are gathered on the device; no loader, no host copies
@@ -224,6 +225,7 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
     running_loss = None
     host_loss = torch.zeros(2, dtype=torch.float32).pin_memory()
     pending = None  # (slot, event) of the previous step's loss copy
+    loss_stream = None  # N > 1: where the all-reduced loss is waited for and copied to the host
     num_steps = config.NUM_STEPS if max_steps is None else min(config.NUM_STEPS, sample_number + max_steps)
 
     def consume(p):
@@ -243,16 +245,25 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                             gt if config.TRAIN_ON_GROUND_TRUTH else None,
                             finish_allreduce=(comm.finish if comm else None))
         # every rank's `loss` is its share of the global mean (the TD kernel divides by the global batch): their SUM is the
-        # batch-mean loss the reference feeds into its running average every update (:228-231).  The 4-byte all-reduce is
-        # queued on the compute stream every update (tens of microseconds beside a multi-millisecond update), so the average
-        # that is printed, logged and returned is the reference's: an EMA of the true global batch-mean loss
-        if world_size > 1:
-            loss = loss.clone()
-            torch.distributed.all_reduce(loss)
+        # batch-mean loss the reference feeds into its running average every update (:228-231).  The stepper has queued that
+        # 4-byte all-reduce on the gradient stream behind the last gradient bucket (dist.launch_loss); it is waited for and
+        # copied to the host on the read-back stream only — the compute stream, i.e. the next update's first kernel, never
+        # waits for it — so the average that is printed, logged and returned is still the reference's: an EMA of the true
+        # global batch-mean loss, one update late like the single-process read-back
         slot = sample_number & 1
-        host_loss[slot:slot + 1].copy_(loss, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record()
+        reduced = comm.take_loss() if comm is not None else None
+        if reduced is not None:
+            buf, work = reduced
+            if loss_stream is None:
+                loss_stream = torch.cuda.Stream(device=model.engine.device)
+            with torch.cuda.stream(loss_stream):
+                work.wait()
+                host_loss[slot:slot + 1].copy_(buf, non_blocking=True)
+                ev.record(loss_stream)
+        else:
+            host_loss[slot:slot + 1].copy_(loss, non_blocking=True)
+            ev.record()
         if pending is not None:
             consume(pending)
         pending = (slot, ev)
