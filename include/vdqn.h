@@ -73,8 +73,9 @@ typedef struct vdqn_conv_args {
   const void* mask;    /* [m][ldo] or NULL */
   void* out;           /* [m][ldo], dtype; may be NULL if out_f32 is given */
   float* out_f32;      /* optional f32 copy of the result [m][ldo] */
-  float* colsum_part;  /* optional [T][ldo] f32, T = ceil(m/128) (stride-2 dgrad: 4*ceil(m/4/128), one run of tiles per output
-                          parity class): per 128-row tile, column sums of the stored `out` values
+  float* colsum_part;  /* optional [T][ldo] f32, T = ceil(m/R) with R = vdqn_conv2d_colsum_rows(a) = 128 for the tiled kernels
+                          (stride-2 dgrad: 4*ceil(m/4/128), one run of tiles per output parity class) and 32 for the Q-head's
+                          skinny GEMMs: per R-row tile, column sums of the stored `out` values
                           (summed over tiles they are the bias / BatchNorm-shift gradient of the layer that `out`
                           is the output-gradient of) */
   int32_t n_img, hi, wi, ci, pix_stride;
@@ -105,6 +106,9 @@ typedef struct vdqn_conv_args {
   int32_t split_img;
 } vdqn_conv_args;
 int vdqn_conv2d(const vdqn_conv_args* a, void* stream);
+/* rows of `out` covered by one entry of colsum_part for this call (what sizes that buffer): 128, or the row tile of the skinny
+ * GEMM kernels that take the Q-head's bf16 linear layers (archs/HabitatDQNMultiAction.py:31; csrc/skinny.hip) */
+int32_t vdqn_conv2d_colsum_rows(const vdqn_conv_args* a);
 
 /* Weight gradient of the same layer:  dw[n][r][s][c] += sum_m gy[m, n] * x[pix(m,r,s), c]
  * (split over `splitk` pixel ranges whose partial tiles are added into dw with f32 atomics).  If dbias != NULL it also

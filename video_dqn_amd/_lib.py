@@ -79,6 +79,7 @@ _SIGS = {
     "vdqn_profile_enable": (C.c_int, [C.c_int]),
     "vdqn_profile_collect": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "vdqn_conv2d": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
+    "vdqn_conv2d_colsum_rows": (c_i32, [C.POINTER(ConvArgs)]),
     "vdqn_conv2d_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
     "vdqn_conv2d_wgrad_workspace_bytes": (c_i64, [C.POINTER(WgradArgs)]),
     "vdqn_pack_input": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp]),

@@ -90,6 +90,16 @@ int vdqn_bn_train_fwd_impl(const void* y, const void* resid, void* z, const floa
 int vdqn_bn_train_bwd_impl(const void* g, const void* y, void* dy, float* work, float* dgamma, float* dbeta, int32_t n_img, int32_t hw, int32_t c,
                            int32_t num_frames, int32_t imgs_per_half, int32_t dtype, void* stream, const BnSync* sync);
 
+// skinny.hip: the Q-head's small GEMMs (bf16).  kind 0 = not taken, 1 = linear layer (32 x 32 tiles), 2 = valid convolution with 64
+// output columns (features.8 forward, 64 x 64 tiles)
+int vdqn_skinny_kind(const vdqn_conv_args* a);
+int vdqn_skinny_part_rows(int conv);
+int vdqn_launch_skinny(const void* igemm_params, int kind, hipStream_t stream);
+
+// ds1x1.hip: the 1x1 / stride-2 downsample convolutions (bf16 forward) as a streaming kernel
+bool vdqn_ds1x1_takes(const vdqn_conv_args* a);
+int vdqn_launch_ds1x1(const void* igemm_params, hipStream_t stream);
+
 #define VDQN_CHECK(cond, ...)        \
   do {                               \
     if (!(cond)) {                   \

@@ -812,9 +812,10 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
   L.g_pool = take(n * 56 * 56 * 64 * e);
   L.g_c1 = take(n * 112 * 112 * 64 * e);
   auto tiles = [](int64_t rows) { return (rows + 127) / 128; };
-  L.p_l1 = take(tiles(n_samples) * 256 * 4);
-  L.p_l0 = take(tiles(n_samples) * 512 * 4);
-  L.p_f8 = take(tiles(n_samples) * 1600 * F * 4);
+  auto tiles32 = [](int64_t rows) { return (rows + 31) / 32; };  // the head's skinny kernels write one entry per 32 rows (skinny.hip)
+  L.p_l1 = take(tiles32(n_samples) * 256 * 4);
+  L.p_l0 = take(tiles32(n_samples) * 512 * 4);
+  L.p_f8 = take(tiles32(n_samples) * 1600 * F * 4);
   L.p_pool = take(tiles(n * 56 * 56) * 64 * 4);
   for (int b = 0; b < 8; ++b) {
     const int64_t planes = 64 << (b / 2), sp = 56 >> (b / 2);
@@ -940,7 +941,8 @@ int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, c
 
 // data gradient: gx = (dgrad(gy) + resid) masked by (mask > 0)
 int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* gy, void* gx, int n_units, const void* resid,
-              const void* mask, hipStream_t st, void* colsum_part = nullptr, const Layer* sib = nullptr, const void* sib_gy = nullptr) {
+              const void* mask, hipStream_t st, void* colsum_part = nullptr, const Layer* sib = nullptr, const void* sib_gy = nullptr,
+              int* part_rows = nullptr) {
   vdqn_conv_args a;
   memset(&a, 0, sizeof(a));
   a.in = gy;
@@ -960,6 +962,10 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
     a.wt2 = packed + sib->wd_off;
     a.ci2 = sib->co_pad;
     g_prof_alg_flops += 2.0 * n_units * sib->ho * sib->wo * (double)sib->co * sib->ci;
+  }
+  if (part_rows) {  // rows of gx one entry of colsum_part covers: the kernel vdqn_conv2d picks for this call decides
+    const int kind = vdqn_skinny_kind(&a);
+    *part_rows = kind ? vdqn_skinny_part_rows(kind == 2) : 128;
   }
   prof_layer(L, n_units);
   return vdqn_conv2d(&a, st);
@@ -1596,6 +1602,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
   bool split_conv1 = false;  // stage 2, extra_capacity: conv1's weight gradient is unfolded separately (see below)
+  int pr_l1 = 128, pr_l0 = 128, pr_f8 = 128;  // row granularity of the head's column-sum partials (stage 0)
 
   if (net->basic()) {
     if (stage == 0) {
@@ -1620,11 +1627,11 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     const Layer& t0 = net->layers[net->l_top0];
     const Layer& f8 = net->layers[net->l_f8];
     RC(run_wgrad(net, t4, bw, bw + W.dq, ao + A.l1, B, wgrad_stream(net, st), true));
-    RC(run_dgrad(net, t4, pk, bw + W.dq, bw + W.g_l1, B, nullptr, ao + A.l1, st, bw + W.p_l1));
+    RC(run_dgrad(net, t4, pk, bw + W.dq, bw + W.g_l1, B, nullptr, ao + A.l1, st, bw + W.p_l1, nullptr, nullptr, &pr_l1));
     RC(run_wgrad(net, t2, bw, bw + W.g_l1, ao + A.l0, B, wgrad_stream(net, st)));
-    RC(run_dgrad(net, t2, pk, bw + W.g_l1, bw + W.g_l0, B, nullptr, ao + A.l0, st, bw + W.p_l0));
+    RC(run_dgrad(net, t2, pk, bw + W.g_l1, bw + W.g_l0, B, nullptr, ao + A.l0, st, bw + W.p_l0, nullptr, nullptr, &pr_l0));
     RC(run_wgrad(net, t0, bw, bw + W.g_l0, ao + A.f8, B, wgrad_stream(net, st)));
-    RC(run_dgrad(net, t0, pk, bw + W.g_l0, bw + W.g_f8, B, nullptr, ao + A.f8, st, bw + W.p_f8));
+    RC(run_dgrad(net, t0, pk, bw + W.g_l0, bw + W.g_f8, B, nullptr, ao + A.f8, st, bw + W.p_f8, nullptr, nullptr, &pr_f8));
     RC(run_wgrad(net, f8, bw, bw + W.g_f8, ao + A.o[7], n, wgrad_stream(net, st)));
     RC(run_dgrad(net, f8, pk, bw + W.g_f8, bw + W.g_o[7], n, nullptr, ao + A.o[7], st, bw + W.p_o[7]));
     RC(block_backward(net, a, 7, A, W, n, st));
@@ -1652,6 +1659,11 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
     set(net->l_top2, W.p_l1, B, 256, 1, 0);
     set(net->l_top0, W.p_l0, B, 512, 1, 0);
     set(net->l_f8, W.p_f8, B, 1600 * F, 25 * F, 64);
+    if (stage == 0) {  // entries per pr_* rows, as the kernels that ran above wrote them
+      pt.tiles[net->l_top2] = (B + pr_l1 - 1) / pr_l1;
+      pt.tiles[net->l_top0] = (B + pr_l0 - 1) / pr_l0;
+      pt.tiles[net->l_f8] = (B + pr_f8 - 1) / pr_f8;
+    }
     set(net->l_conv1, W.p_pool, (int64_t)n * 56 * 56, 64, 1, 0);
     for (int b = 0; b < 8; ++b) {
       const int planes = 64 << (b / 2), sp = 56 >> (b / 2);

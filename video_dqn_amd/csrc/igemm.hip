@@ -1548,6 +1548,20 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
   p.vec_ok = ((a->ldo * esz) % 16 == 0) && ((al & 15) == 0) && (a->ldo % 8 == 0);
   const int mode = a->mode == 0 ? 0 : (a->stride == 2 ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
+  // the Q-head's skinny GEMMs (bf16 linear layers forward / data gradient, features.8 forward): small tiles, K split over the waves
+  if (mode != 2) {
+    vdqn_conv_args one = *a;  // a grouped call is asked as one of its two ranges: they then run as two launches of the SAME kernel
+    one.wt_b = nullptr;       // (bit-identical to the two-pass update: test_grouped_forward_is_bit_identical_to_two_passes)
+    one.bias_b = nullptr;
+    const int sk = vdqn_skinny_kind(&one);
+    if (sk && group_rows > 0) return VDQN_OK;
+    if (sk) return vdqn_launch_skinny(&p, sk, st);
+    // the 1x1 / stride-2 downsample convolutions (bf16 forward): weights in registers, rows streamed (ds1x1.hip)
+    if (vdqn_ds1x1_takes(&one)) {
+      if (group_rows > 0) return VDQN_OK;
+      return vdqn_launch_ds1x1(&p, st);
+    }
+  }
   // 64-column layers with many rows: 256-row tiles, 8 waves (more MFMA work per DMA round trip, half the weight traffic)
   // (VDQN_BM256_MIN_ROWS overrides the row threshold: tests lower it to reach this variant with small tensors, a huge value disables it)
   // 3x3 / stride 1 / pad 1: the window kernel (one staged activation window per kernel row and channel chunk)

@@ -41,16 +41,20 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
     out_f32 = torch.empty((n, ho, wo, ldo), dtype=torch.float32, device=x.device) if want_f32 else None
     a = _lib.ConvArgs()
     a.in_, a.wt, a.bias, a.resid, a.mask = _ptr(x), _ptr(wt), _ptr(bias), _ptr(resid), _ptr(mask)
-    if mode == 1 and stride == 2:  # one run of tiles per output-parity class
-        n_tiles = sum((n * hc * wc + 127) // 128 for hc in ((ho + 1) // 2, ho // 2) for wc in ((wo + 1) // 2, wo // 2))
-    else:
-        n_tiles = (n * ho * wo + 127) // 128
-    part = torch.empty((n_tiles, ldo), dtype=torch.float32, device=x.device) if want_colsum else None
-    a.out, a.out_f32, a.colsum_part = _ptr(out), _ptr(out_f32), _ptr(part)
+    a.out, a.out_f32 = _ptr(out), _ptr(out_f32)
     a.n_img, a.hi, a.wi, a.ci, a.pix_stride = n, hi, wi, ci, pix_stride
     a.ho, a.wo, a.co, a.ldo = ho, wo, co, ldo
     a.r, a.s, a.stride, a.pad = r, s, stride, pad
     a.mode, a.relu, a.dtype = mode, int(relu), dtype_code(x)
+    part = None
+    if want_colsum:
+        rows = lib.vdqn_conv2d_colsum_rows(C.byref(a))  # 128, or the row tile of the kernel that takes this call
+        if mode == 1 and stride == 2:  # one run of tiles per output-parity class
+            n_tiles = sum((n * hc * wc + rows - 1) // rows for hc in ((ho + 1) // 2, ho // 2) for wc in ((wo + 1) // 2, wo // 2))
+        else:
+            n_tiles = (n * ho * wo + rows - 1) // rows
+        part = torch.empty((n_tiles, ldo), dtype=torch.float32, device=x.device)
+    a.colsum_part = _ptr(part)
     out2 = None
     if wt2 is not None and mode == 0:
         out2 = torch.empty((n, ho, wo, co2), dtype=x.dtype, device=x.device)
