@@ -327,6 +327,10 @@ int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnsta
                           void* stream);
 /* with_dgrad is a flag word: bit 0 = also pack the data-gradient operands, bit 1 = do NOT fold BatchNorm (the
  * convolutions then produce the raw pre-BatchNorm output; used by the train-mode BatchNorm path of 'basic'). */
+/* The same for the layers of ONE backward stage (0: head + layer4, 1: layer3, 2: layer2, layer1, stem): lets the caller refresh a
+ * stage's packed weights as soon as that stage's range of `params` has had its optimiser update (vdqn_step_args.prefolded_stages). */
+int vdqn_net_pack_weights_stage(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad,
+                                int32_t stage, void* stream);
 
 /* Forward of `n_samples` samples (n_samples * F frames).  frames: see vdqn_pack_input (src_kind).
  * q_out: f32 [n_samples][num_classes*action_dim] (HabitatDQNMultiAction.forward, archs/...:44-54). */
@@ -393,6 +397,10 @@ typedef struct vdqn_step_args {
                                  arrive packed (or that pack the NEXT minibatch during this update: the loader of
                                  train_q_network.py:213 has it a step ahead — measured slower on one GPU).
                                  NULL: the update packs them itself. */
+  int32_t prefolded_stages;   /* bit s set: `packed_online` ALREADY holds the packed weights of backward stage s's layers for the current
+                                 `params` (the caller ran vdqn_net_pack_weights_stage after that stage's optimiser update of the
+                                 PREVIOUS update, under its remaining backward pass); vdqn_net_td_forward then folds only the other
+                                 stages.  0: it folds everything, as torch does nothing of the kind (set_train, archs/...:37-40). */
   int32_t acts_samples;       /* 0: `acts_online` is laid out as vdqn_net_td_forward leaves it (2B samples, 3B grouped, B on the
                                  ground-truth branch).  > 0: `acts_online` is the workspace of ONE vdqn_net_forward call over that
                                  many samples (== batch) — the backward of a single model call, vdqn_net_backward_begin below. */

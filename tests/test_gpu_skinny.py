@@ -73,9 +73,9 @@ def test_features8_valid_conv_forward(n):
 
 
 @pytest.mark.parametrize("n,hi,ci", [(5, 56, 64), (3, 28, 128), (7, 14, 256), (1, 2, 64), (64, 56, 64)])
-def test_downsample_1x1_stride2_streaming_kernel(n, hi, ci):
-    """The BasicBlock downsample convolution (1x1 / stride 2, C -> 2C, BatchNorm folded into weights + bias, no ReLU) on the
-    streaming kernel (csrc/ds1x1.hip) against torch on the same bf16 operands."""
+def test_downsample_1x1_stride2(n, hi, ci):
+    """The BasicBlock downsample convolution (1x1 / stride 2, C -> 2C, BatchNorm folded into weights + bias, no ReLU) against torch
+    on the same bf16 operands (tiled kernel; the streaming variant of round 4 measured slower and lives in experiments/)."""
     from video_dqn_amd import ops
     co, ho = 2 * ci, hi // 2
     x = rnd(21, "x", (n, hi, hi, ci)).to(BF)

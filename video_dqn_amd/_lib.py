@@ -68,7 +68,7 @@ class StepArgs(C.Structure):
                 ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("train_on_ground_truth", c_i32),
                 ("value_learning", c_i32),
                 ("acts_online", c_vp), ("acts_target", c_vp), ("bwd", c_vp), ("grads", c_vp), ("loss", c_vp),
-                ("q_before", c_vp), ("loss_kind", c_i32), ("packed_frames", c_vp), ("acts_samples", c_i32)]
+                ("q_before", c_vp), ("loss_kind", c_i32), ("packed_frames", c_vp), ("prefolded_stages", c_i32), ("acts_samples", c_i32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, c_vp, c_vp, c_i64, c_vp)  # vdqn_allreduce_fn(user, buf, count, stream)
@@ -115,6 +115,7 @@ _SIGS = {
     "vdqn_net_act_offset": (c_i64, [c_vp, c_i32, C.c_char_p]),
     "vdqn_net_bwd_offset": (c_i64, [c_vp, c_i32, C.c_char_p]),
     "vdqn_net_pack_weights": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "vdqn_net_pack_weights_stage": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vdqn_net_forward": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vdqn_net_trunk_forward": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "vdqn_softmax_rows": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

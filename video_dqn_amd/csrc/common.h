@@ -96,10 +96,6 @@ int vdqn_skinny_kind(const vdqn_conv_args* a);
 int vdqn_skinny_part_rows(int conv);
 int vdqn_launch_skinny(const void* igemm_params, int kind, hipStream_t stream);
 
-// ds1x1.hip: the 1x1 / stride-2 downsample convolutions (bf16 forward) as a streaming kernel
-bool vdqn_ds1x1_takes(const vdqn_conv_args* a);
-int vdqn_launch_ds1x1(const void* igemm_params, hipStream_t stream);
-
 #define VDQN_CHECK(cond, ...)        \
   do {                               \
     if (!(cond)) {                   \

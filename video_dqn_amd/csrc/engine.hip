@@ -1286,6 +1286,13 @@ extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const f
   return pack_weights_layers(net, params, bnstats, packed, with_dgrad, 0, (int)net->layers.size(), (hipStream_t)stream);
 }
 
+extern "C" int vdqn_net_pack_weights_stage(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad, int32_t stage,
+                                           void* stream) {
+  VDQN_CHECK(net && params && bnstats && packed, "vdqn_net_pack_weights_stage: null arg");
+  VDQN_CHECK(stage >= 0 && stage < 3, "vdqn_net_pack_weights_stage: stage %d", stage);
+  return pack_weights_layers(net, params, bnstats, packed, with_dgrad, net->layer_stage_first[stage], net->layer_stage_count[stage], (hipStream_t)stream);
+}
+
 extern "C" int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples, void* acts,
                                 float* q_out, void* stream) {
   VDQN_CHECK(net && packed && frames && acts && q_out, "vdqn_net_forward: null arg");
@@ -1382,8 +1389,17 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     (void)hipEventRecord(e_after, tst);
     RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, st));
   } else {
-    RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, tst));
+    // the two packs run side by side (second side stream; VDQN_PACK_TWO_STREAMS=0: one behind the other): each alone reaches ~3 TB/s,
+    // and nothing else runs at the start of an update
+    static const bool two = [] { const char* e = getenv("VDQN_PACK_TWO_STREAMS"); return !(e && e[0] == '0'); }();
+    hipStream_t pst = (two && tst != st && !gtb) ? fork_side2(net, st) : tst;
+    RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, pst));
     if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
+    if (pst != tst) {  // the side stream (target pass, and the join below) continues behind both packs
+      hipEvent_t e = next_event(net);
+      (void)hipEventRecord(e, pst);
+      (void)hipStreamWaitEvent(tst, e, 0);
+    }
   }
   // VDQN_FOLD_SPLIT=1 (off by default): only stage 2's layers (stem, layer1, layer2: 0.7 M of the 12.4 M parameters) are folded in
   // front of the online pass; the rest (layer3, layer4, head) on the side stream beside the stem and layer1, and the caller's stream
@@ -1394,6 +1410,10 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   hipEvent_t late_weights = nullptr;
   if (fold_split) {
     RC(pack_weights_layers(net, a->params, a->bnstats, a->packed_online, 1, net->layer_stage_first[2], net->layer_stage_count[2], st));
+  } else if (a->prefolded_stages & 7) {  // the caller folded some stages behind their optimiser update: only the others here
+    for (int s = 0; s < 3; ++s)
+      if (!((a->prefolded_stages >> s) & 1))
+        RC(pack_weights_layers(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, net->layer_stage_first[s], net->layer_stage_count[s], st));
   } else {
     RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
   }

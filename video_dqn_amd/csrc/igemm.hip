@@ -1556,11 +1556,6 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
     const int sk = vdqn_skinny_kind(&one);
     if (sk && group_rows > 0) return VDQN_OK;
     if (sk) return vdqn_launch_skinny(&p, sk, st);
-    // the 1x1 / stride-2 downsample convolutions (bf16 forward): weights in registers, rows streamed (ds1x1.hip)
-    if (vdqn_ds1x1_takes(&one)) {
-      if (group_rows > 0) return VDQN_OK;
-      return vdqn_launch_ds1x1(&p, st);
-    }
   }
   // 64-column layers with many rows: 256-row tiles, 8 waves (more MFMA work per DMA round trip, half the weight traffic)
   // (VDQN_BM256_MIN_ROWS overrides the row threshold: tests lower it to reach this variant with small tensors, a huge value disables it)
