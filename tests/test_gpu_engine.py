@@ -684,6 +684,7 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_FOLD_SPLIT": "1"},         # weight fold of stage 2's layers first, the rest on the side stream beside the stem
     {"VDQN_STEM_WGRAD_MAIN": "0"},    # conv1's weight gradient on the side stream behind block 0's instead of beside them
     {"VDQN_SKINNY": "0"},             # the Q-head's layers on the generic tiled kernel instead of the skinny GEMM kernels
+    {"VDQN_EARLY_FOLD": "1", "VDQN_PACK_TWO_STREAMS": "1"},  # stage 0 / 1 weights folded behind their early Adam; the two input packs on two streams
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_non_default_kernel_selections(env):
     """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and
@@ -691,6 +692,6 @@ def test_non_default_kernel_selections(env):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_engine.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "(td_step_matches_oracle_all_elements and 101) or side_stream_overlap or deterministic_mode_is_bit_identical"],
+                        "-k", "(td_step_matches_oracle_all_elements and 101) or side_stream_overlap or deterministic_mode_is_bit_identical or early_adam_is_the_same"],
                        env=dict(os.environ, **env), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]

@@ -1389,9 +1389,10 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     (void)hipEventRecord(e_after, tst);
     RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, st));
   } else {
-    // the two packs run side by side (second side stream; VDQN_PACK_TWO_STREAMS=0: one behind the other): each alone reaches ~3 TB/s,
-    // and nothing else runs at the start of an update
-    static const bool two = [] { const char* e = getenv("VDQN_PACK_TWO_STREAMS"); return !(e && e[0] == '0'); }();
+    // VDQN_PACK_TWO_STREAMS=1 (off by default): the two packs side by side on two streams instead of one behind the other.  Each alone
+    // reaches ~3 TB/s and little else runs at the start of an update, yet measured on alternating runs it is 1 % SLOWER (5.775 against
+    // 5.712 ms per update, profiles/r04g_ab_early_fold_two_stream_packs.txt).
+    static const bool two = [] { const char* e = getenv("VDQN_PACK_TWO_STREAMS"); return e && e[0] == '1'; }();
     hipStream_t pst = (two && tst != st && !gtb) ? fork_side2(net, st) : tst;
     RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, pst));
     if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));

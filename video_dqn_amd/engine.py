@@ -27,8 +27,12 @@ DTYPES = {"f32": _lib.VDQN_F32, "fp32": _lib.VDQN_F32, "float32": _lib.VDQN_F32,
 
 # VDQN_EARLY_ADAM=0: `TDStepper.step` runs the whole optimiser update behind the backward pass (one launch)
 _EARLY_ADAM = os.environ.get("VDQN_EARLY_ADAM", "1") != "0"
-# VDQN_EARLY_FOLD=0: the next update folds all weights at its start (instead of stage 0 / stage 1 right behind their early Adam)
-_EARLY_FOLD = os.environ.get("VDQN_EARLY_FOLD", "1") != "0"
+# VDQN_EARLY_FOLD=1 (off by default): stage 0 / stage 1 weights are folded for the NEXT update right behind their early Adam, so that
+# update starts with a 0.7 M-parameter fold instead of a 12.4 M one.  Measured on alternating runs it is 0.6 % SLOWER (5.747 against
+# 5.712 ms, profiles/r04g_ab_early_fold_two_stream_packs.txt): at the start of an update the fold already runs beside the two input
+# packs on the other stream, so nothing is exposed there, while the moved fold lengthens the gradient stream that carries every
+# weight gradient.  Kept as a tested switch (bit-identical updates).
+_EARLY_FOLD = os.environ.get("VDQN_EARLY_FOLD", "0") == "1"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
