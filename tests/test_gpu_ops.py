@@ -275,6 +275,10 @@ def test_stem_pack_conv1_maxpool(dtype, src_kind):
     xn = synth.normalise_frames(frames)  # [n,3,224,224] f32
     src = torch.from_numpy(frames[:, 0]).to(DEV) if src_kind == 0 else xn.contiguous().to(DEV)
     packed = ops.pack_input(src, src_kind, n, dtype)
+    if src_kind == 0:
+        # the fused normalisation ((u / 255 - mean) / std from a per-block table, util/torch.py:5-12) gives the bits of the f32 tensor
+        # the reference's loader produces (ToTensor + Normalize), rounded once
+        assert torch.equal(packed, ops.pack_input(xn.contiguous().to(DEV), 1, n, dtype))
     w7 = q(rnd(2, "w7", (64, 3, 7, 7), -0.2, 0.2), dtype)
     b = rnd(3, "b", (64,))
     c1 = ops.conv2d(packed, s2d_weights(w7, dtype), ho=112, wo=112, co=64, r=4, s=1, stride=1, pad=0, bias=b.to(DEV),
@@ -293,7 +297,7 @@ def test_stem_pack_conv1_maxpool(dtype, src_kind):
     pool_f, idx_f = ops.stem_conv_pool(packed, s2d_weights(w7, dtype), b.to(DEV))
     torch.cuda.synchronize()
     assert torch.equal(pool_f, pool) and torch.equal(idx_f, idx)
-    # ... and without the arg-max bytes (frames under torch.no_grad(), train_q_network.py:138-142) the pooled values are the same
+    # ... and without the arg-max bytes (frames that never see a backward pass, train_q_network.py:140-142,148,155-156) the pooled values are the same
     pool_n, idx_n = ops.stem_conv_pool(packed, s2d_weights(w7, dtype), b.to(DEV), want_idx=False)
     torch.cuda.synchronize()
     assert idx_n is None and torch.equal(pool_n, pool)

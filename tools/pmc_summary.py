@@ -26,6 +26,9 @@ def tag_of(kernel_name: str):
             return f"stem_conv_pool<{dt}>"
         size = "256x64" if bm == 256 else str(bn)
         return f"igemm<{dt},{size},{('fwd', 'dgrad', 'dgrad_s2')[mode]}>"
+    m = re.search(r"skinny_kernel<(\d+), (\d+), (true|false)", kernel_name)
+    if m:  # the Q-head's skinny GEMMs (forward and data-gradient launches share a symbol)
+        return "skinny<bf16,conv>" if m[3] == "true" else f"skinny<bf16,{m[1]}x{m[2]}>"
     m = re.search(r"win9s_kernel", kernel_name)
     if m:  # plane-window kernel of the stride-2 3x3 forward convolutions
         return "igemm_s2win<bf16,128,fwd>"

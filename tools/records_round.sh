@@ -21,6 +21,8 @@ $B --loss-kind huber                        > $O/${TAG}_bench_huber.json 2>> $O/
 $B --h2d overlap                            > $O/${TAG}_bench_h2d_overlap.json 2>> $O/err.log
 $B --force-dist                             > $O/${TAG}_bench_rccl_1rank.json 2>> $O/err.log
 VDQN_BENCH_SINGLE_DEVICE=1 $B --gpus 2 --backend gloo --batch 128 > $O/${TAG}_bench_2ranks_gloo_shared_gpu.json 2>> $O/err.log
+# BASELINE config 3's per-rank shape, functionally: four self-launched ranks x batch 256 share this box's GPU (gloo carries the exchange)
+VDQN_BENCH_SINGLE_DEVICE=1 $B --gpus 4 --backend gloo --batch 256 --steps 10 --warmup 2 --ramp-seconds 0 --no-profile > $O/${TAG}_bench_c3_4ranks_x256_gloo_shared_gpu.json 2>> $O/err.log
 python3 tools/convergence.py --steps 300 --batch 64 --out $O/${TAG}_convergence.json > $O/${TAG}_convergence.txt 2>> $O/err.log
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/prof_f12 -o k --output-format csv -- python3 $R/bench.py --frames 12 --batch 16 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>> $O/err.log)
 find $O/prof_f12 -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats_f12_b16.csv \;

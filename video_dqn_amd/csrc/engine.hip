@@ -128,8 +128,19 @@ namespace {
 bool side_ready(vdqn_net* net) {
   if (!net->overlap) return false;
   if (!net->side) {
-    if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&net->side2, hipStreamNonBlocking) != hipSuccess) {
+    // The side streams (target forward, weight gradients, unfold) run BELOW the caller's stream in the hardware queues' priority order:
+    // the caller's stream carries the critical chain (online forward, data gradients), the side streams are what fills the chip around
+    // it.  Measured on alternating runs of two boxes (profiles/r04i_*, r04j_*): low 5.766-5.781 against 5.832-5.842 ms per update on one
+    // (+1.0 %, three rounds of three), 5.843-5.856 against 5.849-5.863 on the other (+0.1 %); HIGH priority for them: 5.911-5.916 against
+    // 5.837-5.844 (-1.2 %).  VDQN_SIDE_PRIORITY=normal|high|low overrides.
+    int prio = 0;
+    {
+      const char* e = getenv("VDQN_SIDE_PRIORITY");
+      int lo = 0, hi = 0;  // (numerically lower = higher priority)
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = (!e || e[0] == 'l') ? lo : (e[0] == 'h' ? hi : 0);
+    }
+    if (hipStreamCreateWithPriority(&net->side, hipStreamNonBlocking, prio) != hipSuccess ||
+        hipStreamCreateWithPriority(&net->side2, hipStreamNonBlocking, prio) != hipSuccess) {
       net->overlap = 0;
       net->side = nullptr;
       net->side2 = nullptr;

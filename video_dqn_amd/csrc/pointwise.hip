@@ -57,47 +57,53 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const void* __restrict_
   }
 }
 
-// uint8 HWC source, two packed rows per block: the four source rows (672 bytes each) are read as 16-byte vectors into LDS and
-// every thread builds one packed pixel from there (the per-pixel version above issues twelve single-byte loads per thread).
-// Same arithmetic, so the same bits.
+// uint8 HWC source: a block walks kPackPairs pairs of packed rows; per pair the four source rows (672 bytes each) are read as 16-byte
+// vectors into LDS and every thread builds one packed pixel from there.  The normalisation (u / 255 - mean) / std — two IEEE
+// divisions per element, 24 per packed pixel: what bounded this kernel at 2.9 TB/s — is evaluated ONCE per block for the 3 x 256
+// possible (channel, byte) pairs into an LDS table, with the same expression: same bits as the per-element arithmetic.
+constexpr int kPackPairs = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_rows_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst) {
   __shared__ uint4 rows[4][42];
-  const int n = blockIdx.y, y0 = 2 * blockIdx.x;  // packed rows y0, y0 + 1 -> source rows 2 (y0 - 2) .. + 3
+  __shared__ T lut[3][256];
+  const int n = blockIdx.y;
   const int tid = threadIdx.x;
-  const int Y0 = 2 * (y0 - 2);
-  if (tid < 168) {
-    const int r = tid / 42, c = tid - r * 42, Y = Y0 + r;
-    rows[r][c] = ((unsigned)Y < 224u) ? reinterpret_cast<const uint4*>(src + ((size_t)n * 224 + Y) * 672)[c] : make_uint4(0, 0, 0, 0);
+  {
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lut[c][tid] = from_f32<T>((((float)tid / 255.0f) - mean[c]) / stdv[c]);
   }
-  __syncthreads();
-  const int yy = tid / 115, x = tid - yy * 115, y = y0 + yy;
-  if (tid >= 230 || y >= 115) return;
-  const float mean[3] = {0.485f, 0.456f, 0.406f};
-  const float stdv[3] = {0.229f, 0.224f, 0.225f};
-  const int ys = y - 2, xs = x - 2;
-  float v[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) v[e] = 0.f;
-  if ((unsigned)ys < 112u && (unsigned)xs < 112u) {
-    const uint8_t* b0 = reinterpret_cast<const uint8_t*>(rows[2 * yy]) + 6 * xs;
-    const uint8_t* b1 = reinterpret_cast<const uint8_t*>(rows[2 * yy + 1]) + 6 * xs;
-#pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      v[e] = (((float)b0[e] / 255.0f) - mean[e % 3]) / stdv[e % 3];
-      v[6 + e] = (((float)b1[e] / 255.0f) - mean[e % 3]) / stdv[e % 3];
+  const int yy = tid / 115, x = tid - yy * 115;
+  for (int pr = 0; pr < kPackPairs; ++pr) {
+    const int y0 = 2 * ((int)blockIdx.x * kPackPairs + pr);  // packed rows y0, y0 + 1 -> source rows 2 (y0 - 2) .. + 3
+    if (y0 >= 115) break;
+    const int Y0 = 2 * (y0 - 2);
+    __syncthreads();  // the previous pair's readers are done (first pass: the table is written)
+    if (tid < 168) {
+      const int r = tid / 42, c = tid - r * 42, Y = Y0 + r;
+      rows[r][c] = ((unsigned)Y < 224u) ? reinterpret_cast<const uint4*>(src + ((size_t)n * 224 + Y) * 672)[c] : make_uint4(0, 0, 0, 0);
     }
-  }
-  T* d = dst + ((size_t)n * 115 * 115 + (size_t)y * 115 + x) * 16;
-  if constexpr (sizeof(T) == 2) {
-    uint32_t w[8];
+    __syncthreads();
+    const int y = y0 + yy;
+    if (tid >= 230 || y >= 115) continue;
+    const int ys = y - 2, xs = x - 2;
+    __attribute__((aligned(16))) T v[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) w[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
-    reinterpret_cast<uint4*>(d)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    reinterpret_cast<uint4*>(d)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-  } else {
+    for (int e = 0; e < 16; ++e) v[e] = from_f32<T>(0.f);
+    if ((unsigned)ys < 112u && (unsigned)xs < 112u) {
+      const uint8_t* b0 = reinterpret_cast<const uint8_t*>(rows[2 * yy]) + 6 * xs;
+      const uint8_t* b1 = reinterpret_cast<const uint8_t*>(rows[2 * yy + 1]) + 6 * xs;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) reinterpret_cast<float4*>(d)[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+      for (int e = 0; e < 6; ++e) {
+        v[e] = lut[e % 3][b0[e]];
+        v[6 + e] = lut[e % 3][b1[e]];
+      }
+    }
+    T* d = dst + ((size_t)n * 115 * 115 + (size_t)y * 115 + x) * 16;
+    constexpr int V16 = (int)(16 * sizeof(T) / 16);
+#pragma unroll
+    for (int q = 0; q < V16; ++q) reinterpret_cast<uint4*>(d)[q] = reinterpret_cast<const uint4*>(v)[q];
   }
 }
 
@@ -415,8 +421,8 @@ extern "C" int vdqn_pack_input(const void* src, int32_t src_kind, void* dst, int
   const int g = grid_for((long)n_img * 115 * 115);
   ProfScope ps_("pack_input", 0.0, (double)n_img * (224.0 * 224 * 3 * (src_kind == 0 ? 1 : 4) + 115.0 * 115 * 16 * (dtype == VDQN_BF16 ? 2 : 4)), (hipStream_t)stream);
   if (src_kind == 0 && n_img <= 65535 && (((uintptr_t)src) & 15) == 0) {  // frames are 150528 = 16 * 9408 bytes: every source row is 16-byte aligned
-    if (dtype == VDQN_BF16) hipLaunchKernelGGL((pack_input_rows_kernel<bf16raw>), dim3(58, n_img), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (bf16raw*)dst);
-    else hipLaunchKernelGGL((pack_input_rows_kernel<float>), dim3(58, n_img), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (float*)dst);
+    if (dtype == VDQN_BF16) hipLaunchKernelGGL((pack_input_rows_kernel<bf16raw>), dim3((58 + kPackPairs - 1) / kPackPairs, n_img), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (bf16raw*)dst);
+    else hipLaunchKernelGGL((pack_input_rows_kernel<float>), dim3((58 + kPackPairs - 1) / kPackPairs, n_img), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (float*)dst);
     VDQN_LAUNCH_CHECK();
     return VDQN_OK;
   }
