@@ -102,6 +102,7 @@ _SIGS = {
     "vdqn_stem_wgrad_pool_workspace_bytes": (c_i64, [c_i32]),
     "vdqn_net_set_overlap": (C.c_int, [c_vp, C.c_int]),
     "vdqn_net_grad_stream": (c_vp, [c_vp]),
+    "vdqn_net_aux_stream": (c_vp, [c_vp]),
     "vdqn_net_set_bn_sync": (C.c_int, [c_vp, c_vp, c_vp, c_i32]),
     "vdqn_net_num_params": (C.c_int, [c_vp]),
     "vdqn_net_param_info": (C.c_int, [c_vp, C.c_int, C.POINTER(ParamInfo)]),

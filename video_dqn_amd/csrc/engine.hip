@@ -1622,6 +1622,11 @@ extern "C" void* vdqn_net_grad_stream(vdqn_net* net) {
   return (void*)net->side;
 }
 
+extern "C" void* vdqn_net_aux_stream(vdqn_net* net) {
+  if (!net || !side_ready(net)) return nullptr;
+  return (void*)net->side2;
+}
+
 extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream) {
   VDQN_CHECK(net && a && a->grads, "vdqn_net_backward_stage: null arg");
   VDQN_CHECK(stage >= 0 && stage < 3, "vdqn_net_backward_stage: stage %d", stage);

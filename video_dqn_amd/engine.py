@@ -33,6 +33,9 @@ _EARLY_ADAM = os.environ.get("VDQN_EARLY_ADAM", "1") != "0"
 # packs on the other stream, so nothing is exposed there, while the moved fold lengthens the gradient stream that carries every
 # weight gradient.  Kept as a tested switch (bit-identical updates).
 _EARLY_FOLD = os.environ.get("VDQN_EARLY_FOLD", "0") == "1"
+# VDQN_AUX_STREAM=1: work of the NEXT update that runs under the current one (frames packed ahead, early fold) goes to the engine's
+# auxiliary low-priority stream (vdqn_net_aux_stream) instead of the gradient stream, where it delays no weight gradient
+_AUX_STREAM = os.environ.get("VDQN_AUX_STREAM", "0") == "1"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -332,6 +335,7 @@ class TDStepper:
         self.adam_step = 0
         self.sample_number = 0
         self._grad_stream = None  # torch view of the engine's side stream (vdqn_net_grad_stream)
+        self._aux_stream, self._aux_used = None, False  # ... and of its auxiliary low-priority stream
         self._adam_done = []
         self._prefolded, self._prefold_key = 0, None  # stages of packed_online refreshed behind their early Adam, and for which parameters
         self._packed_bufs, self._ahead = [None, None], None
@@ -390,9 +394,10 @@ class TDStepper:
         half = buf.numel() // 2
         dt = _lib.VDQN_BF16 if n.dtype_name == "bf16" else _lib.VDQN_F32
         main = torch.cuda.current_stream()
-        with self._grad_stream_ctx():
+        with (self._aux_stream_ctx() if _AUX_STREAM else self._grad_stream_ctx()):
             # the announced tensors may have been produced on the caller's stream a moment ago (a host-to-device copy, a gather)
             torch.cuda.current_stream().wait_stream(main)
+            self._aux_used = self._aux_used or _AUX_STREAM
             _lib.check(self.lib.vdqn_pack_input(_ptr(nb), int(nk), buf.data_ptr(), nf, dt, _stream()), "vdqn_pack_input")
             if na is not None and not self.gtb:
                 _lib.check(self.lib.vdqn_pack_input(_ptr(na), int(nk), buf.data_ptr() + half, nf, dt, _stream()), "vdqn_pack_input")
@@ -412,6 +417,9 @@ class TDStepper:
         with torch.cuda.device(n.device):
             a = self._args(before, after, src_kind, act, rew, term, valid if valid is not None else self._ones, gt)
             st = _stream()
+            if self._aux_used:  # what the previous update queued on the auxiliary stream (packed frames, folded weights) is consumed now
+                torch.cuda.current_stream().wait_stream(self._aux_stream)
+                self._aux_used = False
             ahead, self._ahead = self._ahead, None
             slot = None
             if ahead is not None and ahead[0] == self._frames_key(before, after, src_kind):
@@ -447,12 +455,29 @@ class TDStepper:
                             # them any more: the stage's data gradients are done), so that update starts with a 0.7 M-parameter fold
                             # instead of a 12.4 M one in front of its first convolution
                             if _EARLY_FOLD and (b, e) == tuple(self.stage_ranges[stage]):
-                                _lib.check(self.lib.vdqn_net_pack_weights_stage(n.handle, _ptr(n.params), _ptr(n.bnstats), _ptr(self.packed_online),
-                                                                                1, stage, _stream()), "vdqn_net_pack_weights_stage")
+                                fold_ctx = contextlib.nullcontext()
+                                if _AUX_STREAM:
+                                    done = torch.cuda.Event()
+                                    done.record()  # this stage's Adam, on the gradient stream
+                                    fold_ctx = self._aux_stream_ctx()
+                                with fold_ctx:
+                                    if _AUX_STREAM:
+                                        torch.cuda.current_stream().wait_event(done)
+                                        self._aux_used = True
+                                    _lib.check(self.lib.vdqn_net_pack_weights_stage(n.handle, _ptr(n.params), _ptr(n.bnstats), _ptr(self.packed_online),
+                                                                                    1, stage, _stream()), "vdqn_net_pack_weights_stage")
                                 prefolded |= 1 << stage
                         self._adam_done.append((b, e))
         self._prefolded = prefolded
         del keep
+
+    def _aux_stream_ctx(self):
+        ptr = self.lib.vdqn_net_aux_stream(self.net.handle)
+        if not ptr:
+            return contextlib.nullcontext()
+        if self._aux_stream is None or self._aux_stream.cuda_stream != ptr:
+            self._aux_stream = torch.cuda.ExternalStream(ptr, device=self.net.device)
+        return torch.cuda.stream(self._aux_stream)
 
     def _grad_stream_ctx(self):
         ptr = self.lib.vdqn_net_grad_stream(self.net.handle)
