@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="skip the event-profiled steps (roofline = null)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes for roofline.traffic "
+                                                                 "(the committed passes of profiles/pmc_latest.json are quoted instead)")
     ap.add_argument("--pack-ahead", action="store_true",
                     help="pack the next minibatch's frames under the current update's backward pass (default: every update packs its own frames at its start)")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -117,6 +119,45 @@ def cpu_baseline(batch: int, budget_s: float = 25.0):
             "multi_threads": threads, "host_cores_visible": avail}
 
 
+def live_pmc_traffic(args):
+    """HBM bytes per launch of every kernel, measured NOW: two rocprofv3 child passes (--kernel-trace --pmc FETCH_SIZE, then
+    --pmc WRITE_SIZE: separate passes, no other tracing, the program itself behind `--`, as MI355X_MICROARCH.md prescribes) of this
+    bench command at 2 steps with the side streams serialised, started BEFORE this process touches the GPU.  Corrections as in
+    tools/pmc_summary.py (FETCH_SIZE counts half of wide streaming reads on gfx950).  Returns {kernel tag: bytes per launch} or
+    None (no rocprofv3, a failed pass, VDQN_BENCH_NO_LIVE_PMC=1 / --no-live-pmc): the caller then quotes the committed passes."""
+    import shutil
+    import subprocess
+    import tempfile
+    if args.no_live_pmc or os.environ.get("VDQN_BENCH_NO_LIVE_PMC") == "1" or shutil.which("rocprofv3") is None:
+        return None
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None  # this process is itself being profiled
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import per_kernel
+        tmp = tempfile.mkdtemp(prefix="vdqn_pmc_", dir="/tmp")
+        tot = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline",
+                   "--no-profile", "--no-live-pmc", "--pool", "1", "--batch", str(args.batch), "--frames", str(args.frames), "--dtype", args.dtype,
+                   "--arch", args.arch, "--loss-kind", args.loss_kind]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", VDQN_NO_OVERLAP="1"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=180)
+            if r.returncode != 0:
+                return None
+            csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, counter)) for f in fs if f.endswith("counter_collection.csv")]
+            if not csvs:
+                return None
+            tot[counter] = per_kernel(csvs[0], counter)
+        (ft, fc), (wt, wc) = tot["FETCH_SIZE"], tot["WRITE_SIZE"]
+        out = {t: int(round(2 * 1024 * ft[t] / max(fc[t], 1) + 1024 * wt[t] / max(wc[t], 1))) for t in set(ft) | set(wt)}
+        shutil.rmtree(tmp, ignore_errors=True)
+        return out
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel: str, batch: int, frames: int, dtype: str, arch: str = "extra_capacity"):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_latest.json: rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes).
@@ -145,6 +186,8 @@ def main():
     out_stream = launch.claim_stdout()  # the JSON line goes here; fd 1 now points at stderr (native-library chatter)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    # roofline.traffic, live: PMC child passes before this process initialises the GPU (one process, the default path only)
+    live_traffic = live_pmc_traffic(args) if (world == 1 and not args.no_profile and not args.force_dist and args.h2d == "none") else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     if os.environ.get("VDQN_BENCH_SINGLE_DEVICE") == "1":
@@ -310,10 +353,14 @@ def main():
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         if v["flops"] > 0:
             ach = v["flops"] / v["ms"] / 1e9
+            live = (live_traffic or {}).get(name)
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B, F, args.dtype, args.arch),
-                        "traffic_source": "profiles/pmc_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                          "command (PMC cannot be collected from inside the process), per launch",
+                        "frac": round(ach / peak, 4), "traffic": live if live else pmc_traffic(name, B, F, args.dtype, args.arch),
+                        "traffic_source": ("live: two rocprofv3 child passes of this command (--kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE; "
+                                           "2 steps, side streams serialised) run before the timed region; 2 x FETCH_SIZE + WRITE_SIZE per launch"
+                                           if live else
+                                           "profiles/pmc_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command, committed (the live child passes were skipped or failed), per launch"),
                         "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
                         "alg_flops_per_launch": round(v["flops"] / v["launches"]),
                         "alg_bytes_per_launch": round(v["bytes"] / v["launches"]),

@@ -18,6 +18,7 @@ def _env(**kw):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
+    env.setdefault("VDQN_BENCH_NO_LIVE_PMC", "1")  # (the rocprofv3 child passes behind roofline.traffic have a test of their own)
     env.update(kw)
     return env
 
@@ -246,3 +247,17 @@ def test_two_gpus_rccl_equal_one_big_batch(tmp_path, arch_ec):
     nt = net.trainable_numel
     d = (net.params.cpu()[:nt] - r0["params"][:nt]).abs()
     assert d.max().item() <= 2.5e-4 and d.mean().item() < (2e-6 if arch_ec else 2e-5)
+
+
+def test_bench_roofline_traffic_is_measured_live():
+    """bench.py's `roofline.traffic` comes from two rocprofv3 --pmc child passes of the same command started before the process
+    touches the GPU (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md): present, labelled live, and of the order of
+    the kernel's algorithmic bytes (0.5x .. 4x).  Skipped where rocprofv3 is absent."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("no rocprofv3 on this box")
+    out = _bench(["--ramp-seconds", "0", "--batch", "32", "--steps", "3", "--warmup", "1", "--profile-steps", "1", "--no-cpu-baseline", "--pool", "1"],
+                 VDQN_BENCH_NO_LIVE_PMC="0")
+    r = out["roofline"]
+    assert r is not None and r["traffic"] is not None and r["traffic_source"].startswith("live"), r
+    assert 0.5 * r["alg_bytes_per_launch"] <= r["traffic"] <= 4.0 * r["alg_bytes_per_launch"], r

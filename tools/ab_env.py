@@ -33,7 +33,7 @@ def main():
     kern = {n: [] for n, _ in variants}
     for r in range(rounds):
         for name, env in variants:
-            e = dict(os.environ)
+            e = dict(os.environ, VDQN_BENCH_NO_LIVE_PMC="1")  # (roofline.traffic is not what an A/B compares)
             e.update(env)
             p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "20", "--no-cpu-baseline"] + extra,
                                env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/records_$TAG
 mkdir -p $O
 cd $R
+export VDQN_BENCH_NO_LIVE_PMC=1  # the PMC child passes belong to the headline run (tools/profile_round.sh), not to every record
 B="python3 bench.py --no-cpu-baseline"
 $B                                          > $O/${TAG}_bench_c2.json 2> $O/err.log
 $B --frames 12 --batch 16                   > $O/${TAG}_bench_f12_b16.json 2>> $O/err.log

@@ -95,7 +95,7 @@ def main():
         rec["runs"][tag] = {"rc": 0, "steps": steps, "workers": workers, "timed_updates": last - first, "seconds": round(dt, 4),
                             "ms_per_update": round(1e3 * dt / (last - first), 4), "tuples_per_s": round(args.batch * (last - first) / dt, 1),
                             "startup_seconds_to_first_update": round(stamps[ns[0]] - t0, 2), "process_seconds": round(t1 - t0, 2)}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "20", "--no-cpu-baseline"], cwd=ROOT,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "20", "--no-cpu-baseline", "--no-live-pmc"], cwd=ROOT,
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if line:
