@@ -282,6 +282,9 @@ class HabitatDQNMultiAction(nn.Module):
                 raise Exception("bad shape")
             inp = inp.float()
             src_kind = 1
+        if inp.requires_grad:
+            raise NotImplementedError("HabitatDQNMultiAction on the HIP engine differentiates with respect to its parameters only "
+                                      "(the reference never asks for the gradient of a frame): detach the input")
         b = inp.shape[0]
         inp = inp.to(eng.device).contiguous()
         if b > eng.max_batch:
