@@ -676,7 +676,7 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_WGRAD_WINDOW": "1"},       # round 2's choice: 64x64 window weight-gradient tiles up to 256 channels, generic 128x128 tiles for layer4
     {"VDQN_WGRAD_WIN128": "1"},       # eight-wave 128x128 window weight-gradient tiles for the 128+ channel layers
     {"VDQN_WGRAD_TWO_STAGE": "1"},    # split-K partials as plain stores + ordered reduce kernels instead of f32 atomics
-    {"VDQN_WGRAD_STREAMS": "2"},      # weight gradients alternate between the two side streams
+    {"VDQN_WGRAD_STREAMS": "1"},      # all weight gradients on ONE side stream (default: alternating between the two)
     {"VDQN_S2WIN": "0"},              # stride-2 3x3 forward convolutions on the generic kernel (no plane-window kernel)
     {"VDQN_STEM_NOIDX": "0"},         # the stem writes the max-pool arg-max bytes of the no-grad frames too
     {"VDQN_EARLY_ADAM": "0"},         # TDStepper.step: one Adam launch behind the whole backward pass

@@ -190,12 +190,14 @@ void join_side2(vdqn_net* net, hipStream_t main) {
   (void)hipStreamWaitEvent(main, e, 0);
 }
 
-// Stream of the next weight-gradient launch.  VDQN_WGRAD_STREAMS=2: the launches alternate between the two side streams, so that
-// one kernel's tail (a single round of split-K blocks that all end in f32 atomics) runs beside the next kernel's start; not in the
-// deterministic / two-stage modes, whose partial copies share one workspace.  The stage's unfold kernel waits for both
-// (join_wgrad_streams).
+// Stream of the next weight-gradient launch.  The launches alternate between the two side streams, so that one kernel's tail (a
+// single round of split-K blocks that all end in f32 atomics) runs beside the next kernel's start; not in the deterministic /
+// two-stage modes, whose partial copies share one workspace.  The stage's unfold kernel waits for both (join_wgrad_streams).
+// Round 4: default ON now that the side streams run below the caller's stream in priority — seven alternating rounds on one box:
+// better in five, equal in two, median 5.828 against 5.900 ms per update (profiles/r04n_ab_wgrad_two_low_priority_streams.txt;
+// at equal priorities round 3 had measured no gain).  VDQN_WGRAD_STREAMS=1 keeps them on one stream.
 bool wgrad_two_streams(const vdqn_net* net) {
-  static const bool on = [] { const char* e = getenv("VDQN_WGRAD_STREAMS"); return e && atoi(e) == 2; }();
+  static const bool on = [] { const char* e = getenv("VDQN_WGRAD_STREAMS"); return !e || atoi(e) == 2; }();
   static const bool two_stage = [] { const char* e = getenv("VDQN_WGRAD_TWO_STAGE"); return e && e[0] == '1'; }();
   return on && !two_stage && !net->cfg.deterministic;
 }
