@@ -25,14 +25,14 @@ namespace {
 
 // One chunk = 32 consecutive k of every operand row.  Linear layers: row m of A starts at in + m * pix_stride.  CONV (features.8
 // forward: r x s valid convolution, stride 1): row m = (img, oy, ox) and chunk c covers tap c * 32 / ci, channels (c * 32) % ci.
-// kDepth = chunks in flight per wave
-template <int TM, int TN, bool CONV, int kDepth>
-__global__ __launch_bounds__(256, 2) void skinny_kernel(const IgemmParams p, const int n_chunks, const FastDiv d_wo, const FastDiv d_howo) {
+// kDepth = chunks in flight per wave; NW = waves per workgroup (the K range is split NW ways)
+template <int TM, int TN, bool CONV, int kDepth, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const IgemmParams p, const int n_chunks, const FastDiv d_wo, const FastDiv d_howo) {
   using T = bf16raw;
   constexpr int FM = TM / 16, FN = TN / 16;
   constexpr int PITCH = TN + 4;  // f32 row pitch of a partial tile in LDS
   extern __shared__ __attribute__((aligned(16))) unsigned char skinny_smem[];
-  float (*sRed)[TM][PITCH] = reinterpret_cast<float (*)[TM][PITCH]>(skinny_smem);  // [4 waves][TM][PITCH]
+  float (*sRed)[TM][PITCH] = reinterpret_cast<float (*)[TM][PITCH]>(skinny_smem);  // [NW waves][TM][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const int tile_n = (int)(blockIdx.x % (unsigned)p.tiles_n), tile_m = (int)(blockIdx.x / (unsigned)p.tiles_n);
@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256, 2) void skinny_kernel(const IgemmParams p, con
 #pragma unroll
   for (int j = 0; j < FN; ++j) w_base[j] = reinterpret_cast<const unsigned char*>(p.wt) + (long)(n0 + j * 16 + i16) * p.ktot * 2 + g * 16;
 
-  // chunk c of this wave = global chunk wave + 4 c
-  const int my_chunks = (n_chunks - wave + 3) >> 2;
-  auto a_off = [&](int c) -> long {  // byte offset of global chunk (wave + 4 c) inside an A row
-    const int k = (wave + 4 * c) * 32;
+  // chunk c of this wave = global chunk wave + NW c
+  const int my_chunks = (n_chunks - wave + NW - 1) / NW;
+  auto a_off = [&](int c) -> long {  // byte offset of global chunk (wave + NW c) inside an A row
+    const int k = (wave + NW * c) * 32;
     if constexpr (CONV) {
       const int tap = k / p.ci, c0 = k - tap * p.ci;
       const int ky = tap / p.s, kx = tap - ky * p.s;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void skinny_kernel(const IgemmParams p, con
   auto load = [&](int d, int c) {
     c = c < my_chunks ? c : (my_chunks > 0 ? my_chunks - 1 : 0);  // beyond the end: re-load the last chunk (unused)
     const long ao = a_off(c);
-    const long wo = (long)(wave + 4 * c) * 64;
+    const long wo = (long)(wave + NW * c) * 64;
 #pragma unroll
     for (int i = 0; i < FM; ++i) fa[d][i] = *reinterpret_cast<const uint4*>(a_base[i] + ao);
 #pragma unroll
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void skinny_kernel(const IgemmParams p, con
 
   // epilogue: thread -> (row, four consecutive columns)
   constexpr int TPR = TN / 4;          // threads per row
-  constexpr int RPP = 256 / TPR;       // rows per pass
+  constexpr int RPP = 64 * NW / TPR;   // rows per pass
   const int er = tid / TPR, ec = (tid % TPR) * 4;
   const int ncol = n0 + ec;
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void skinny_kernel(const IgemmParams p, con
     const int m = m0 + r;
     f32x4 v = *reinterpret_cast<const f32x4*>(&sRed[0][r][ec]);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(&sRed[w][r][ec]);
       v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
     }
@@ -207,13 +207,13 @@ extern "C" int32_t vdqn_conv2d_colsum_rows(const vdqn_conv_args* a) {
 }
 
 namespace {
-template <int TM, int TN, bool CONV, int D>
+template <int TM, int TN, bool CONV, int D, int NW = 4>
 void launch_cfg(IgemmParams& p, int n_chunks, hipStream_t stream) {
   p.tiles_m = (p.M + TM - 1) / TM;
   p.tiles_n = (p.co + TN - 1) / TN;
-  constexpr size_t smem = 4 * TM * (TN + 4) * 4;
-  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&skinny_kernel<TM, TN, CONV, D>), smem);
-  hipLaunchKernelGGL((skinny_kernel<TM, TN, CONV, D>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), smem, stream, p, n_chunks,
+  constexpr size_t smem = (size_t)NW * TM * (TN + 4) * 4;
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&skinny_kernel<TM, TN, CONV, D, NW>), smem);
+  hipLaunchKernelGGL((skinny_kernel<TM, TN, CONV, D, NW>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * NW), smem, stream, p, n_chunks,
                      make_fastdiv((uint32_t)(CONV ? p.wo : 1)), make_fastdiv((uint32_t)(CONV ? p.howo : 1)));
 }
 }  // namespace
@@ -238,6 +238,11 @@ int vdqn_launch_skinny(const void* pv, int kind, hipStream_t stream) {
       case 3: launch_cfg<64, 32, true, 6>(p, n_chunks, stream); break;
       case 4: launch_cfg<32, 32, true, 8>(p, n_chunks, stream); break;
       case 5: launch_cfg<64, 64, true, 2>(p, n_chunks, stream); break;
+      // eight waves (twice the loads in flight per CU): 43.9 / 42.2 us at 512 / 256 frames against 40.8 / 31.7 — the kernel is not
+      // bound by loads in flight; its im2col re-reads (9 taps of a 125 KB working set per workgroup) come from beyond L2
+      // (profiles/r04p_bench_head_f8_eight_waves.txt)
+      case 6: launch_cfg<64, 64, true, 4, 8>(p, n_chunks, stream); break;
+      case 7: launch_cfg<32, 64, true, 6, 8>(p, n_chunks, stream); break;
       default: launch_cfg<64, 64, true, 4>(p, n_chunks, stream); break;
     }
   }
