@@ -684,6 +684,7 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_FOLD_SPLIT": "1"},         # weight fold of stage 2's layers first, the rest on the side stream beside the stem
     {"VDQN_STEM_WGRAD_MAIN": "0"},    # conv1's weight gradient on the side stream behind block 0's instead of beside them
     {"VDQN_SKINNY": "0"},             # the Q-head's layers on the generic tiled kernel instead of the skinny GEMM kernels
+    {"VDQN_SKINNY_CONV_CFG": "9"},    # features.8 on the skinny kernel that reads its input from global memory (default: images in LDS)
     {"VDQN_SIDE_PRIORITY": "normal"}, # the side streams at the caller's stream priority (default: below it)
     {"VDQN_EARLY_FOLD": "1", "VDQN_PACK_TWO_STREAMS": "1"},  # stage 0 / 1 weights folded behind their early Adam; the two input packs on two streams
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))

@@ -58,7 +58,7 @@ def test_linear_dgrad_with_mask_and_column_sums(B, fin, fout):
     assert float(gx.view(B, fout).float()[act.to(DEV).float() <= 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n", [512, 3, 77])
+@pytest.mark.parametrize("n", [512, 3, 77, 1])
 def test_features8_valid_conv_forward(n):
     from video_dqn_amd import ops
     x = rnd(11, "x", (n, 7, 7, 512)).to(BF)

@@ -174,6 +174,136 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   }
 }
 
+// features.8 with its input images in LDS: a workgroup owns G whole images (G * ho * wo <= 64 output pixels, G = 2 for the 7 x 7 -> 5 x 5
+// geometry), stages their hi * wi pixels ONCE by LDS-DMA (one 2 ci-byte pixel per DMA piece at a pitch of 2 ci + 32 bytes: the lanes
+// of a fragment read then fall on different bank quads) and serves all r * s taps from there — the skinny kernel above re-reads every
+// input pixel nine times from beyond L2 (a workgroup's 125 KB working set, 41 us at 512 frames whatever the tile or the depth).  The
+// weights still come straight from global memory (each element is used once per workgroup), kDepth chunks ahead; the K range (tap,
+// 32-channel chunk) is split over the four waves as above, one reduction through LDS (over the consumed images), same epilogue.
+template <int kDepth>
+__global__ __launch_bounds__(256, 1) void f8_lds_kernel(const IgemmParams p, const int n_chunks, const int g_img, const int pitch) {
+  using T = bf16raw;
+  constexpr int TM = 64, TN = 64, FM = 4, FN = 4, NW = 4;
+  constexpr int PITCH = TN + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char f8_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int img0 = (int)blockIdx.x * g_img;
+  const int n_here = min(g_img, p.n_img - img0);
+  const int rows_here = n_here * p.howo;      // valid output pixels of this workgroup
+  const int hw_in = p.hi * p.wi;
+
+  // ---- stage the images: pixel q (0 .. n_here * hi * wi) -> LDS offset q * pitch, 2 ci bytes = ci / 32 pieces of 64 lanes x 16 B...
+  // one wave-instruction moves 1024 bytes: a pixel of ci = 512 channels is exactly one piece
+  {
+    const unsigned long long a_ptr = (unsigned long long)p.in + (unsigned long long)img0 * hw_in * p.pix_stride * 2;
+    const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
+                        __builtin_amdgcn_readfirstlane(n_here * hw_in * p.pix_stride * 2), 0x00020000};
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)f8_smem;
+    const int pieces_per_pix = p.ci * 2 / 1024;
+    const int n_pieces = n_here * hw_in * pieces_per_pix;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int pc = wave_u; pc < n_pieces; pc += NW) {
+      const int pix = pc / pieces_per_pix, part = pc - pix * pieces_per_pix;
+      const uint32_t voff = (uint32_t)(pix * p.pix_stride * 2 + part * 1024 + lane * 16);
+      const uint32_t l_ = lds_base + (uint32_t)(pix * pitch + part * 1024);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(voff), "s"(l_), "s"(rs_a) : "memory");
+    }
+  }
+
+  // per-lane rows: local output pixel r -> (image, oy, ox) -> LDS byte offset of input pixel (oy, ox) of that image
+  uint32_t a_lds[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int r = i * 16 + i16;
+    r = r < rows_here ? r : rows_here - 1;
+    const int im = r / p.howo, rem = r - im * p.howo;
+    const int oy = rem / p.wo, ox = rem - oy * p.wo;
+    a_lds[i] = (uint32_t)((im * hw_in + oy * p.wi + ox) * pitch + g * 16);
+  }
+  const unsigned char* __restrict__ w_base[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) w_base[j] = reinterpret_cast<const unsigned char*>(p.wt) + (long)(j * 16 + i16) * p.ktot * 2 + g * 16;
+
+  const int my_chunks = (n_chunks - wave + NW - 1) / NW;
+  const int cpt = p.ci / 32;  // 32-deep chunks per tap
+  uint4 fb[kDepth][FN];
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_w = [&](int d, int c) {
+    c = c < my_chunks ? c : (my_chunks > 0 ? my_chunks - 1 : 0);
+    const long wo = (long)(wave + NW * c) * 64;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb[d][j] = *reinterpret_cast<const uint4*>(w_base[j] + wo);
+  };
+  if (my_chunks > 0) {
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) load_w(d, d);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also the first weight fragments: simple, once per workgroup)
+  __syncthreads();                                   // the images are in LDS for every wave
+  if (my_chunks > 0) {
+    for (int c = 0; c < my_chunks; c += kDepth) {
+#pragma unroll
+      for (int d = 0; d < kDepth; ++d) {
+        if (c + d < my_chunks) {
+          const int ch = wave + NW * (c + d);
+          const int tap = ch / cpt, c32 = ch - tap * cpt;
+          const int ky = tap / p.s, kx = tap - ky * p.s;
+          const uint32_t toff = (uint32_t)((ky * p.wi + kx) * pitch + c32 * 64);
+          uint4 fa[FM];
+#pragma unroll
+          for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const uint4*>(f8_smem + a_lds[i] + toff);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[d][j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+          load_w(d, c + d + kDepth);
+        }
+      }
+    }
+  }
+  __syncthreads();  // every wave is done reading the images: LDS becomes the reduction buffer
+  float (*sRed)[TM][PITCH] = reinterpret_cast<float (*)[TM][PITCH]>(f8_smem);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(&sRed[wave][i * 16 + i16][j * 16 + g * 4]) = acc[i][j];
+  __syncthreads();
+  constexpr int TPR = TN / 4, RPP = 256 / TPR;
+  const int er = tid / TPR, ec = (tid % TPR) * 4;
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  float bv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bv[e] = (p.bias && ec + e < p.co) ? p.bias[ec + e] : 0.f;
+#pragma unroll
+  for (int it = 0; it < TM / RPP; ++it) {
+    const int r = it * RPP + er;
+    if (r >= rows_here || ec >= p.co) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&sRed[0][r][ec]);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(&sRed[w][r][ec]);
+      v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    T ov[4];
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[e] = v[e] + bv[e];
+      if (p.relu) x[e] = fmaxf(x[e], 0.f);
+      ov[e] = from_f32<T>(x[e]);
+    }
+    const size_t m = (size_t)img0 * p.howo + r;
+    if (out) *reinterpret_cast<uint2*>(out + m * p.ldo + ec) = *reinterpret_cast<const uint2*>(ov);
+    if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + m * p.ldo + ec) = make_float4(x[0], x[1], x[2], x[3]);
+  }
+}
+
 }  // namespace
 
 // rows of `out` one entry of colsum_part covers when vdqn_launch_skinny takes a call (the generic kernels: 128)
@@ -230,9 +360,26 @@ int vdqn_launch_skinny(const void* pv, int kind, hipStream_t stream) {
     // VDQN_SKINNY_CONV_CFG: tile / prefetch-depth variants of the features.8 kernel (measurement switch)
     static const int cfg = [] { const char* e = getenv("VDQN_SKINNY_CONV_CFG"); return e ? atoi(e) : 0; }();
     vdqn_prof_begin("skinny<bf16,conv>", flops, bytes, stream);
+    // default (VDQN_SKINNY_CONV_CFG unset or 8): the input images of a workgroup in LDS (f8_lds_kernel) where the geometry allows it:
+    // pixels of whole 1 KB pieces, at least one image per 64-row tile, the images of a tile within 150 KB
+    {
+      const int g_img = p.howo > 0 ? 64 / p.howo : 0;
+      const int pitch = p.ci * 2 + 32;  // +8 banks per pixel, +4 per K group: the 16 lanes of a ds_read_b128 group cover all 64 banks once
+      const size_t img_bytes = (size_t)g_img * p.hi * p.wi * pitch;
+      const size_t smem = img_bytes > (size_t)4 * 64 * 68 * 4 ? img_bytes : (size_t)4 * 64 * 68 * 4;
+      if ((cfg == 0 || cfg == 8) && g_img >= 1 && (p.ci * 2) % 1024 == 0 && p.pix_stride == p.ci && smem <= 150 * 1024 && p.co == 64 &&
+          (long long)p.n_img * p.hi * p.wi * p.ci * 2 < 0x7fffffffLL) {
+        // (four weight chunks in flight per wave: 26.3 us at 512 frames; eight 27.9, twelve 29.6 — profiles/r04r_bench_head_f8_lds.txt)
+        vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&f8_lds_kernel<4>), smem);
+        hipLaunchKernelGGL((f8_lds_kernel<4>), dim3((unsigned)((p.n_img + g_img - 1) / g_img)), dim3(256), smem, stream, p, n_chunks, g_img, pitch);
+        vdqn_prof_end(stream);
+        VDQN_LAUNCH_CHECK();
+        return VDQN_OK;
+      }
+    }
     // default: 64 x 64 tiles; a launch of at most 128 of them (the target network's 256 frames) runs on 32-row tiles instead — twice
     // the workgroups on a chip that would be half empty (measured 39 -> 32 us at 256 frames, 41 -> 60 us at 512: tools/bench_head.py)
-    switch (cfg ? cfg : (p.M <= 64 * 128 ? 1 : 0)) {
+    switch ((cfg && cfg != 9) ? cfg : (p.M <= 64 * 128 ? 1 : 0)) {  // (9: the global-memory kernel with its default tile choice)
       case 1: launch_cfg<32, 64, true, 6>(p, n_chunks, stream); break;
       case 2: launch_cfg<32, 64, true, 8>(p, n_chunks, stream); break;
       case 3: launch_cfg<64, 32, true, 6>(p, n_chunks, stream); break;
