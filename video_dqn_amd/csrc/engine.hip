@@ -298,10 +298,15 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldTable tab, const fl
 // (Wf rows [co][tap][c], Wd rows [c][tap][co]).  The element-wise kernel above read the master weights with a stride of `taps`
 // floats for Wf and of ci*taps floats for Wd: 706 MB of HBM traffic per launch for ~150 MB of algorithmic bytes (PMC).
 // grid: (64x64-channel tiles over all tiled layers, 2 halves of 32 output channels)
+#ifndef VDQN_FOLD_COT
+#define VDQN_FOLD_COT 32
+#endif
+constexpr int kFoldCot = VDQN_FOLD_COT;  // output channels per fold_tile block (a build-time choice: 64 / kFoldCot blocks per 64 x 64 tile)
+
 template <typename T, int TAPS>
 __device__ __forceinline__ void fold_tile_body(const FoldDesc& d, const float* __restrict__ params, const float* __restrict__ bnstats,
                                                unsigned char* __restrict__ packed, int with_dgrad, int raw, float* sW, float* s_scale, int t, int cot_sub) {
-  constexpr int COT = 32;              // output channels per block
+  constexpr int COT = kFoldCot;        // output channels per block
   constexpr int RUN = 64 * TAPS;       // floats per output channel in this tile (contiguous in OIHW)
   constexpr int PITCH = RUN + 1;       // LDS row pitch: odd, so the column walk of the Wd pass spreads over the banks
   const int ci_tiles = d.ci / 64;
@@ -1276,18 +1281,18 @@ static int pack_weights_layers(vdqn_net* net, const float* params, const float* 
   }
   const double share = (double)n_layers / (double)net->layers.size();
   ProfScope ps_("fold_weights", 0.0, ((double)net->trainable_numel * 4.0 + (double)net->packed_bytes * (dgrad ? 1.0 : 0.5)) * share, stream);
-  const size_t tile_smem = 32 * (64 * 9 + 1) * 4;  // [32 output channels][64 * taps + 1] f32
+  const size_t tile_smem = kFoldCot * (64 * 9 + 1) * 4;  // [kFoldCot output channels][64 * taps + 1] f32
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&fold_tile_kernel<bf16raw>), (size_t)tile_smem);
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&fold_tile_kernel<float>), (size_t)tile_smem);
   if (net->cfg.dtype == VDQN_BF16) {
     hipLaunchKernelGGL((fold_kernel<bf16raw>), grid, dim3(256), 0, stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw, first_layer);
     if (tile_first >= 0)
-      hipLaunchKernelGGL((fold_tile_kernel<bf16raw>), dim3(tile_end - tile_first, 2), dim3(256), tile_smem, stream, net->fold, params, bnstats,
+      hipLaunchKernelGGL((fold_tile_kernel<bf16raw>), dim3(tile_end - tile_first, 64 / kFoldCot), dim3(256), tile_smem, stream, net->fold, params, bnstats,
                          (unsigned char*)packed, dgrad, raw, tile_first);
   } else {
     hipLaunchKernelGGL((fold_kernel<float>), grid, dim3(256), 0, stream, net->fold, params, bnstats, (unsigned char*)packed, dgrad, raw, first_layer);
     if (tile_first >= 0)
-      hipLaunchKernelGGL((fold_tile_kernel<float>), dim3(tile_end - tile_first, 2), dim3(256), tile_smem, stream, net->fold, params, bnstats,
+      hipLaunchKernelGGL((fold_tile_kernel<float>), dim3(tile_end - tile_first, 64 / kFoldCot), dim3(256), tile_smem, stream, net->fold, params, bnstats,
                          (unsigned char*)packed, dgrad, raw, tile_first);
   }
   VDQN_LAUNCH_CHECK();
