@@ -206,9 +206,6 @@ def main():
     from video_dqn_amd.engine import NetEngine, TDStepper
     from video_dqn_amd.dist import BucketAllReduce
 
-    # VDQN_MAIN_PRIORITY=high (measurement switch): the whole loop on a high-priority stream of its own instead of the default stream
-    if os.environ.get("VDQN_MAIN_PRIORITY") == "high":
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     B, F = args.batch, args.frames
     ec = args.arch == "extra_capacity"
     net = NetEngine(3, 5, F, ec, args.dtype, 2 * B, device=dev, deterministic=(True if args.deterministic else None))
