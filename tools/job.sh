@@ -8,7 +8,7 @@
 #   profile        rocprofv3 kernel stats (serial + overlap) and the event-profiled bench line: tools/profile_round.sh
 #   pmc            rocprofv3 --pmc passes (MFMA busy, LDS conflicts, HBM traffic): tools/pmc_mfma.sh
 #   records        the other configurations of BASELINE.json and the mode records: tools/records_round.sh
-#   ab:<a>@<b>     alternating bench runs of two environments, e.g. ab:new:@old:VDQN_SKINNY=0,VDQN_DS_STREAM=0
+#   ab:<a>@<b>     alternating bench runs of two environments, e.g. ab:new:@old:VDQN_SKINNY=0,VDQN_WGRAD_STREAMS=1
 #   e2e            the trainer-loop throughput record next to bench.py: tools/trainer_e2e.py
 #   head           per-launch times of the Q-head's layers: tools/bench_head.py
 #   diag:<script>  python tools/<script>.py (diag_bf16_emulation, diag_basic_outlier, ...), output captured
