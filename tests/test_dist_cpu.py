@@ -95,3 +95,35 @@ def test_ddp_equals_big_batch(tmp_path):
         ref = dict(tr.model.named_parameters())[s.name].grad.reshape(-1)
         g = got["flat"][s.offset:s.offset + s.numel]
         assert (g - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-12, s.name
+
+
+def _worker_loss(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from video_dqn_amd.dist import BucketAllReduce
+    comm = BucketAllReduce(world)
+    got = []
+    for step in range(3):  # the two buffers are used in turn; a result is only valid until the launch after next
+        comm.launch_loss(torch.tensor([float(rank + 1) * (step + 1)]))
+        buf, work = comm.take_loss()
+        work.wait()
+        got.append(float(buf))
+        assert comm.take_loss() is None  # taken once
+    if rank == 0:
+        torch.save(got, os.path.join(out_dir, "loss.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_loss_shares_are_summed_off_the_compute_stream(tmp_path):
+    """BucketAllReduce.launch_loss / take_loss (the trainer's running loss under N > 1: every rank's scalar is its share of the
+    global batch mean, train_q_network.py:180,228-231): the SUM over ranks arrives in a buffer of its own, once per launch."""
+    world = 2
+    mp.spawn(_worker_loss, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert torch.load(tmp_path / "loss.pt") == [3.0, 6.0, 9.0]
+    from video_dqn_amd.dist import BucketAllReduce
+    single = BucketAllReduce(1)
+    single.launch_loss(torch.tensor([1.0]))  # one process: nothing to reduce, nothing pending
+    assert single.take_loss() is None
