@@ -1280,7 +1280,12 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
     pl->variant = bco == 128 ? 2 : 1;
     pl->ci_tiles = a->ci / bci;
     pl->tiles = (co_pad / bco) * 3 * pl->ci_tiles;
-    splitk = a->splitk > 0 ? a->splitk : 512 / pl->tiles;
+    // VDQN_WGRAD_WIN_BLOCKS: workgroups per window weight-gradient launch.  512 = one full round at two per CU, the fastest launch on
+    // its own (0.903 ms per update for the 13 launches; 384: 0.938, 768: 1.090) — but with the weight gradients alternating between two
+    // low-priority streams beside the data-gradient chain, slightly fewer and longer blocks give the shorter UPDATE: 448: 5.636-5.643,
+    // 384: 5.648-5.655, 512: 5.653-5.671, 768: 5.746, 256: 5.703 ms (steady box, profiles/r04ab_ab_wgrad_win_blocks.txt)
+    static const int target_w = [] { const char* e = getenv("VDQN_WGRAD_WIN_BLOCKS"); return e ? atoi(e) : 448; }();
+    splitk = a->splitk > 0 ? a->splitk : target_w / pl->tiles;
     if (splitk > max_split) splitk = max_split;
     if (splitk < 1) splitk = 1;
   }
