@@ -605,6 +605,36 @@ def test_deterministic_mode_is_bit_identical_run_to_run(dtype, B):
     assert abs(a[2][0] - c[2][0]) <= 1e-6 * abs(c[2][0])
 
 
+def test_update_replays_bit_identically_as_a_hip_graph():
+    """One update is kernels, stream waits and event records only — no host synchronisation, no allocation inside the library — so
+    it can be captured into a hipGraph through the caller's stream (the engine's side streams join the capture through the fork /
+    join events they already use), and a replay reproduces the eager update bit for bit (deterministic mode, train_q_network.py:
+    88-89; loss.backward() :226 is the captured work).  On this hardware the replay is SLOWER than the stream schedule (7.25 vs
+    6.01 ms per update at batch 256, profiles/r04ad_graph_replay_probe.txt), so neither bench.py nor the trainer replays graphs;
+    this test keeps the update capturable for callers that need it."""
+    from video_dqn_amd.engine import NetEngine, TDStepper
+    B = 16
+    (tup, raw) = synth.make_batch(812, B, 1, structured=True, reward_p=0.3)
+    args = (torch.from_numpy(raw[0]).to(DEV), torch.from_numpy(raw[1]).to(DEV), 0, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV))
+    net = NetEngine(3, 5, 1, True, "bf16", 2 * B, deterministic=True)
+    net.load_tensors(synth.make_state_dict(7))
+    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True)
+    stp.forward_backward(*args)
+    torch.cuda.synchronize()
+    g_eager, l_eager = stp.grads.clone(), stp.loss.item()
+    assert g_eager.abs().sum().item() > 0
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+        stp.forward_backward(*args)
+    for _ in range(2):
+        stp.grads.zero_()
+        stp.loss.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert stp.loss.item() == l_eager
+        assert torch.equal(stp.grads, g_eager)
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("bf16", 1e-4)])
 def test_default_schedule_gradients_equal_deterministic_per_tensor(dtype, tol):
     """The DEFAULT placement (atomic split-K sums, weight gradients on the side stream, conv1's weight gradient on the caller's
