@@ -69,53 +69,47 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
         for (int j = 0; j < 4; ++j)
           fb[kr][h][j] = *reinterpret_cast<const u32x4*>(wrow + (size_t)j * 4 * 512 + kr * 128 + ((lane >> 4) + 4 * h) * 16);
   }
-  // stage the window of tile t into buffer `buf` (10 pieces per thread-row group)
+  // The window of tile t_seq: 10 LDS-DMA pieces per thread; piece i = window rows lrow + 32 i = packed row sy0 + 2 i, LDS offset
+  // i * PSTR, global offset v0 + i * (2 packed rows).  A thread keeps (v0, sy0) and derives a piece's address when it issues it.
   // tile ids are remapped so that the workgroups of one XCD (blockIdx % 8) walk a contiguous range of tiles: neighbouring
   // patches share two packed rows / columns, which then hit in that XCD's L2
-  auto issue_window = [&](int t_seq, int buf) {
+  struct Win {
+    uint32_t v0;
+    int sy0;  // (far below zero for a window that is not to be loaded: every piece out of range = zero fill, no memory access)
+    i32x4 rs;
+  };
+  auto window_addrs = [&](int t_seq, bool live) {
     const int t = (int)xcd_remap((uint32_t)t_seq, (uint32_t)p.n_tiles);
     const int img = t >> 6, ty = (t >> 3) & 7, tx = t & 7;
     const int y0 = 14 * ty - 1, x0 = 14 * tx - 1;
     const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.t_in + (long long)img * kImgBytes);
-    const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)), (int)kImgBytes, 0x00020000};
-    uint32_t vw[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const int R = lrow + 32 * i;
-      const int sy = y0 + (R >> 4);
-      const bool ok = (R < 304) && ((unsigned)sy < 115u);
-      // packed column -1 / 115 (only read for conv columns that are never pooled) wraps inside the image or falls out of
-      // the descriptor's range (zeros): either way harmless
-      vw[i] = ok ? (uint32_t)((sy * 115 + x0 + (R & 15)) * 32 + lchunk_a * 16) : kOobS;
-    }
-    const uint32_t l0 = lds_wave + (uint32_t)(buf * kWBytes);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t l_ = l0 + (uint32_t)(2 * q * PSTR);
-      asm volatile(
-          "s_nop 4\n\t"
-          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, 0 offen lds\n\t"
-          "s_add_u32 m0, %2, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds"
-          ::"v"(vw[2 * q]), "v"(vw[2 * q + 1]), "s"(l_), "s"(rs_a), "n"(PSTR)
-          : "memory", "scc");
-    }
-    // last pass (rows 256..319): rows 304.. are padding, so the pieces of waves 2 and 3 in its second half are skipped —
-    // rows 312.. of buffer 0 hold the bias vector
-    {
-      const uint32_t l_ = l0 + (uint32_t)(8 * PSTR);
-      asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vw[8]), "s"(l_), "s"(rs_a) : "memory");
-      if (wave_u < 2) {
-        const uint32_t l2_ = l_ + (uint32_t)PSTR;
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vw[9]), "s"(l2_), "s"(rs_a) : "memory");
-      }
-    }
+    Win w;
+    w.rs = i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)), (int)kImgBytes, 0x00020000};
+    w.sy0 = live ? y0 + (lrow >> 4) : -100000;
+    // packed column -1 / 115 (only read for conv columns that are never pooled) wraps inside the image or falls out of
+    // the descriptor's range (zeros): either way harmless
+    w.v0 = (uint32_t)(((y0 + (lrow >> 4)) * 115 + x0 + (lrow & 15)) * 32 + lchunk_a * 16);
+    return w;
+  };
+  // piece i of window w into buffer `buf`.  Rows 304.. are padding (rows 312.. of buffer 0 hold the bias vector): piece 9 of
+  // waves 2 and 3 would land there and is skipped.
+  auto issue_piece = [&](int i, const Win& w, int buf) {
+    if (i == 9 && wave_u >= 2) return;
+    const bool ok = (lrow + 32 * i < 304) && ((unsigned)(w.sy0 + 2 * i) < 115u);
+    const uint32_t v = ok ? w.v0 + (uint32_t)(i * 2 * 115 * 32) : kOobS;
+    const uint32_t l_ = lds_wave + (uint32_t)(buf * kWBytes + i * PSTR);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(v), "s"(l_), "s"(w.rs) : "memory");
   };
   if (tid < 64) reinterpret_cast<float*>(sW + kBiasRow * 128)[tid] = p.bias[tid];  // visible after the first tile's barrier
 
   const int coff0 = ((g ^ (i16 & 7)) << 4), coff1 = (((g + 4) ^ (i16 & 7)) << 4);
 
   int t = blockIdx.x, buf = 0;
-  if (t < p.n_tiles) issue_window(t, 0);
+  if (t < p.n_tiles) {
+    const Win w0 = window_addrs(t, true);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) issue_piece(i, w0, 0);
+  }
   for (; t < p.n_tiles; t += gridDim.x, buf ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // window t visible; everyone is done pooling the previous tile (its patch lived in buf ^ 1)
@@ -125,11 +119,14 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     unsigned long long* st_row = (p.stamps && st_k < 16) ? reinterpret_cast<unsigned long long*>(p.stamps) + ((size_t)blockIdx.x * 16 + st_k) * 8 : nullptr;
     if (st_row && tid == 0) { st_row[0] = __builtin_amdgcn_s_memtime(); st_row[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); }
 #endif
-    // (The ten pieces of the burst hold the wave for ≈ 2200 cycles, as long as the K loop itself, while the CU's other workgroup
-    // has the matrix pipe: a CU's LDS-DMA queue drains one piece per wave and ≈ 220 cycles.  Issuing the pieces between the MFMA
-    // groups of the K loop, or spread over the whole tile, moves that wait into the K loop and leaves the tile period where it
-    // was — tools/stamp_stem.py, profiles/r04aj-r04al_*, experiments/README.md.)
-    if (t + (int)gridDim.x < p.n_tiles) issue_window(t + gridDim.x, buf ^ 1);
+    // The next tile's window is issued piece by piece over the WHOLE tile (four pieces between the MFMA groups of the K loop, two
+    // on either side of the patch phase, two in front of the pooling phase).  As one burst in front of the K loop the ten pieces
+    // held the wave for ≈ 2200 cycles — as long as the K loop itself — before its first MFMA: a CU's LDS-DMA queue drains one
+    // piece per wave and ≈ 220 cycles (tools/stamp_stem.py, profiles/r04aj_stamp_stem_before.txt), all ten inside the K loop
+    // only moved that stall into it (profiles/r04ak_*).
+    // (A workgroup's last tile issues out-of-range pieces: zero fill into the unused buffer, no memory access.)
+    const bool have_next = t + (int)gridDim.x < p.n_tiles;
+    const Win wn = window_addrs(have_next ? t + (int)gridDim.x : t, have_next);
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) st_row[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -149,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
         u32x4 fa[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) fa[f] = *reinterpret_cast<const u32x4*>(a_rd + (kr * 16 + f * 16) * 128 + (h ? coff1 : coff0));
+        if (h == 0) issue_piece(kr, wn, buf ^ 1);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -162,6 +160,8 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[f][j][0] = __builtin_bit_cast(float, fb[f][0][j][0] & 0x3f800000u);  // (keeps the weight registers live)
     (void)a_rd; (void)coff0; (void)coff1;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) issue_piece(i, wn, buf ^ 1);
 #endif
 
     // ---- bias + ReLU -> bf16 patch in LDS (over the window just consumed), then the 7x7 pooled pixels ----
@@ -178,12 +178,16 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) sum += acc[f][j][0] + acc[f][j][1] + acc[f][j][2] + acc[f][j][3];
       if (sum == 12345.678f) p.pool[tid] = 1;
+#pragma unroll
+      for (int i = 4; i < 10; ++i) issue_piece(i, wn, buf ^ 1);
       continue;
     }
 #endif
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) { asm volatile("s_nop 0" ::"v"(acc[3][3][3])); st_row[2] = __builtin_amdgcn_s_memtime(); }
 #endif
+    issue_piece(4, wn, buf ^ 1);
+    issue_piece(5, wn, buf ^ 1);
     __syncthreads();
     bf16raw* sT = reinterpret_cast<bf16raw*>(sW + buf * kWBytes);
     float bv[16];  // (re-read per tile from LDS: the weights occupy the registers a resident copy would need)
@@ -203,7 +207,11 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
         *reinterpret_cast<uint4*>(sT + (size_t)r * 64 + chunk * 8) = reinterpret_cast<const uint4*>(ov)[c];
       }
     }
+    issue_piece(6, wn, buf ^ 1);
+    issue_piece(7, wn, buf ^ 1);
     __syncthreads();
+    issue_piece(8, wn, buf ^ 1);
+    issue_piece(9, wn, buf ^ 1);
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) st_row[3] = __builtin_amdgcn_s_memtime();
 #endif
