@@ -12,9 +12,12 @@
 //     is read ONCE per wave into registers (its 32 MFMA B-fragments = 128 VGPRs) and never touches LDS.
 //   * That leaves LDS for two windows: the LDS-DMA of tile t+1 runs underneath the MFMAs and the pooling epilogue of tile t.
 //   * No barrier and no DMA inside a tile's K loop.
-// Epilogue as in igemm.hip MODE 3: bias + ReLU -> bf16 patch in LDS (aliasing the window just consumed) -> 49 pooled pixels
-// x 64 channels with the first-maximum-wins rule of maxpool_fwd_kernel.  Results are bit-identical to vdqn_conv2d followed
-// by vdqn_maxpool_fwd (same K order, same rounding points).
+// Epilogue, tiles that need arg-max bytes (frames that see a backward pass), as in igemm.hip MODE 3: bias + ReLU -> bf16 patch in
+// LDS (aliasing the window just consumed) -> 49 pooled pixels x 64 channels with the first-maximum-wins rule of
+// maxpool_fwd_kernel.  Tiles without arg-max (two thirds of a TD update's frames) are pooled straight from the accumulators:
+// column maxima by DPP row shifts, row maxima inside the lane, one pooled row per wave pair exchanged through 896 bytes of LDS
+// (round 4: 150 -> 139 us per 256 frames, profiles/r04ap_*; -DVDQN_STEM_LDS_POOL compiles the LDS path for every tile).
+// Results are bit-identical to vdqn_conv2d followed by vdqn_maxpool_fwd (same K order, same rounding points).
 #include "common.h"
 
 namespace {
@@ -184,11 +187,95 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) { asm volatile("s_nop 0" ::"v"(acc[3][3][3])); st_row[2] = __builtin_amdgcn_s_memtime(); }
 #endif
-    __syncthreads();
-    bf16raw* sT = reinterpret_cast<bf16raw*>(sW + buf * kWBytes);
+    const int tl = (int)xcd_remap((uint32_t)t, (uint32_t)p.n_tiles);
+    const int img = tl >> 6, ty = (tl >> 3) & 7, tx = tl & 7;
     float bv[16];  // (re-read per tile from LDS: the weights occupy the registers a resident copy would need)
 #pragma unroll
     for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(bv + 4 * e) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + 4 * e) * 4);
+#if !defined(VDQN_STEM_LDS_POOL)
+    if (img >= p.n_idx_img) {  // (uniform over the workgroup)
+      // ---- no arg-max: pooled straight from the accumulators.  A lane holds conv-patch rows 4 wave + f (f = 0..3), column i16,
+      // 16 channels: the three columns of a pooling window are the lanes i16, i16 + 1, i16 + 2 of a 16-lane row (two DPP row
+      // shifts; the even lanes 0..12 end with pooled column i16 / 2), the three rows of pooled row 2 wave are the lane's own
+      // f = 0..2, and pooled row 2 wave + 1 needs rows f = 2, 3 and row f = 0 of the NEXT wave — the only thing that goes through
+      // LDS (its column maximum: 896 bytes per wave in the never-staged rows 304.. of the window buffers), behind the tile's
+      // only barrier besides the one at its top.  No patch in LDS, no patch barriers, no strided patch reads.
+      // bf16 bit patterns of non-negative values order like SIGNED 16-bit integers and every negative value (-0.0 included) is a
+      // negative integer, so the ReLU is folded into the maxima: max(+0.0, a, b, ...) over the unclamped values.  Taps outside
+      // the image (conv row / column -1: patch row 0 of the first tile row, this lane's own column in lane 0 of the first tile
+      // column) are replaced by +0.0, which is what a maximum that starts at +0.0 and skips them gives.  Same bits as the LDS
+      // path below and as the two separate kernels (rounding and ReLU are monotonic: they commute with the maximum).
+      // (Register budget: the weights hold 128 VGPRs, so patch row f = 0 is converted first — the only row the exchange needs —
+      // and rows 1..3 are converted, pooled and stored in two channel halves behind the barrier.)
+      int lane_l = lane;
+      asm volatile("" : "+v"(lane_l));  // (lane-derived addresses of this path are recomputed per tile instead of living in registers across the K loop)
+      const int i16 = lane_l & 15, g = lane_l >> 4;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const uint32_t keep = (tx == 0 && i16 == 0) ? 0u : 0xffffffffu;  // conv column -1: this lane's own values drop out
+      auto cvt = [&](int f, int e) {  // channels 2e, 2e + 1 of patch row f: bias, bf16, packed (v_pk_add_f32, v_cvt_pk_bf16_f32)
+        const f32x2 v = f32x2{acc[f][e >> 1][(e & 1) * 2], acc[f][e >> 1][(e & 1) * 2 + 1]} + f32x2{bv[2 * e], bv[2 * e + 1]};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+      };
+      auto pmax = [](uint32_t a, uint32_t b) {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b)));
+      };
+      auto hmax = [&](uint32_t x) {  // max over lanes i16, i16 + 1, i16 + 2 (lanes past the row read 0 = +0.0; only odd / unused lanes see them)
+        const uint32_t x1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);  // row_shl:1
+        const uint32_t x2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xf, 0xf, true);  // row_shl:2
+        return pmax(pmax(x & keep, x1), x2);
+      };
+      const bool col_lane = (i16 & 1) == 0 && i16 <= 12;
+      // exchange slots: sender wave 1 -> buffer 0 rows 304..310, sender waves 2, 3 -> buffer 1 rows 304..317; [pooled column][g][32 B]
+      auto xch = [&](int sender) {
+        return sW + (sender == 1 ? 0 : kWBytes) + (304 + (sender == 3 ? 7 : 0)) * 128 + (i16 >> 1) * 128 + g * 32;
+      };
+      const bool row_out = ty == 0 && wave_u == 0;  // conv row -1: patch row 0 of the first tile row drops out (uniform)
+      uint32_t P0[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) P0[e] = row_out ? 0u : cvt(0, e);
+      if (wave_u >= 1) {
+        uint32_t S[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) S[e] = hmax(P0[e]);
+        if (col_lane) {
+          unsigned char* d = xch(wave_u);
+          *reinterpret_cast<uint4*>(d) = make_uint4(S[0], S[1], S[2], S[3]);
+          *reinterpret_cast<uint4*>(d + 16) = make_uint4(S[4], S[5], S[6], S[7]);
+        }
+      }
+      __syncthreads();
+#ifdef VDQN_STAMP
+      if (st_row && tid == 0) st_row[3] = __builtin_amdgcn_s_memtime();
+#endif
+      const size_t o0 = (((size_t)img * 56 + 7 * ty + 2 * wave_u) * 56 + 7 * tx + (i16 >> 1)) * 64 + g * 16;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        uint32_t P2[4], A[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          P2[e] = cvt(2, hf * 4 + e);
+          A[e] = pmax(hmax(pmax(pmax(P0[hf * 4 + e], cvt(1, hf * 4 + e)), P2[e])), 0u);
+        }
+        if (col_lane) *reinterpret_cast<uint4*>(p.pool + o0 + hf * 8) = make_uint4(A[0], A[1], A[2], A[3]);
+        if (wave_u < 3) {
+          uint4 n = make_uint4(0, 0, 0, 0);
+          if (col_lane) n = *reinterpret_cast<const uint4*>(xch(wave_u + 1) + hf * 16);
+          const uint32_t N[4] = {n.x, n.y, n.z, n.w};
+          uint32_t B[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) B[e] = pmax(pmax(hmax(pmax(P2[e], cvt(3, hf * 4 + e))), N[e]), 0u);
+          if (col_lane) *reinterpret_cast<uint4*>(p.pool + o0 + 56 * 64 + hf * 8) = make_uint4(B[0], B[1], B[2], B[3]);
+        }
+      }
+#ifdef VDQN_STAMP
+      if (st_row && tid == 0) st_row[4] = __builtin_amdgcn_s_memtime();
+#endif
+      continue;
+    }
+#endif
+    __syncthreads();
+    bf16raw* sT = reinterpret_cast<bf16raw*>(sW + buf * kWBytes);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int r = wave * 64 + f * 16 + i16;
@@ -207,8 +294,6 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) st_row[3] = __builtin_amdgcn_s_memtime();
 #endif
-    const int tl = (int)xcd_remap((uint32_t)t, (uint32_t)p.n_tiles);
-    const int img = tl >> 6, ty = (tl >> 3) & 7, tx = tl & 7;
 #if defined(VDQN_STEM_PROBE) && (VDQN_STEM_PROBE & 2)  // bit 1 = no pooling phase (one word per lane keeps the patch writes live)
     if (tid == 0) p.pool[(size_t)t * 64] = sT[0];
     if (false)
