@@ -15,8 +15,10 @@
 // Epilogue, tiles that need arg-max bytes (frames that see a backward pass), as in igemm.hip MODE 3: bias + ReLU -> bf16 patch in
 // LDS (aliasing the window just consumed) -> 49 pooled pixels x 64 channels with the first-maximum-wins rule of
 // maxpool_fwd_kernel.  Tiles without arg-max (two thirds of a TD update's frames) are pooled straight from the accumulators:
-// column maxima by DPP row shifts, row maxima inside the lane, one pooled row per wave pair exchanged through 896 bytes of LDS
-// (round 4: 150 -> 139 us per 256 frames, profiles/r04ap_*; -DVDQN_STEM_LDS_POOL compiles the LDS path for every tile).
+// column maxima by DPP row shifts, row maxima inside the lane, one pooled row per wave pair exchanged through 896 bytes of LDS.
+// A workgroup walks its arg-max tiles and then its plain tiles in two loops over one body, so that each instance is register-
+// allocated with its own epilogue only (round 4: stem_conv_pool 0.446 -> 0.398 ms per update, no scratch;
+// profiles/r04at_*; -DVDQN_STEM_LDS_POOL sends every tile through the LDS epilogue).
 // Results are bit-identical to vdqn_conv2d followed by vdqn_maxpool_fwd (same K order, same rounding points).
 #include "common.h"
 
@@ -36,6 +38,9 @@ struct StemParams {
   int n_idx_img;         // images [0, n_idx_img) get arg-max bytes
   void* stamps;          // -DVDQN_STAMP builds only (tools/stamp_stem.py): s_memtime at the phase boundaries of a workgroup's first tiles
 };
+
+struct KindArg { static constexpr bool value = true; };     // tile loop instances of stem_kernel
+struct KindPlain { static constexpr bool value = false; };
 
 constexpr int kWRows = 320;                    // 19 * 16 = 304 window rows, rounded up to the 32-row staging pass
 constexpr int kWBytes = kWRows * 128;          // one window buffer
@@ -59,11 +64,13 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   constexpr int PSTR = 32 * 128;  // 32 rows per staging pass
   constexpr long long kImgBytes = 115ll * 115 * 16 * 2;
 
-  // ---- weights: this wave's fragments of all four K-steps, once, into REGISTERS (128 VGPRs): fragment j of K-step kr,
-  // K half h = 16 bytes of weight row (i16 >> 2) * 16 + j * 4 + (i16 & 3) (the permuted order of igemm.hip) ----
-  u32x4 fb[4][2][4];
-  {
+  // ---- weights: this wave's fragments of all four K-steps in REGISTERS (128 VGPRs): fragment j of K-step kr, K half h = 16 bytes
+  // of weight row (i16 >> 2) * 16 + j * 4 + (i16 & 3) (the permuted order of igemm.hip).  Loaded once per tile LOOP (there are
+  // two, below): as one value live through both loops the register allocator spilled two fragments to scratch and reloaded them
+  // inside every K loop; loaded again in front of the second loop they are two independent live ranges and nothing spills. ----
+  auto load_weights = [&](u32x4 (&fb)[4][2][4]) {
     const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.wt) + (size_t)((lane & 15) >> 2) * 16 * 512 + (size_t)(lane & 3) * 512;
+    asm volatile("" : "+v"(wrow));  // (a pointer the optimiser cannot match with the other loop's: two sets of loads)
 #pragma unroll
     for (int kr = 0; kr < 4; ++kr)
 #pragma unroll
@@ -71,25 +78,28 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           fb[kr][h][j] = *reinterpret_cast<const u32x4*>(wrow + (size_t)j * 4 * 512 + kr * 128 + ((lane >> 4) + 4 * h) * 16);
-  }
+  };
   // stage the window of tile t into buffer `buf` (10 pieces per thread-row group)
-  // tile ids are remapped so that the workgroups of one XCD (blockIdx % 8) walk a contiguous range of tiles: neighbouring
-  // patches share two packed rows / columns, which then hit in that XCD's L2
-  auto issue_window = [&](int t_seq, int buf) {
-    const int t = (int)xcd_remap((uint32_t)t_seq, (uint32_t)p.n_tiles);
+  auto issue_window = [&](int t, int buf) {  // t: logical tile id (tile_at)
+    int tid_w = tid;
+    asm volatile("" : "+v"(tid_w));  // (the staging row / chunk of a thread is recomputed per tile instead of living in registers across the K loop)
+    const int lrow = tid_w >> 3;
+    const int lchunk_a = (tid_w & 7) ^ (lrow & 7);
     const int img = t >> 6, ty = (t >> 3) & 7, tx = t & 7;
     const int y0 = 14 * ty - 1, x0 = 14 * tx - 1;
     const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.t_in + (long long)img * kImgBytes);
     const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)), (int)kImgBytes, 0x00020000};
+    // piece i = window rows lrow + 32 i = packed row sy0 + 2 i, columns x0 + (lrow & 15): one base offset per thread and tile, a
+    // constant step per piece (written so that the thread keeps lrow, not ten per-piece row numbers, across the K loop)
+    const int sy0 = y0 + (lrow >> 4);
+    const uint32_t v0 = (uint32_t)((sy0 * 115 + x0 + (lrow & 15)) * 32 + lchunk_a * 16);
     uint32_t vw[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-      const int R = lrow + 32 * i;
-      const int sy = y0 + (R >> 4);
-      const bool ok = (R < 304) && ((unsigned)sy < 115u);
+      const bool ok = (i < 9 || lrow < 16) && ((unsigned)(sy0 + 2 * i) < 115u);  // (rows 304.. of the last piece are padding)
       // packed column -1 / 115 (only read for conv columns that are never pooled) wraps inside the image or falls out of
       // the descriptor's range (zeros): either way harmless
-      vw[i] = ok ? (uint32_t)((sy * 115 + x0 + (R & 15)) * 32 + lchunk_a * 16) : kOobS;
+      vw[i] = ok ? v0 + (uint32_t)(i * 2 * 115 * 32) : kOobS;
     }
     const uint32_t l0 = lds_wave + (uint32_t)(buf * kWBytes);
 #pragma unroll
@@ -117,14 +127,35 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 
   const int coff0 = ((g ^ (i16 & 7)) << 4), coff1 = (((g + 4) ^ (i16 & 7)) << 4);
 
-  int t = blockIdx.x, buf = 0;
-  if (t < p.n_tiles) issue_window(t, 0);
-  for (; t < p.n_tiles; t += gridDim.x, buf ^= 1) {
+  // The workgroup's tile sequence: first its tiles WITH arg-max bytes (images < n_idx_img), then those without, as two loops over
+  // the same body — each instance is compiled with its own epilogue only, so the loop invariants of one pooling path do not
+  // occupy registers in the other's K loop (one common loop spilled 13 VGPRs and reloaded them in front of every window issue:
+  // three scratch round trips per tile).  Every workgroup gets the same share of both kinds (tiles b, b + G, b + 2G, ... of
+  // either range), and inside a range the ids are remapped so that the workgroups of one XCD (blockIdx % 8; G is a multiple of 8
+  // or the whole tile count) walk a contiguous piece: neighbouring patches share two packed rows / columns, which then hit in
+  // that XCD's L2.
+#ifdef VDQN_STEM_LDS_POOL
+  const int Ta = p.n_tiles;        // every tile through the LDS-patch epilogue
+#else
+  const int Ta = p.n_idx_img * 64;
+#endif
+  const int Tn = p.n_tiles - Ta, G = (int)gridDim.x, b0 = (int)blockIdx.x;
+  const int ka = b0 < Ta ? (Ta - b0 + G - 1) / G : 0;
+  const int kn = b0 < Tn ? (Tn - b0 + G - 1) / G : 0;
+  auto tile_at = [&](int k) {  // logical id of this workgroup's k-th tile; -1 behind the last
+    if (k < ka) return (int)xcd_remap((uint32_t)(b0 + k * G), (uint32_t)Ta);
+    if (k < ka + kn) return Ta + (int)xcd_remap((uint32_t)(b0 + (k - ka) * G), (uint32_t)Tn);
+    return -1;
+  };
+  auto tile = [&](auto kind, const int k, const u32x4 (&fb)[4][2][4]) {
+    constexpr bool ARG = decltype(kind)::value;
+    const int buf = k & 1;
+    const int tl = tile_at(k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // window t visible; everyone is done pooling the previous tile (its patch lived in buf ^ 1)
 #ifdef VDQN_STAMP
     // row of 8 words per (workgroup, tile number < 16): top, DMA issued, K loop done, patch written, pooled, HW_ID
-    const int st_k = (t - (int)blockIdx.x) / (int)gridDim.x;
+    const int st_k = k;
     unsigned long long* st_row = (p.stamps && st_k < 16) ? reinterpret_cast<unsigned long long*>(p.stamps) + ((size_t)blockIdx.x * 16 + st_k) * 8 : nullptr;
     if (st_row && tid == 0) { st_row[0] = __builtin_amdgcn_s_memtime(); st_row[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); }
 #endif
@@ -132,7 +163,10 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     // has the matrix pipe: a CU's LDS-DMA queue drains one piece per wave and ≈ 220 cycles.  Issuing the pieces between the MFMA
     // groups of the K loop, or spread over the whole tile, moves that wait into the K loop and leaves the tile period where it
     // was — tools/stamp_stem.py, profiles/r04aj-r04al_*, experiments/README.md.)
-    if (t + (int)gridDim.x < p.n_tiles) issue_window(t + gridDim.x, buf ^ 1);
+    {
+      const int nx = tile_at(k + 1);
+      if (nx >= 0) issue_window(nx, buf ^ 1);
+    }
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) st_row[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -181,19 +215,14 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) sum += acc[f][j][0] + acc[f][j][1] + acc[f][j][2] + acc[f][j][3];
       if (sum == 12345.678f) p.pool[tid] = 1;
-      continue;
+      return;
     }
 #endif
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) { asm volatile("s_nop 0" ::"v"(acc[3][3][3])); st_row[2] = __builtin_amdgcn_s_memtime(); }
 #endif
-    const int tl = (int)xcd_remap((uint32_t)t, (uint32_t)p.n_tiles);
     const int img = tl >> 6, ty = (tl >> 3) & 7, tx = tl & 7;
-    float bv[16];  // (re-read per tile from LDS: the weights occupy the registers a resident copy would need)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(bv + 4 * e) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + 4 * e) * 4);
-#if !defined(VDQN_STEM_LDS_POOL)
-    if (img >= p.n_idx_img) {  // (uniform over the workgroup)
+    if constexpr (!ARG) {
       // ---- no arg-max: pooled straight from the accumulators.  A lane holds conv-patch rows 4 wave + f (f = 0..3), column i16,
       // 16 channels: the three columns of a pooling window are the lanes i16, i16 + 1, i16 + 2 of a 16-lane row (two DPP row
       // shifts; the even lanes 0..12 end with pooled column i16 / 2), the three rows of pooled row 2 wave are the lane's own
@@ -213,8 +242,14 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       const uint32_t keep = (tx == 0 && i16 == 0) ? 0u : 0xffffffffu;  // conv column -1: this lane's own values drop out
-      auto cvt = [&](int f, int e) {  // channels 2e, 2e + 1 of patch row f: bias, bf16, packed (v_pk_add_f32, v_cvt_pk_bf16_f32)
-        const f32x2 v = f32x2{acc[f][e >> 1][(e & 1) * 2], acc[f][e >> 1][(e & 1) * 2 + 1]} + f32x2{bv[2 * e], bv[2 * e + 1]};
+      // (the bias is read from LDS eight channels at a time, where it is used: sixteen resident values are registers the K loop of
+      // this instance does not have)
+      auto bias8 = [&](int hf, float (&b8)[8]) {
+        *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + hf * 8) * 4);
+        *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + hf * 8 + 4) * 4);
+      };
+      auto cvt = [&](int f, int e, const float (&b8)[8]) {  // channels 2e, 2e + 1 of patch row f: bias, bf16, packed (v_pk_add_f32, v_cvt_pk_bf16_f32)
+        const f32x2 v = f32x2{acc[f][e >> 1][(e & 1) * 2], acc[f][e >> 1][(e & 1) * 2 + 1]} + f32x2{b8[2 * (e & 3)], b8[2 * (e & 3) + 1]};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
       };
       auto pmax = [](uint32_t a, uint32_t b) {
@@ -233,7 +268,12 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
       const bool row_out = ty == 0 && wave_u == 0;  // conv row -1: patch row 0 of the first tile row drops out (uniform)
       uint32_t P0[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) P0[e] = row_out ? 0u : cvt(0, e);
+      for (int hf = 0; hf < 2; ++hf) {
+        float b8[8];
+        bias8(hf, b8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) P0[hf * 4 + e] = row_out ? 0u : cvt(0, hf * 4 + e, b8);
+      }
       if (wave_u >= 1) {
         uint32_t S[8];
 #pragma unroll
@@ -252,10 +292,12 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         uint32_t P2[4], A[4];
+        float b8[8];
+        bias8(hf, b8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          P2[e] = cvt(2, hf * 4 + e);
-          A[e] = pmax(hmax(pmax(pmax(P0[hf * 4 + e], cvt(1, hf * 4 + e)), P2[e])), 0u);
+          P2[e] = cvt(2, hf * 4 + e, b8);
+          A[e] = pmax(hmax(pmax(pmax(P0[hf * 4 + e], cvt(1, hf * 4 + e, b8)), P2[e])), 0u);
         }
         if (col_lane) *reinterpret_cast<uint4*>(p.pool + o0 + hf * 8) = make_uint4(A[0], A[1], A[2], A[3]);
         if (wave_u < 3) {
@@ -264,16 +306,18 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
           const uint32_t N[4] = {n.x, n.y, n.z, n.w};
           uint32_t B[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) B[e] = pmax(pmax(hmax(pmax(P2[e], cvt(3, hf * 4 + e))), N[e]), 0u);
+          for (int e = 0; e < 4; ++e) B[e] = pmax(pmax(hmax(pmax(P2[e], cvt(3, hf * 4 + e, b8))), N[e]), 0u);
           if (col_lane) *reinterpret_cast<uint4*>(p.pool + o0 + 56 * 64 + hf * 8) = make_uint4(B[0], B[1], B[2], B[3]);
         }
       }
 #ifdef VDQN_STAMP
       if (st_row && tid == 0) st_row[4] = __builtin_amdgcn_s_memtime();
 #endif
-      continue;
+      return;
     }
-#endif
+    float bv[16];  // (re-read per tile from LDS: the weights occupy the registers a resident copy would need)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(bv + 4 * e) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + 4 * e) * 4);
     __syncthreads();
     bf16raw* sT = reinterpret_cast<bf16raw*>(sW + buf * kWBytes);
 #pragma unroll
@@ -295,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     if (st_row && tid == 0) st_row[3] = __builtin_amdgcn_s_memtime();
 #endif
 #if defined(VDQN_STEM_PROBE) && (VDQN_STEM_PROBE & 2)  // bit 1 = no pooling phase (one word per lane keeps the patch writes live)
-    if (tid == 0) p.pool[(size_t)t * 64] = sT[0];
+    if (tid == 0) p.pool[(size_t)tl * 64] = sT[0];
     if (false)
 #endif
     for (int item = tid; item < 49 * 8; item += 256) {
@@ -369,6 +413,17 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) st_row[4] = __builtin_amdgcn_s_memtime();
 #endif
+  };
+  if (ka + kn > 0) issue_window(tile_at(0), 0);
+  if (ka > 0) {
+    u32x4 fb[4][2][4];
+    load_weights(fb);
+    for (int k = 0; k < ka; ++k) tile(KindArg{}, k, fb);
+  }
+  if (kn > 0) {
+    u32x4 fb[4][2][4];
+    load_weights(fb);
+    for (int k = ka; k < ka + kn; ++k) tile(KindPlain{}, k, fb);
   }
 }
 
