@@ -5,20 +5,23 @@
 // Tile = a 16x16 patch of conv pixels (rows 14 ty - 1 .., cols 14 tx - 1 ..) that contains every window of a 7x7 patch
 // of pooled pixels; 64 tiles per image.  What makes this kernel different from the generic implicit GEMM (igemm.hip,
 // MODE 3, still used for f32):
-//   * K-step kr of conv row py reads the packed rows of conv row py + 1 at K-step kr - 1, so ONE staged window of 19 x 16
-//     rows (window row wy*16 + px = the 128 bytes at packed pixel (y0 + wy, x0 + px)) serves all four K-steps: fragments
-//     of step kr are read 16 rows further down.  38 KiB staged per tile instead of 4 x 32 KiB.
+//   * The operand of a tile is the 19 x 19 packed pixels its conv pixels read through their 4 x 4 taps, staged ONCE as they lie
+//     in the image (11.3 KB, three LDS-DMA pieces per thread; round 3 staged a 128-byte K row per conv pixel and kernel row:
+//     38 KB, ten pieces, whose issue alone held a wave as long as its K loop).  A fragment read is 16 bytes of window row
+//     f + kr at pixel i16 + kx: window row R serves every (conv row f, kernel row kr) pair with f + kr = R — 14 fragment reads
+//     per lane and tile, read one row ahead of the MFMAs that use them; a one-bit chunk swizzle keeps them conflict-free.
 //   * Workgroups are persistent (two per CU) and walk the tile list with a stride of gridDim.x; the 64 x 256 weight matrix
-//     is read ONCE per wave into registers (its 32 MFMA B-fragments = 128 VGPRs) and never touches LDS.
-//   * That leaves LDS for two windows: the LDS-DMA of tile t+1 runs underneath the MFMAs and the pooling epilogue of tile t.
+//     is read ONCE per wave and tile loop into registers (its 32 MFMA fragments = 128 VGPRs) and never touches LDS.
+//   * Two window buffers: the LDS-DMA of tile t+1 runs underneath the MFMAs and the pooling epilogue of tile t.
 //   * No barrier and no DMA inside a tile's K loop.
 // Epilogue, tiles that need arg-max bytes (frames that see a backward pass), as in igemm.hip MODE 3: bias + ReLU -> bf16 patch in
-// LDS (aliasing the window just consumed) -> 49 pooled pixels x 64 channels with the first-maximum-wins rule of
-// maxpool_fwd_kernel.  Tiles without arg-max (two thirds of a TD update's frames) are pooled straight from the accumulators:
-// column maxima by DPP row shifts, row maxima inside the lane, one pooled row per wave pair exchanged through 896 bytes of LDS.
-// A workgroup walks its arg-max tiles and then its plain tiles in two loops over one body, so that each instance is register-
-// allocated with its own epilogue only (round 4: stem_conv_pool 0.446 -> 0.398 ms per update, no scratch;
-// profiles/r04at_*; -DVDQN_STEM_LDS_POOL sends every tile through the LDS epilogue).
+// LDS (a region of its own) -> 49 pooled pixels x 64 channels with the first-maximum-wins rule of maxpool_fwd_kernel.  Tiles
+// without arg-max (two thirds of a TD update's frames) are pooled straight from the accumulators: column maxima by DPP row
+// shifts, row maxima inside the lane, one pooled row per wave pair exchanged through 896 bytes of LDS.  A workgroup walks its
+// arg-max tiles and then its plain tiles in two loops over one body, so that each instance is register-allocated with its own
+// epilogue only.  Round 4 (tools/stem_phases.py, tools/stamp_stem.py): stem_conv_pool 0.446 -> 0.398 ms per update
+// with the register pooling (profiles/r04at_*), 0.473 -> 0.420 on a slower box with the compact window on top (r04bd);
+// -DVDQN_STEM_LDS_POOL sends every tile through the LDS epilogue.
 // Results are bit-identical to vdqn_conv2d followed by vdqn_maxpool_fwd (same K order, same rounding points).
 #include "common.h"
 
@@ -42,26 +45,28 @@ struct StemParams {
 struct KindArg { static constexpr bool value = true; };     // tile loop instances of stem_kernel
 struct KindPlain { static constexpr bool value = false; };
 
-constexpr int kWRows = 320;                    // 19 * 16 = 304 window rows, rounded up to the 32-row staging pass
-constexpr int kWBytes = kWRows * 128;          // one window buffer
-constexpr int kSmem = 2 * kWBytes;  // two windows = 80 KiB: two workgroups per CU (the weights live in registers)
+// LDS: two windows of 19 x 19 packed pixels (32 B each, stored as they lie in the image: 38 chunks of 16 B per row, 722 chunks
+// rounded up to three staging pieces of 256), the arg-max path's bf16 patch, the bias vector and the row-exchange slots of the
+// plain path.  59 KiB: two workgroups per CU (the weights live in registers).
+constexpr int kRowPitch = 38 * 16;             // bytes per window row
+constexpr int kWBytes = 3 * 256 * 16;          // one window buffer
+constexpr int kPatchOff = 2 * kWBytes;
+constexpr int kBiasOff = kPatchOff + 256 * 128;
+constexpr int kXchOff = kBiasOff + 256;        // 3 sender waves x 7 pooled columns x 128 B
+constexpr int kSmem = kXchOff + 3 * 7 * 128;
 constexpr unsigned kOobS = 0x80000000u;
 
 // Images from p.n_idx_img on get no arg-max bytes (frames that never see a backward pass: the s' half of the online pass and the
 // whole target pass of a TD update): their pooling is a plain packed 16-bit maximum, a quarter of the vector instructions.
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sW = smem;                    // [2][320 rows][128 B]
+  unsigned char* sW = smem;                    // [2][19 rows][38 chunks][16 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int lrow = tid >> 3;
-  const int lchunk_a = (tid & 7) ^ (lrow & 7);
-  const int lchunk_b = (tid & 7) ^ ((((lrow >> 4) & 1) << 2) | (lrow & 3));  // permuted weight rows, see igemm.hip (CPL = 16)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const uint32_t lds_wave = lds_base + (uint32_t)wave_u * (8 * 128);
-  constexpr int kBiasRow = 312;  // window rows 304..319 of buffer 0 are never staged (see issue_window)
-  constexpr int PSTR = 32 * 128;  // 32 rows per staging pass
+  const uint32_t lds_wave = lds_base + (uint32_t)wave_u * 1024u;
+  constexpr int PSTR = 256 * 16;  // bytes per staging piece
   constexpr long long kImgBytes = 115ll * 115 * 16 * 2;
 
   // ---- weights: this wave's fragments of all four K-steps in REGISTERS (128 VGPRs): fragment j of K-step kr, K half h = 16 bytes
@@ -79,53 +84,48 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
         for (int j = 0; j < 4; ++j)
           fb[kr][h][j] = *reinterpret_cast<const u32x4*>(wrow + (size_t)j * 4 * 512 + kr * 128 + ((lane >> 4) + 4 * h) * 16);
   };
-  // stage the window of tile t into buffer `buf` (10 pieces per thread-row group)
+  // Stage the window of tile t into buffer `buf`: the 19 x 19 packed pixels (y0 .. y0 + 18, x0 .. x0 + 18) a 16 x 16 patch of
+  // conv pixels reads with its 4 x 4 taps, ONCE each (11.3 KB, three LDS-DMA pieces per thread).  Round 3 staged one 128-byte
+  // K row (four neighbouring pixels) per conv pixel and kernel row — 38 KB and ten pieces per tile for the same 11.3 KB of image,
+  // and the ten pieces held each wave for ≈ 2200 cycles per tile, as long as the K loop (tools/stamp_stem.py,
+  // profiles/r04aj_stamp_stem_before.txt).  The LDS image of a piece is lane-linear, so the swizzle (chunk c of a row stored at
+  // c ^ ((c >> 4) & 1): the two halves of a pixel swap places in pixels 8..15) is applied to the SOURCE chunk.
   auto issue_window = [&](int t, int buf) {  // t: logical tile id (tile_at)
     int tid_w = tid;
-    asm volatile("" : "+v"(tid_w));  // (the staging row / chunk of a thread is recomputed per tile instead of living in registers across the K loop)
-    const int lrow = tid_w >> 3;
-    const int lchunk_a = (tid_w & 7) ^ (lrow & 7);
+    asm volatile("" : "+v"(tid_w));  // (a thread's staging slots are recomputed per tile instead of living in registers across the K loop)
     const int img = t >> 6, ty = (t >> 3) & 7, tx = t & 7;
     const int y0 = 14 * ty - 1, x0 = 14 * tx - 1;
     const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.t_in + (long long)img * kImgBytes);
     const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)), (int)kImgBytes, 0x00020000};
-    // piece i = window rows lrow + 32 i = packed row sy0 + 2 i, columns x0 + (lrow & 15): one base offset per thread and tile, a
-    // constant step per piece (written so that the thread keeps lrow, not ten per-piece row numbers, across the K loop)
-    const int sy0 = y0 + (lrow >> 4);
-    const uint32_t v0 = (uint32_t)((sy0 * 115 + x0 + (lrow & 15)) * 32 + lchunk_a * 16);
-    uint32_t vw[10];
+    uint32_t vw[3];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const bool ok = (i < 9 || lrow < 16) && ((unsigned)(sy0 + 2 * i) < 115u);  // (rows 304.. of the last piece are padding)
-      // packed column -1 / 115 (only read for conv columns that are never pooled) wraps inside the image or falls out of
-      // the descriptor's range (zeros): either way harmless
-      vw[i] = ok ? v0 + (uint32_t)(i * 2 * 115 * 32) : kOobS;
+    for (int i = 0; i < 3; ++i) {
+      const int sl = i * 256 + tid_w;            // slot = window row * 38 + stored chunk
+      const int row = (sl * 1725) >> 16;        // sl / 38, exact for sl < 768
+      const int pc = sl - row * 38;
+      const int lc = pc ^ ((pc >> 4) & 1);       // the image chunk this slot holds
+      const int sy = y0 + row;
+      // packed column -1 / 115 (only read for conv columns that are never pooled) wraps inside the image or falls out of the
+      // descriptor's range (zeros): either way harmless; rows outside the image and the slots behind row 18 are zero-filled
+      const bool ok = row < 19 && (unsigned)sy < 115u;
+      vw[i] = ok ? (uint32_t)((sy * 115 + x0) * 32 + lc * 16) : kOobS;
     }
     const uint32_t l0 = lds_wave + (uint32_t)(buf * kWBytes);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t l_ = l0 + (uint32_t)(2 * q * PSTR);
-      asm volatile(
-          "s_nop 4\n\t"
-          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, 0 offen lds\n\t"
-          "s_add_u32 m0, %2, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds"
-          ::"v"(vw[2 * q]), "v"(vw[2 * q + 1]), "s"(l_), "s"(rs_a), "n"(PSTR)
-          : "memory", "scc");
-    }
-    // last pass (rows 256..319): rows 304.. are padding, so the pieces of waves 2 and 3 in its second half are skipped —
-    // rows 312.. of buffer 0 hold the bias vector
-    {
-      const uint32_t l_ = l0 + (uint32_t)(8 * PSTR);
-      asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vw[8]), "s"(l_), "s"(rs_a) : "memory");
-      if (wave_u < 2) {
-        const uint32_t l2_ = l_ + (uint32_t)PSTR;
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vw[9]), "s"(l2_), "s"(rs_a) : "memory");
-      }
-    }
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %4, 0 offen lds\n\t"
+        "s_add_u32 m0, %3, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
+        "s_add_u32 m0, %3, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds"
+        ::"v"(vw[0]), "v"(vw[1]), "v"(vw[2]), "s"(l0), "s"(rs_a), "n"(PSTR), "n"(2 * PSTR)
+        : "memory", "scc");
   };
-  if (tid < 64) reinterpret_cast<float*>(sW + kBiasRow * 128)[tid] = p.bias[tid];  // visible after the first tile's barrier
+  if (tid < 64) reinterpret_cast<float*>(smem + kBiasOff)[tid] = p.bias[tid];  // visible after the first tile's barrier
 
-  const int coff0 = ((g ^ (i16 & 7)) << 4), coff1 = (((g + 4) ^ (i16 & 7)) << 4);
+  // fragment read of conv pixel (4 wave + f, i16), kernel row kr, K half h: 16 bytes = chunk 2 i16 + 4 h + g of window row
+  // 4 wave + f + kr (pixel i16 + 2 h + g / 2, channel half g & 1), at its swizzled place.  The 16 lanes of a group read chunks
+  // c, c + 2, ..., c + 30: lanes 8 apart would meet in one bank quad, the swizzle puts them in neighbouring ones.
+  const int lc0 = 2 * i16 + g, lc1 = lc0 + 4;
+  const int coff0 = (lc0 ^ ((lc0 >> 4) & 1)) << 4, coff1 = (lc1 ^ ((lc1 >> 4) & 1)) << 4;
 
   // The workgroup's tile sequence: first its tiles WITH arg-max bytes (images < n_idx_img), then those without, as two loops over
   // the same body — each instance is compiled with its own epilogue only, so the loop invariants of one pooling path do not
@@ -177,21 +177,32 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const unsigned char* a_rd = sW + buf * kWBytes + (wave * 64 + i16) * 128;
+    const unsigned char* a_rd = sW + buf * kWBytes + (4 * wave) * kRowPitch;
 #if !(defined(VDQN_STEM_PROBE) && (VDQN_STEM_PROBE & 1))  // diagnostic builds (tools/stem_phases.py): bit 0 = no K loop
+    // Window row R = f + kr serves every (conv row f, kernel row kr) pair on its diagonal: 14 fragment reads per tile instead of
+    // 32.  For a fixed f the products still arrive in the order kr = 0..3, h = 0, 1 — the accumulation order of vdqn_conv2d.
+    // (the two fragments of row R + 1 are read before the MFMAs of row R are issued: one LDS latency per tile instead of seven)
+    u32x4 fa[2][2];
+    fa[0][0] = *reinterpret_cast<const u32x4*>(a_rd + coff0);
+    fa[0][1] = *reinterpret_cast<const u32x4*>(a_rd + coff1);
 #pragma unroll
-    for (int kr = 0; kr < 4; ++kr) {
+    for (int R = 0; R < 7; ++R) {
+      if (R < 6) {
+        fa[(R + 1) & 1][0] = *reinterpret_cast<const u32x4*>(a_rd + (R + 1) * kRowPitch + coff0);
+        fa[(R + 1) & 1][1] = *reinterpret_cast<const u32x4*>(a_rd + (R + 1) * kRowPitch + coff1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        u32x4 fa[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) fa[f] = *reinterpret_cast<const u32x4*>(a_rd + (kr * 16 + f * 16) * 128 + (h ? coff1 : coff0));
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int kr = (R > 3 ? R - 3 : 0); kr <= (R < 3 ? R : 3); ++kr) {
+          const int f = R - kr;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[kr][h][j]), __builtin_bit_cast(bf16x8, fa[f]), acc[f][j], 0, 0, 0);
+            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[kr][h][j]), __builtin_bit_cast(bf16x8, fa[R & 1][h]), acc[f][j], 0, 0, 0);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);  // (keeps the next row's reads in front of this row's MFMAs and the rows in order)
     }
 #else
 #pragma unroll
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
       // 16 channels: the three columns of a pooling window are the lanes i16, i16 + 1, i16 + 2 of a 16-lane row (two DPP row
       // shifts; the even lanes 0..12 end with pooled column i16 / 2), the three rows of pooled row 2 wave are the lane's own
       // f = 0..2, and pooled row 2 wave + 1 needs rows f = 2, 3 and row f = 0 of the NEXT wave — the only thing that goes through
-      // LDS (its column maximum: 896 bytes per wave in the never-staged rows 304.. of the window buffers), behind the tile's
+      // LDS (its column maximum: 896 bytes per wave), behind the tile's
       // only barrier besides the one at its top.  No patch in LDS, no patch barriers, no strided patch reads.
       // bf16 bit patterns of non-negative values order like SIGNED 16-bit integers and every negative value (-0.0 included) is a
       // negative integer, so the ReLU is folded into the maxima: max(+0.0, a, b, ...) over the unclamped values.  Taps outside
@@ -245,8 +256,8 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
       // (the bias is read from LDS eight channels at a time, where it is used: sixteen resident values are registers the K loop of
       // this instance does not have)
       auto bias8 = [&](int hf, float (&b8)[8]) {
-        *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + hf * 8) * 4);
-        *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + hf * 8 + 4) * 4);
+        *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(smem + kBiasOff + (g * 16 + hf * 8) * 4);
+        *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(smem + kBiasOff + (g * 16 + hf * 8 + 4) * 4);
       };
       auto cvt = [&](int f, int e, const float (&b8)[8]) {  // channels 2e, 2e + 1 of patch row f: bias, bf16, packed (v_pk_add_f32, v_cvt_pk_bf16_f32)
         const f32x2 v = f32x2{acc[f][e >> 1][(e & 1) * 2], acc[f][e >> 1][(e & 1) * 2 + 1]} + f32x2{b8[2 * (e & 3)], b8[2 * (e & 3) + 1]};
@@ -261,10 +272,8 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
         return pmax(pmax(x & keep, x1), x2);
       };
       const bool col_lane = (i16 & 1) == 0 && i16 <= 12;
-      // exchange slots: sender wave 1 -> buffer 0 rows 304..310, sender waves 2, 3 -> buffer 1 rows 304..317; [pooled column][g][32 B]
-      auto xch = [&](int sender) {
-        return sW + (sender == 1 ? 0 : kWBytes) + (304 + (sender == 3 ? 7 : 0)) * 128 + (i16 >> 1) * 128 + g * 32;
-      };
+      // exchange slots: [sender wave - 1][pooled column][g][32 B]
+      auto xch = [&](int sender) { return smem + kXchOff + ((sender - 1) * 7 + (i16 >> 1)) * 128 + g * 32; };
       const bool row_out = ty == 0 && wave_u == 0;  // conv row -1: patch row 0 of the first tile row drops out (uniform)
       uint32_t P0[8];
 #pragma unroll
@@ -317,9 +326,9 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     }
     float bv[16];  // (re-read per tile from LDS: the weights occupy the registers a resident copy would need)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(bv + 4 * e) = *reinterpret_cast<const float4*>(sW + kBiasRow * 128 + (g * 16 + 4 * e) * 4);
-    __syncthreads();
-    bf16raw* sT = reinterpret_cast<bf16raw*>(sW + buf * kWBytes);
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(bv + 4 * e) = *reinterpret_cast<const float4*>(smem + kBiasOff + (g * 16 + 4 * e) * 4);
+    // (the patch has a region of its own: everyone finished pooling the previous tile's patch before this tile's top barrier)
+    bf16raw* sT = reinterpret_cast<bf16raw*>(smem + kPatchOff);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int r = wave * 64 + f * 16 + i16;
