@@ -328,6 +328,26 @@ def test_stem_pack_conv1_maxpool(dtype, src_kind):
     assert relerr(got, wref) < TOL_F32OUT[dtype]
 
 
+@pytest.mark.parametrize("n,n_idx", [(11, 0), (11, 3), (11, 11), (3, 1)])
+def test_stem_tile_loops_bit_identical(n, n_idx):
+    """The persistent stem walks a workgroup's arg-max tiles and then its plain tiles in two loops (csrc/stem.hip): 11 frames = 704
+    tiles on 512 workgroups (one or two tiles per workgroup and kind, ranges that are no multiple of the grid), 3 frames = fewer tiles
+    than workgroups.  Pooled values and arg-max bytes must be the bits of vdqn_conv2d + vdqn_maxpool_fwd for every split of the
+    frames into arg-max (the `s` rows of the online pass, train_q_network.py:131) and plain ones (:140-142)."""
+    from video_dqn_amd import ops
+    dtype = torch.bfloat16
+    frames = synth.make_frames_uint8(5, "t", n, 1, structured=True)
+    packed = ops.pack_input(torch.from_numpy(frames[:, 0]).to(DEV), 0, n, dtype)
+    w7 = q(rnd(2, "w7", (64, 3, 7, 7), -0.2, 0.2), dtype)
+    b = rnd(3, "b", (64,)).to(DEV)
+    c1 = ops.conv2d(packed, s2d_weights(w7, dtype), ho=112, wo=112, co=64, r=4, s=1, stride=1, pad=0, bias=b, relu=True, ci=64, pix_stride=16)
+    pool, idx = ops.maxpool_fwd(c1)
+    pool_p, idx_p = ops.stem_conv_pool(packed, s2d_weights(w7, dtype), b, n_idx=n_idx)
+    torch.cuda.synchronize()
+    assert torch.equal(pool_p, pool)
+    assert torch.equal(idx_p[:n_idx], idx[:n_idx]) and (n_idx == n or int(idx_p[n_idx:].max()) == 0)
+
+
 @pytest.mark.parametrize("n", [2, 5])
 def test_stem_wgrad_from_pooled_gradient(n):
     """vdqn_stem_wgrad_pool (max-pool backward fused into conv1's weight gradient) == vdqn_maxpool_bwd + vdqn_conv2d_wgrad."""
