@@ -1213,9 +1213,22 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
   for (; t < g_tiles; t += g_blocks, buf ^= 1) {
     const int tl = g_first + (int)xcd_remap((uint32_t)t, (uint32_t)g_tiles);
     const int m0 = tl * 128;
+#ifdef VDQN_STAMP
+    const unsigned long long st_w0 = __builtin_amdgcn_s_memtime();  // (tools/stamp_conv64.py) arrival at the tile's top
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // window t visible; everyone is done with the other buffer (and with the scratch)
+#ifdef VDQN_STAMP
+    // row of 8 words per (workgroup, tile number < 16): arrival, top (barrier passed), DMA issued, held stores + edge bits done
+    // (K loop begins), K loop done, epilogue done
+    const int st_k = (t - g_bid) / g_blocks;
+    unsigned long long* st_row = (p.pool_out && st_k < 16) ? reinterpret_cast<unsigned long long*>(p.pool_out) + ((size_t)blockIdx.x * 16 + st_k) * 8 : nullptr;
+    if (st_row && tid == 0) { st_row[0] = st_w0; st_row[1] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (t + g_blocks < g_tiles) issue_window(g_first + (int)xcd_remap((uint32_t)(t + g_blocks), (uint32_t)g_tiles), buf ^ 1);
+#ifdef VDQN_STAMP
+    if (st_row && tid == 0) st_row[2] = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b128(held[f], r_out, (int)held_off[f], 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(held_cs), r_cs, (int)held_cs_off, 0, 0);
@@ -1311,6 +1324,9 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     }                                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
   }
+#ifdef VDQN_STAMP
+    if (st_row && tid == 0) st_row[3] = __builtin_amdgcn_s_memtime();
+#endif
     VDQN_C64_LOAD(0, 0)
     VDQN_C64_STEP(0) VDQN_C64_STEP(1) VDQN_C64_STEP(2) VDQN_C64_STEP(3) VDQN_C64_STEP(4) VDQN_C64_STEP(5)
     VDQN_C64_STEP(6) VDQN_C64_STEP(7) VDQN_C64_STEP(8) VDQN_C64_STEP(9) VDQN_C64_STEP(10) VDQN_C64_STEP(11)
@@ -1318,6 +1334,9 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
 #undef VDQN_C64_STEP
 #undef VDQN_C64_MMA
 #undef VDQN_C64_LOAD
+#ifdef VDQN_STAMP
+    if (st_row && tid == 0) { asm volatile("s_nop 0" ::"v"(acc[3][1][3])); st_row[4] = __builtin_amdgcn_s_memtime(); }
+#endif
     // ---- epilogue (the arithmetic of igemm_epilogue, CPL = 8): lane (i16, g) owns channels ncol .. ncol + 7 of pixels f*16 + i16 ----
     {
       float bv[8];
@@ -1381,6 +1400,9 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
         }
       }
     }
+#ifdef VDQN_STAMP
+    if (st_row && tid == 0) st_row[5] = __builtin_amdgcn_s_memtime();
+#endif
   }
   // the last tile's stores
 #pragma unroll
@@ -1411,7 +1433,13 @@ int launch_conv64(const IgemmParams& p, hipStream_t stream) {
   }
   vdqn_prof_begin(MODE == 0 ? "conv64<bf16,fwd>" : "conv64<bf16,dgrad>", 2.0 * p.M * p.co * p.ktot,
                   2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
+#ifdef VDQN_STAMP
+  IgemmParams ps = p;
+  ps.pool_out = g_stamp_buffer;  // (conv64 has no pooled output: the field carries the stamp buffer in diagnostic builds)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kC64Smem, stream, ps, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), grp_a);
+#else
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kC64Smem, stream, p, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), grp_a);
+#endif
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
