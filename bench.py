@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--pack-ahead", action="store_true",
                     help="pack the next minibatch's frames under the current update's backward pass (default: every update packs its own frames at its start)")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="consecutive timed windows of --steps updates each (barrier + synchronize around every one); `value` is the MEDIAN "
+                         "window, `window_values` lists them all (1 = the single window of rounds 1-4)")
     ap.add_argument("--pool", type=int, default=4,
                     help="distinct synthetic minibatches resident in HBM, used round-robin (4 x 77 MB of frames at batch 256 do "
                          "not fit the 256 MiB Infinity Cache together, so no step reads its frames from cache)")
@@ -80,6 +83,8 @@ def parse():
     if args.c4:
         args.steps = max(args.steps, 2200)
         args.target_update_interval = 1000
+        args.windows = 1
+    args.windows = max(1, args.windows)
     return args
 
 
@@ -120,42 +125,51 @@ def cpu_baseline(batch: int, budget_s: float = 25.0):
 
 
 def live_pmc_traffic(args):
-    """HBM bytes per launch of every kernel, measured NOW: two rocprofv3 child passes (--kernel-trace --pmc FETCH_SIZE, then
+    """HBM bytes per launch of every kernel, measured in THIS run: two rocprofv3 child passes (--kernel-trace --pmc FETCH_SIZE, then
     --pmc WRITE_SIZE: separate passes, no other tracing, the program itself behind `--`, as MI355X_MICROARCH.md prescribes) of this
-    bench command at 2 steps with the side streams serialised, started BEFORE this process touches the GPU.  Corrections as in
-    tools/pmc_summary.py (FETCH_SIZE counts half of wide streaming reads on gfx950).  Returns {kernel tag: bytes per launch} or
-    None (no rocprofv3, a failed pass, VDQN_BENCH_NO_LIVE_PMC=1 / --no-live-pmc): the caller then quotes the committed passes."""
+    bench command at 2 steps with the side streams serialised.  They run AFTER the timed region and the event-profiled steps (this
+    process then only holds its memory), each bounded by a 100 s timeout; the scratch directory is removed whatever happens.
+    Corrections as in tools/pmc_summary.py (FETCH_SIZE counts half of wide streaming reads on gfx950).
+    Returns ({kernel tag: bytes per launch} or None, reason): None = the caller quotes the committed passes and says why."""
     import shutil
     import subprocess
     import tempfile
-    if args.no_live_pmc or os.environ.get("VDQN_BENCH_NO_LIVE_PMC") == "1" or shutil.which("rocprofv3") is None:
-        return None
+    if args.no_live_pmc or os.environ.get("VDQN_BENCH_NO_LIVE_PMC") == "1":
+        return None, "switched off (--no-live-pmc / VDQN_BENCH_NO_LIVE_PMC=1)"
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
     if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
-        return None  # this process is itself being profiled
+        return None, "this process is itself being profiled"
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    tmp = None
     try:
         from pmc_summary import per_kernel
         tmp = tempfile.mkdtemp(prefix="vdqn_pmc_", dir="/tmp")
         tot = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--output-format", "csv", "--",
-                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--windows", "1", "--ramp-seconds", "0", "--no-cpu-baseline",
                    "--no-profile", "--no-live-pmc", "--pool", "1", "--batch", str(args.batch), "--frames", str(args.frames), "--dtype", args.dtype,
                    "--arch", args.arch, "--loss-kind", args.loss_kind]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", VDQN_NO_OVERLAP="1"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=180)
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", VDQN_NO_OVERLAP="1"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.PIPE, timeout=100)
+            except subprocess.TimeoutExpired:
+                return None, f"the {counter} pass exceeded its 100 s timeout"
             if r.returncode != 0:
-                return None
+                tail = (r.stderr or b"").decode(errors="replace").strip().splitlines()[-1:] or [""]
+                return None, f"the {counter} pass returned {r.returncode}: {tail[0][:160]}"
             csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, counter)) for f in fs if f.endswith("counter_collection.csv")]
             if not csvs:
-                return None
+                return None, f"the {counter} pass wrote no counter_collection.csv"
             tot[counter] = per_kernel(csvs[0], counter)
         (ft, fc), (wt, wc) = tot["FETCH_SIZE"], tot["WRITE_SIZE"]
-        out = {t: int(round(2 * 1024 * ft[t] / max(fc[t], 1) + 1024 * wt[t] / max(wc[t], 1))) for t in set(ft) | set(wt)}
-        shutil.rmtree(tmp, ignore_errors=True)
-        return out
-    except Exception:
-        return None
+        return {t: int(round(2 * 1024 * ft[t] / max(fc[t], 1) + 1024 * wt[t] / max(wc[t], 1))) for t in set(ft) | set(wt)}, "live"
+    except Exception as e:  # noqa: BLE001 - any failure falls back to the committed passes, with the reason on the line
+        return None, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        if tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pmc_traffic(kernel: str, batch: int, frames: int, dtype: str, arch: str = "extra_capacity"):
@@ -186,8 +200,6 @@ def main():
     out_stream = launch.claim_stdout()  # the JSON line goes here; fd 1 now points at stderr (native-library chatter)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
-    # roofline.traffic, live: PMC child passes before this process initialises the GPU (one process, the default path only)
-    live_traffic = live_pmc_traffic(args) if (world == 1 and not args.no_profile and not args.force_dist and args.h2d == "none") else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     if os.environ.get("VDQN_BENCH_SINGLE_DEVICE") == "1":
@@ -297,21 +309,34 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     sample0 = stp.sample_number
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    per_rank_ms = [round(1e3 * elapsed / args.steps, 3)]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per_rank_ms = [round(1e3 * x.item() / args.steps, 3) for x in allt]
-        elapsed = max(x.item() for x in allt)  # MAX over ranks
+    # --windows consecutive timed windows of EXACTLY --steps updates, each bracketed by barrier + synchronize on both sides and
+    # reduced by MAX over ranks; the reported value is the median window (a single 20-step window is 0.11 s: inside the box's noise)
+    win_elapsed, win_rank_ms = [], []
+    for _w in range(args.windows):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        rank_ms = [round(1e3 * el / args.steps, 3)]
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            rank_ms = [round(1e3 * x.item() / args.steps, 3) for x in allt]
+            el = max(x.item() for x in allt)  # MAX over ranks
+        win_elapsed.append(el)
+        win_rank_ms.append(rank_ms)
+    order = sorted(range(args.windows), key=lambda i: win_elapsed[i])
+    med = order[(args.windows - 1) // 2]  # (an even count: the slower of the two middle windows)
+    elapsed, per_rank_ms = win_elapsed[med], win_rank_ms[med]
     loss_val = float(loss.item())
     params_sha = None
     if args.params_digest and rank == 0:
@@ -328,48 +353,36 @@ def main():
         # runs these steps (they contain the gradient all-reduce); only rank 0 records and reports.
         net.lib.vdqn_net_set_overlap(net.handle, 0)
         torch.cuda.synchronize()
-        if rank == 0:
-            _lib.profile_enable(True)
+        per_step = []  # one profile per event-profiled step (rank 0): the spread of the dominant kernel's launch time over them
         for _ in range(args.profile_steps):
+            if rank == 0:
+                _lib.profile_enable(True)
             stp.forward_backward(before, after, 0, act, rew, term)
             if comm:
                 comm.finish()
             stp.optimizer_step()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            if rank == 0:
+                per_step.append(_lib.profile_collect())
+                _lib.profile_enable(False)
         net.lib.vdqn_net_set_overlap(net.handle, 1)
+    prof = None
     if not args.no_profile and rank == 0:
-        prof = _lib.profile_collect()
-        _lib.profile_enable(False)
+        prof = {}
+        for ps in per_step:
+            for k, v in ps.items():
+                d = prof.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                for f in ("launches", "ms", "flops", "bytes"):
+                    d[f] += v[f]
         tot_ms = sum(v["ms"] for v in prof.values())
         kernels = {k: {"launches_per_step": v["launches"] // args.profile_steps, "ms_per_step": round(v["ms"] / args.profile_steps, 4),
                        "share": round(v["ms"] / tot_ms, 4),
                        "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] > 0 else None,
                        "alg_gbs": round(v["bytes"] / v["ms"] / 1e6, 1)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        name, v = dom
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        if v["flops"] > 0:
-            ach = v["flops"] / v["ms"] / 1e9
-            live = (live_traffic or {}).get(name)
-            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": live if live else pmc_traffic(name, B, F, args.dtype, args.arch),
-                        "traffic_source": ("live: two rocprofv3 child passes of this command (--kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE; "
-                                           "2 steps, side streams serialised) run before the timed region; 2 x FETCH_SIZE + WRITE_SIZE per launch"
-                                           if live else
-                                           "profiles/pmc_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "command, committed (the live child passes were skipped or failed), per launch"),
-                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
-                        "alg_flops_per_launch": round(v["flops"] / v["launches"]),
-                        "alg_bytes_per_launch": round(v["bytes"] / v["launches"]),
-                        "measured": f"HIP events around every launch, {args.profile_steps} steps right after the timed region, side-stream overlap off"}
-        else:
-            ach = v["bytes"] / v["ms"] / 1e6
-            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"]}
 
     # the shader clock this device holds under a full-rate bf16 MFMA stream on random operands (in-kernel s_memtime /
     # s_memrealtime): what the 2.5 PFLOP/s nominal peak of `roofline.peak` shrinks to on this box
+    # (measured right behind the profiled steps, while the device is still hot)
     mfma_clock = None
     if rank == 0 and not args.no_profile:
         try:
@@ -382,6 +395,39 @@ def main():
                                      "clock = delta s_memtime / delta s_memrealtime x 100 MHz, median over waves"}
         except Exception:
             mfma_clock = None
+
+    if prof:
+        name, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        step_us = sorted(1e3 * ps[name]["ms"] / ps[name]["launches"] for ps in per_step if name in ps and ps[name]["launches"])
+        spread = {"min": round(step_us[0], 2), "median": round(step_us[(len(step_us) - 1) // 2], 2), "max": round(step_us[-1], 2),
+                  "over": f"{len(step_us)} profiled steps (average launch of each)"} if step_us else None
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        if v["flops"] > 0:
+            # roofline.traffic, live: two rocprofv3 --pmc child passes of this command, AFTER everything that is timed (one process,
+            # the default path only); the committed passes are quoted, with the reason, when they are skipped or fail
+            live_traffic, live_reason = None, "not a default one-process run"
+            if world == 1 and not args.force_dist and args.h2d == "none":
+                live_traffic, live_reason = live_pmc_traffic(args)
+            ach = v["flops"] / v["ms"] / 1e9
+            live = (live_traffic or {}).get(name)
+            if live_traffic is not None and not live:
+                live_reason = f"the live passes hold no row for {name}"
+            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": live if live else pmc_traffic(name, B, F, args.dtype, args.arch),
+                        "traffic_source": ("live: two rocprofv3 child passes of this command (--kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE; "
+                                           "2 steps, side streams serialised) run after the timed region; 2 x FETCH_SIZE + WRITE_SIZE per launch"
+                                           if live else
+                                           "profiles/pmc_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           f"command, committed, per launch (live passes: {live_reason})"),
+                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "avg_launch_us_per_step": spread, "launches": v["launches"],
+                        "alg_flops_per_launch": round(v["flops"] / v["launches"]),
+                        "alg_bytes_per_launch": round(v["bytes"] / v["launches"]),
+                        "measured": f"HIP events around every launch, {args.profile_steps} steps right after the timed region, side-stream overlap off"}
+        else:
+            ach = v["bytes"] / v["ms"] / 1e6
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "avg_launch_us_per_step": spread, "launches": v["launches"]}
     if rank == 0:
         tuples = B * world * args.steps
         value = tuples / elapsed
@@ -389,6 +435,9 @@ def main():
         out = {
             "metric": "(s,a,r,s') TD-updates/sec, 224x224 frames, batch 256, 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "tuples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_steps": ramp_steps,
+            "windows": args.windows, "window_values": [round(B * world * args.steps / e, 2) for e in win_elapsed],
+            "window_ms_per_step": [round(1e3 * e / args.steps, 3) for e in win_elapsed],
+            "value_is": f"median of {args.windows} consecutive windows of {args.steps} updates" if args.windows > 1 else f"one window of {args.steps} updates",
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if args.h2d == "none" else f"synthetic, uint8 frames copied from pinned host memory every step ({args.h2d})",
             "config": {"workload": f"HabitatDQNMultiAction ResNet-18 {args.arch}, 5 categories x 3 actions, full TD update "

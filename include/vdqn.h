@@ -412,7 +412,8 @@ int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream);
  * for stage 2 makes `stream` wait for the side stream, so vdqn_adam on `stream` sees every gradient.  A consumer of one stage's
  * gradients (the data-parallel all-reduce) orders itself behind vdqn_net_grad_stream. */
 int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream);
-/* A second internal stream (below the caller's stream in priority, idle in the default schedule): for work of the NEXT update that a
+/* A second internal stream (below the caller's stream in priority).  In the default schedule the engine runs every other weight
+ * gradient on it (two weight-gradient streams, VDQN_WGRAD_STREAMS=2) and joins it at the end of each backward stage; it is also for work of the NEXT update that a
  * loop wants to run under the current one (its frames packed ahead, vdqn_step_args.packed_frames; a stage's weights folded ahead,
  * vdqn_net_pack_weights_stage).  The caller orders it (hipStreamWaitEvent both ways); NULL when the overlap is off. */
 void* vdqn_net_aux_stream(vdqn_net* net);

@@ -37,16 +37,16 @@ def _run(net_stepper, tup, lo, hi, finish=None):
     torch.cuda.synchronize()
 
 
-def _make(B, world, hook=None):
+def _make(B, world, hook=None, deterministic=True):
     from video_dqn_amd import synth
     from video_dqn_amd.engine import NetEngine, TDStepper
-    net = NetEngine(3, 5, 1, True, "f32", 2 * B, deterministic=True)
+    net = NetEngine(3, 5, 1, True, "f32", 2 * B, deterministic=deterministic)
     net.load_tensors(synth.make_state_dict(7))
     stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, world_size=world, allreduce=hook)
     return net, stp
 
 
-def _worker(rank, world, port, out_dir, per_rank=4):
+def _worker(rank, world, port, out_dir, per_rank=4, deterministic=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -59,7 +59,7 @@ def _worker(rank, world, port, out_dir, per_rank=4):
         dist.all_reduce(h)
         grad_slice.copy_(h)
 
-    ns = _make(per_rank, world, hook)
+    ns = _make(per_rank, world, hook, deterministic)
     for step in (1, 2):
         tup = _batch(200 + step, per_rank * world)
         _run(ns, tup, rank * per_rank, (rank + 1) * per_rank)
@@ -68,18 +68,21 @@ def _worker(rank, world, port, out_dir, per_rank=4):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,per_rank", [(2, 4), (4, 2), (8, 2)], ids=["world2", "world4", "world8"])
-def test_n_ranks_equal_one_big_batch(tmp_path, world, per_rank):
+@pytest.mark.parametrize("world,per_rank,deterministic", [(2, 4, True), (4, 2, True), (8, 2, True), (2, 4, False)],
+                         ids=["world2", "world4", "world8", "world2_default_atomic_mode"])
+def test_n_ranks_equal_one_big_batch(tmp_path, world, per_rank, deterministic):
     """N ranks x per_rank samples == ONE process on the N * per_rank samples (the reference is one process,
     train_q_network.py:255-259,275): after two updates every replica holds bit-identical parameters (same reduced gradient,
     same Adam), and they equal the big-batch run's up to the summation order of the gradient (f32, deterministic mode).
-    Arithmetic, not plumbing: world 4 and 8 run the same bound as world 2."""
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), per_rank), nprocs=world, join=True)
+    Arithmetic, not plumbing: world 4 and 8 run the same bound as world 2.  One case runs the SHIPPED default (f32 atomic sums
+    for the split-K weight gradients): the replicas still hold bit-identical parameters (every rank applies the same reduced
+    gradient) and meet the same bound against the big batch."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), per_rank, deterministic), nprocs=world, join=True)
     ranks = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
     r0 = ranks[0]
     for r in ranks[1:]:
         assert torch.equal(r0["params"], r["params"])  # replicas stay bit-identical: same reduced gradient, same Adam
-    ns = _make(per_rank * world, 1)
+    ns = _make(per_rank * world, 1, None, deterministic)
     for step in (1, 2):
         _run(ns, _batch(200 + step, per_rank * world), 0, per_rank * world)
     big = ns[0].params.cpu()

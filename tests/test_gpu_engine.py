@@ -387,6 +387,38 @@ def test_frames_packed_one_update_ahead_is_the_same_update(dtype):
     assert stp._packed_bufs[0] is not None  # the wrong announcements were packed (and discarded)
 
 
+@pytest.mark.parametrize("dtype", ["bf16"])
+def test_frames_announced_ahead_may_alias_this_calls_tensors(dtype):
+    """`next_frames` that ARE this call's tensors.  A loop that replays one resident minibatch (bench.py --pack-ahead
+    --pool 1) gets a valid pack; a loop that refills fixed staging tensors in place advances their `_version`, so the pack announced
+    on the old content is discarded and the call packs its own frames.  Both bit-equal to the loop without announcements."""
+    from video_dqn_amd.engine import TDStepper
+    B = 4
+    batches = []
+    for seed in (5, 6, 7):
+        (tup, _) = synth.make_batch(seed, B, 1, structured=True, reward_p=0.3)
+        batches.append((tup[0].contiguous().to(DEV), tup[1].contiguous().to(DEV), 1, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV)))
+
+    def run(mode):
+        net = make_engine(dtype, seed=7, max_batch=2 * B, deterministic=True)
+        stp = TDStepper(net, B, lr=1e-3, gamma=0.99, clip_rect=True, target_update_interval=3)
+        sb, sa = torch.empty_like(batches[0][0]), torch.empty_like(batches[0][1])
+        losses = []
+        for i in range(6):
+            b = batches[0] if mode.startswith("replay") else batches[i % 3]
+            if mode.startswith("refill"):
+                sb.copy_(b[0]); sa.copy_(b[1])
+                b = (sb, sa) + b[2:]
+            nxt = b[:3] if mode.endswith("announced") else None
+            losses.append(stp.step(*b, next_frames=nxt).clone())
+        torch.cuda.synchronize()
+        return net.params.clone(), torch.cat(losses)
+    for kind in ("replay", "refill"):
+        p0, l0 = run(kind)
+        p1, l1 = run(kind + "_announced")
+        assert torch.equal(p0, p1) and torch.equal(l0, l1), kind
+
+
 def _act(net, buf, n_samples, name, shape):
     """View of a named activation inside the engine's workspace (vdqn_net_act_offset)."""
     off = net.lib.vdqn_net_act_offset(net.handle, n_samples, name.encode())

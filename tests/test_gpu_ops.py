@@ -635,3 +635,50 @@ def test_weight_gradient_kernels_both_tilings(win128):
                         "-m", "gpu", "-q", "-x", "-k", "(test_conv_wgrad and not both_tilings) or deterministic_wgrad_operator"],
                        env=dict(os.environ, VDQN_WGRAD_WIN128=win128), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+S2P_CASES = [  # n, ci, planes, h, pretend-CUs: layer2.0 / 3.0 / 4.0 chunk counts (1 / 2 / 4), tile walks of 2 - 13 tiles per workgroup
+    (21, 64, 128, 28, 4), (9, 64, 128, 56, 5), (40, 128, 256, 20, 4), (17, 128, 256, 28, 7), (90, 256, 512, 14, 4), (33, 256, 512, 12, 9),
+    (3, 64, 128, 8, 4), (2, 128, 256, 6, 4), (2, 256, 512, 4, 4),
+]
+
+
+@pytest.mark.parametrize("sib", [True, False])
+@pytest.mark.parametrize("case", S2P_CASES)
+def test_stride2_persistent_kernel_with_fused_downsample(case, sib):
+    """win9sp_kernel (round 5): the stride-2 plane-window kernel as persistent workgroups that walk their XCD's tiles, the next tile's
+    first two K-steps staged under the current tile's last steps, and (sib) the block's 1x1 / stride-2 downsample as extra K-steps
+    on the P00 window behind the 3x3's epilogue.  With the device pretended to have 4 - 9 CUs a workgroup walks up to 13 tiles,
+    XCD ranges of unequal length included.  Both outputs must be BIT-IDENTICAL to the same kernel run one tile per workgroup, the
+    downsample also to its own launch on the generic kernel (same K order), and both match torch."""
+    from video_dqn_amd import ops, _lib
+    n, ci, co, h, cus = case
+    dtype = torch.bfloat16
+    ho = h // 2
+    x = q(rnd(51, "x", (n, ci, h, h)), dtype)
+    w1 = q(rnd(52, "w1", (co, ci, 3, 3), -0.1, 0.1), dtype)
+    w2 = q(rnd(53, "w2", (co, ci, 1, 1), -0.2, 0.2), dtype)
+    b1, b2 = rnd(54, "b1", (co,)), rnd(55, "b2", (co,))
+    xd = nhwc(x, dtype)
+    kw = dict(ho=ho, wo=ho, co=co, r=3, s=3, stride=2, pad=1, bias=b1.to(DEV), relu=True)
+    kw2 = dict(wt2=krsc(w2, dtype), bias2=b2.to(DEV), co2=co, relu2=False) if sib else {}
+    lib = _lib.load()
+
+    def run():
+        r = ops.conv2d(xd, krsc(w1, dtype), **kw, **kw2)
+        torch.cuda.synchronize()
+        return r if sib else (r, None)
+    one_out, one_out2 = run()  # the real CU count: these sizes are at most one round of tiles -> one tile per workgroup
+    lib.vdqn_debug_set_num_cus(cus)
+    try:
+        walk_out, walk_out2 = run()
+    finally:
+        lib.vdqn_debug_set_num_cus(0)
+    assert torch.equal(walk_out, one_out)
+    assert relerr(one_out.float().cpu().permute(0, 3, 1, 2), F.relu(F.conv2d(x, w1, b1, 2, 1))) < TOL[dtype]
+    if sib:
+        assert torch.equal(walk_out2, one_out2)
+        sep2 = ops.conv2d(xd, krsc(w2, dtype), ho=ho, wo=ho, co=co, r=1, s=1, stride=2, pad=0, bias=b2.to(DEV), relu=False)
+        torch.cuda.synchronize()
+        assert torch.equal(one_out2, sep2)
+        assert relerr(one_out2.float().cpu().permute(0, 3, 1, 2), F.conv2d(x, w2, b2, 2, 0)) < TOL[dtype]

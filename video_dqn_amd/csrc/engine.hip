@@ -904,8 +904,10 @@ int64_t wgrad_max_imgs(const vdqn_net* net, const Layer& L) {
 
 // VDQN_FUSE_DS: the 1x1 downsample of a stride-2 BasicBlock rides in its sibling 3x3's launches.  Bit 0 (default on): backward —
 // extra K-steps of the 3x3's stride-2 data gradient, the shortcut gradient never exists (0.27 instead of 0.42 ms per update);
-// bit 1 (default off): forward — second output of one launch, three launches fewer per pass, bit-identical outputs, but the
-// short sibling tiles (1-4 K-steps) between the long ones cost 0.07 ms per update more than their own launch did.
+// bit 1 (default on since round 5, bf16 engines): forward — second output of one launch, three launches fewer per pass,
+// bit-identical outputs: the persistent plane-window kernel (win9s.hip, win9sp_kernel) runs the 1x1 as extra K-steps on the P00
+// window behind the 3x3's epilogue.  (On the generic kernel — f32 engines, odd-sized inputs — the short sibling tiles between the
+// long ones cost more than their own launch did: bit 2 forces the fused form there too.)
 // VDQN_WGRAD_TWO_STAGE=1: the split-K weight-gradient partials as plain stores into per-split copies + one ordered reduce kernel
 // per layer (the deterministic mode's path, include/vdqn.h vdqn_wgrad_args.workspace) also in the default mode — instead of
 // ~25-50 MB of f32 atomics per launch at the ~1.3 TB/s the memory side sustains for them
@@ -915,11 +917,11 @@ bool wgrad_two_stage() {
 }
 
 int fuse_ds_mask() {
-  static const int m = [] { const char* e = getenv("VDQN_FUSE_DS"); return e ? atoi(e) : 1; }();
+  static const int m = [] { const char* e = getenv("VDQN_FUSE_DS"); return e ? atoi(e) : 3; }();
   return m;
 }
 bool fuse_ds() { return (fuse_ds_mask() & 1) != 0; }
-bool fuse_ds_fwd() { return (fuse_ds_mask() & 2) != 0; }
+bool fuse_ds_fwd(int dtype) { return (fuse_ds_mask() & 2) != 0 && (dtype == VDQN_BF16 || (fuse_ds_mask() & 4) != 0); }
 
 // packed_b / split_units: grouped forward — units [split_units, n_units) run with the second network's packed weights
 int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* in, void* out, int n_units, const void* resid,
@@ -1069,7 +1071,7 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
       (void)hipStreamWaitEvent(st, late_weights, 0);
       late_weights = nullptr;
     }
-    if (net->l_b_ds[b] >= 0 && fuse_ds_fwd() && !packed_b) {  // stride-2 block: conv1 and the downsample read the same pixels — one launch
+    if (net->l_b_ds[b] >= 0 && fuse_ds_fwd(dt) && !packed_b) {  // stride-2 block: conv1 and the downsample read the same pixels — one launch
       RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st, &net->layers[net->l_b_ds[b]], acts + A.ds[b]));
       identity = acts + A.ds[b];
     } else {

@@ -29,6 +29,7 @@
 
 int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, int n_idx_img, hipStream_t st);  // stem.hip
 int vdqn_launch_win9s(const void* igemm_params, hipStream_t stream);                                                              // win9s.hip
+int vdqn_win9s_supports(int cpk, int has_sib);                                                                                    // win9s.hip
 int vdqn_launch_win9m(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9m.hip
 int vdqn_launch_win9u(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9.hip
 
@@ -1622,11 +1623,13 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
     return mode == 0 ? launch_igemm_win<float, 64, 0>(p, st) : launch_igemm_win<float, 64, 1>(p, st);
   }
   // 3x3 / stride 2 / pad 1 forward over an even-sized input (conv1 of layer2.0 / layer3.0 / layer4.0), bf16, 128-column tiles: the
-  // plane-window kernel (win9s.hip; VDQN_S2WIN=0 keeps the generic kernel).  No grouped form, no fused sibling.
+  // plane-window kernel (win9s.hip; VDQN_S2WIN=0 keeps the generic kernel).  No grouped form.  A fused sibling 1x1 (the block's
+  // downsample) rides in the same persistent launch for 1, 2 or 4 channel chunks (round 5).
   static const int use_s2win = [] { const char* e = getenv("VDQN_S2WIN"); return e ? atoi(e) : 1; }();
-  if (use_s2win && mode == 0 && !has_sib && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 2 && a->pad == 1 &&
+  if (use_s2win && mode == 0 && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 2 && a->pad == 1 &&
       bn == 128 && a->co % 128 == 0 && a->hi == 2 * a->ho && a->wi == 2 * a->wo && a->wo >= 2 && a->wo <= 28 && a->pix_stride == a->ci && a->ci % 64 == 0 &&
-      p.in_bytes < 0x7fffffffLL && !a->colsum_part && !a->mask) {
+      p.in_bytes < 0x7fffffffLL && !a->colsum_part && !a->mask && vdqn_win9s_supports(a->ci / 64, has_sib) &&
+      (!has_sib || (a->co2 == a->co && p.vec_ok && !a->out_f32 && !a->resid))) {
     if (group_rows > 0) return VDQN_OK;  // no grouped form: the caller runs the two row ranges as two launches of THIS kernel (same bits as two passes)
     return vdqn_launch_win9s(&p, st);
   }

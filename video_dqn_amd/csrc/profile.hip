@@ -4,6 +4,7 @@
 // cross-checked against `rocprofv3 --kernel-trace --stats` (profiles/).
 #include <algorithm>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -39,7 +40,13 @@ void vdqn_ensure_dyn_smem(const void* kernel, size_t bytes) {
   }
 }
 
+// test hook (not part of include/vdqn.h): pretend the device has n CUs (0 = the real count).  The persistent kernels size their
+// grids by it, so a test can run their tile walks — several tiles per workgroup, XCD ranges of unequal length — on small tensors.
+static std::atomic<int> g_cus_override{0};
+extern "C" void vdqn_debug_set_num_cus(int n) { g_cus_override.store(n > 0 ? n : 0); }
+
 int vdqn_num_cus() {
+  if (const int o = g_cus_override.load()) return o;
   static std::mutex mu;
   static int cus[64] = {0};
   int dev = 0;

@@ -28,6 +28,7 @@ class BucketAllReduce:
         self._loss_bufs = [None, None]     # launch_loss: two device scalars used in turn
         self._loss_slot = 0
         self._loss_pending = None
+        self._loss_copied = None           # event behind launch_loss's read of the stepper's loss scalar (finish() waits for it)
 
     def launch_loss(self, loss: torch.Tensor) -> None:
         """SUM the ranks' shares of the global-batch mean loss (train_q_network.py:180,228-231) WITHOUT the compute stream ever
@@ -41,6 +42,11 @@ class BucketAllReduce:
         if buf is None or buf.device != loss.device:
             buf = self._loss_bufs[self._loss_slot] = torch.zeros(1, dtype=torch.float32, device=loss.device)
         buf.copy_(loss.reshape(1))
+        # the NEXT update zeroes `loss` on the compute stream: finish() orders that stream behind this 4-byte read (not behind the
+        # collective), so the read / overwrite pair is ordered whatever the schedule of the target pass is
+        if loss.is_cuda:
+            self._loss_copied = torch.cuda.Event()
+            self._loss_copied.record()
         self._loss_pending = (buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def take_loss(self):
@@ -61,6 +67,9 @@ class BucketAllReduce:
         for w in self._works:
             w.wait()
         self._works.clear()
+        if self._loss_copied is not None:
+            torch.cuda.current_stream().wait_event(self._loss_copied)
+            self._loss_copied = None
 
 
 class CAbiBucketAllReduce:
@@ -82,7 +91,7 @@ class CAbiBucketAllReduce:
         self.world_size, self.force = world_size, force
         self.bucket_bytes: List[int] = []
         self._events: List = []
-        self._loss_bufs, self._loss_slot, self._loss_pending = [None, None], 0, None
+        self._loss_bufs, self._loss_slot, self._loss_pending, self._loss_copied = [None, None], 0, None, None
         uid = C.create_string_buffer(_lib.COMM_UID_BYTES)
         nonce = os.environ.get("VDQN_JOB_NONCE") or os.environ.get("MASTER_PORT") or os.environ.get("VDQN_LAUNCHER_PID") or "0"
         uid_path = f"{uid_path}.{nonce}"
@@ -126,6 +135,9 @@ class CAbiBucketAllReduce:
         for ev in self._events:
             cur.wait_event(ev)
         self._events.clear()
+        if self._loss_copied is not None:
+            cur.wait_event(self._loss_copied)
+            self._loss_copied = None
 
     class _EventWork:  # the `work` of take_loss(): wait() orders the current stream behind the collective
         def __init__(self, ev):
@@ -144,6 +156,8 @@ class CAbiBucketAllReduce:
             buf = self._loss_bufs[self._loss_slot] = torch.zeros(1, dtype=torch.float32, device=loss.device)
         buf.copy_(loss.reshape(1))
         st = torch.cuda.current_stream()
+        self._loss_copied = torch.cuda.Event()  # (see BucketAllReduce.launch_loss)
+        self._loss_copied.record(st)
         self._lib.check(self.lib.vdqn_allreduce_bucket(self.handle, buf.data_ptr(), 1, self._lib.VDQN_F32, st.cuda_stream), "vdqn_allreduce_bucket")
         ev = torch.cuda.Event()
         ev.record(st)

@@ -427,10 +427,9 @@ class TDStepper:
                 a.packed_frames = self._packed_buffer(slot).data_ptr()
             _lib.check(self.lib.vdqn_net_td_forward(n.handle, C.byref(a), st), "vdqn_net_td_forward")
             if next_frames is not None:
-                mine = {before.data_ptr(), None if after is None else after.data_ptr()} - {None}
-                if next_frames[0].data_ptr() in mine or (next_frames[1] is not None and next_frames[1].data_ptr() in mine):
-                    raise _lib.VdqnError("next_frames alias this call's before/after tensors: a buffer that is refilled for the next "
-                                         "call cannot be packed ahead (it still holds THIS call's frames) — pass distinct tensors")
+                # (next_frames may alias this call's tensors — a loop that replays the same resident minibatch: the pack made now is
+                # valid as long as the tensors are not rewritten.  A loop that REFILLS them in place advances `_version`, the key
+                # announced here then differs from the one that arrives, and the stale pack is discarded: _frames_key)
                 self._pack_ahead(next_frames, 1 if slot == 0 else 0)
             if not n.extra_capacity:  # train-mode BatchNorm: model(before) [+ model(after)], F feature calls each
                 n.num_batches_tracked += (1 if self.gtb else 2) * n.num_frames

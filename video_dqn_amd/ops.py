@@ -46,8 +46,17 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
     a.ho, a.wo, a.co, a.ldo = ho, wo, co, ldo
     a.r, a.s, a.stride, a.pad = r, s, stride, pad
     a.mode, a.relu, a.dtype = mode, int(relu), dtype_code(x)
+    # every field that decides which kernel takes the call is set BEFORE the colsum-row query (the skinny kernels refuse a call with
+    # column sums or a sibling: a query on half-filled args would answer for another kernel than the one that runs)
+    out2 = None
+    if wt2 is not None and mode == 0:
+        out2 = torch.empty((n, ho, wo, co2), dtype=x.dtype, device=x.device)
+        a.wt2, a.bias2, a.out2, a.co2, a.ldo2, a.relu2 = _ptr(wt2), _ptr(bias2), _ptr(out2), co2, co2, int(relu2)
+    elif wt2 is not None:
+        a.wt2, a.in2, a.ci2 = _ptr(wt2), _ptr(in2), in2.shape[-1]
     part = None
     if want_colsum:
+        a.colsum_part = 16  # non-null placeholder for the query; the real buffer is set below
         rows = lib.vdqn_conv2d_colsum_rows(C.byref(a))  # 128, or the row tile of the kernel that takes this call
         if mode == 1 and stride == 2:  # one run of tiles per output-parity class
             n_tiles = sum((n * hc * wc + rows - 1) // rows for hc in ((ho + 1) // 2, ho // 2) for wc in ((wo + 1) // 2, wo // 2))
@@ -55,12 +64,6 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
             n_tiles = (n * ho * wo + rows - 1) // rows
         part = torch.empty((n_tiles, ldo), dtype=torch.float32, device=x.device)
     a.colsum_part = _ptr(part)
-    out2 = None
-    if wt2 is not None and mode == 0:
-        out2 = torch.empty((n, ho, wo, co2), dtype=x.dtype, device=x.device)
-        a.wt2, a.bias2, a.out2, a.co2, a.ldo2, a.relu2 = _ptr(wt2), _ptr(bias2), _ptr(out2), co2, co2, int(relu2)
-    elif wt2 is not None:
-        a.wt2, a.in2, a.ci2 = _ptr(wt2), _ptr(in2), in2.shape[-1]
     _lib.check(lib.vdqn_conv2d(C.byref(a), _stream()), "vdqn_conv2d")
     if out2 is not None:
         return out, out2
