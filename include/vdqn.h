@@ -134,6 +134,13 @@ typedef struct vdqn_wgrad_args {
 int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream);
 int64_t vdqn_conv2d_wgrad_workspace_bytes(const vdqn_wgrad_args* a);  /* -1 on invalid arguments */
 
+/* Host side of the streaming input path (decoded-frame shards that do not fit in HBM): gather n records of bytes_each bytes —
+ * record i from src[i], e.g. a frame inside a memory-mapped shard — into dst + i * bytes_each (a pinned staging buffer) on
+ * `threads` host threads; returns when all are in place.  One copy per frame where the reference's loader makes three
+ * (worker decode + stack, collate, pin: dataloaders/q_learning_real.py:55-73 under torch's DataLoader, train_q_network.py:98,114).
+ * No GPU involved. */
+int vdqn_host_gather(void* dst, const void* const* src, int64_t n, int64_t bytes_each, int32_t threads);
+
 /* Input packing: normalise + space-to-depth the 224x224 RGB frames into the conv1 operand
  * [n][115][115][16] (2x2x3 -> 12 channels + 4 zero, 2-pixel zero border top/left, 1 bottom/right), so the
  * 7x7/2 stem is a 4x4/1 implicit GEMM with 128-byte contiguous K rows.

@@ -32,7 +32,7 @@ def _bench(args, **env):
     return json.loads(lines[0])
 
 
-SMALL = ["--ramp-seconds", "0", "--batch", "8", "--steps", "3", "--warmup", "1", "--profile-steps", "1", "--no-cpu-baseline", "--pool", "2"]
+SMALL = ["--ramp-seconds", "0", "--batch", "8", "--steps", "3", "--warmup", "1", "--windows", "1", "--profile-steps", "1", "--no-cpu-baseline", "--pool", "2"]
 
 
 def test_bench_self_launches_two_ranks_without_torchrun():
@@ -53,7 +53,7 @@ def test_bench_single_rank_through_rccl():
     mode the run with the collectives must leave the SAME BITS in the master parameters as the run without them: any
     mis-ordering of side stream -> RCCL -> Adam (a bucket reduced before its unfold finished, Adam before a bucket landed)
     changes them."""
-    det = ["--dtype", "f32", "--deterministic", "--params-digest", "--batch", "4", "--steps", "3", "--warmup", "0", "--ramp-seconds", "0",
+    det = ["--dtype", "f32", "--deterministic", "--params-digest", "--batch", "4", "--steps", "3", "--warmup", "0", "--windows", "1", "--ramp-seconds", "0",
            "--profile-steps", "1", "--no-cpu-baseline", "--pool", "1"]
     a = _bench(["--gpus", "1", "--force-dist"] + det)
     b = _bench(["--gpus", "1"] + det)

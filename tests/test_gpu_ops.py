@@ -682,3 +682,40 @@ def test_stride2_persistent_kernel_with_fused_downsample(case, sib):
         torch.cuda.synchronize()
         assert torch.equal(one_out2, sep2)
         assert relerr(one_out2.float().cpu().permute(0, 3, 1, 2), F.conv2d(x, w2, b2, 2, 0)) < TOL[dtype]
+
+
+BAL_CASES = [  # n, c (ci = co), h, pretend-CUs: column tiles 1 / 2 / 4; ranges of 1 - 6 tiles whose last tile holds 16, <= 16, 17 - 64, > 64 rows
+    (37, 128, 28, 4), (16, 128, 28, 4), (9, 128, 20, 12), (61, 256, 14, 8), (40, 256, 14, 16), (90, 512, 7, 16),
+    (2, 128, 28, 4), (4, 128, 28, 8), (8, 256, 14, 8),   # ranges of 208 rows: the last tile holds 80 (second wave row: one fragment)
+    (21, 512, 7, 16), (8, 128, 12, 4), (29, 128, 6, 4),  # ranges of 144 rows: the last tile holds 16 (first wave row: one fragment, second: none)
+]
+
+
+@pytest.mark.parametrize("case", BAL_CASES)
+def test_nine_tap_window_kernel_balanced_walk(case):
+    """win9u_kernel's balanced walk (round 5, forward; an off-by-default switch — it measured slower than the static walk): the rows of
+    a launch are split EVENLY over the resident workgroups of each column tile, every workgroup walks its range in 128-row tiles
+    (first launch) and a second launch computes every range's partial last tile, in which a wave computes all four, one or none of
+    its 16-row fragments.  With the device pretended to have 4 - 32 CUs small tensors take that walk; the output
+    must be BIT-IDENTICAL to the one-workgroup-per-tile launch of the same kernel (same K order per element) and match torch."""
+    from video_dqn_amd import ops, _lib
+    n, c, h, cus = case
+    dtype = torch.bfloat16
+    x = q(rnd(61, "x", (n, c, h, h)), dtype)
+    w = q(rnd(62, "w", (c, c, 3, 3), -0.05, 0.05), dtype)
+    b = rnd(63, "b", (c,))
+    res = q(rnd(64, "res", (n, c, h, h)), dtype)
+    kw = dict(ho=h, wo=h, co=c, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
+    lib = _lib.load()
+    one = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), **kw)  # the real CU count: at most one round of tiles -> one tile per workgroup
+    torch.cuda.synchronize()
+    lib.vdqn_debug_set_num_cus(cus)
+    lib.vdqn_debug_set_win9_balanced(1)  # (off by default since it measured slower: DESIGN.md section 6d)
+    try:
+        bal = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), **kw)
+        torch.cuda.synchronize()
+    finally:
+        lib.vdqn_debug_set_num_cus(0)
+        lib.vdqn_debug_set_win9_balanced(-1)
+    assert torch.equal(bal, one)
+    assert relerr(one.float().cpu().permute(0, 3, 1, 2), F.relu(F.conv2d(x, w, b, 1, 1) + res)) < TOL[dtype]

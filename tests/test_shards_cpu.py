@@ -49,3 +49,75 @@ def test_shards_equal_jpeg_loader(tmp_path):
             np.testing.assert_array_equal(ta[6], tb[6])
     batch = next(iter(torch.utils.data.DataLoader(ShardDataset(out, inverse_actions=True, previous_images=True), batch_size=4)))
     assert batch[0].shape == (4, 4, 224, 224, 3) and batch[0].dtype == torch.uint8
+
+
+def _synthetic_shards(root, n_frames=24, shard_frames=8, n_samples=37):
+    import os
+    os.makedirs(root, exist_ok=True)
+    rng = np.random.default_rng(5)
+    for s in range(n_frames // shard_frames):
+        mm = np.lib.format.open_memmap(os.path.join(root, f"frames_{s:05d}.npy"), mode="w+", dtype=np.uint8, shape=(shard_frames, 224, 224, 3))
+        mm[:] = rng.integers(0, 256, (shard_frames, 224, 224, 3), dtype=np.uint8)
+        mm.flush()
+    np.savez(os.path.join(root, "index.npz"), before=rng.integers(0, n_frames, (n_samples, 4)), after=rng.integers(0, n_frames, (n_samples, 4)),
+             shard_frames=np.int64(shard_frames), n_frames=np.int64(n_frames), detector_score=rng.random((n_samples, 5)),
+             sparse_reward=rng.integers(0, 2, (n_samples, 5)), steps_to_reward=rng.random((n_samples, 5)),
+             inverse_actions=rng.integers(0, 3, n_samples), has_inverse_actions=np.int64(1), with_previous=np.int64(1))
+
+
+def test_host_frame_stream_equals_resident_store(tmp_path):
+    """The streaming input path (memory-mapped shards -> vdqn_host_gather -> staging buffers -> device) delivers the SAME minibatch
+    sequence as the HBM-resident store for the same seed, bit for bit: frames, labels, order — over more than one epoch (the
+    per-epoch permutation), with and without the PREVIOUS_IMAGES gather, and for both ranks of a two-rank job (rank-strided slices
+    of one permutation).  Runs on the CPU: the gather is host code of libvdqn.so (no GPU call), the device is 'cpu'."""
+    from video_dqn_amd.shards import DeviceFrameStore, HostFrameStream
+    root = str(tmp_path / "shards")
+    _synthetic_shards(root)
+    for kw in (dict(inverse_actions=True), dict(inverse_actions=True, previous_images=True), dict(one_action=True, value_learning=True)):
+        for world in (1, 2):
+            for rank in range(world):
+                store = DeviceFrameStore(root, "cpu", **kw)
+                ref = store.batches(4, 11, rank, world)
+                stream = HostFrameStream(root, "cpu", 4, 11, rank, world, threads=3, depth=2, **kw)
+                got = stream.batches()
+                per_epoch = (37 // world // 4)
+                for _ in range(2 * per_epoch + 3):  # crosses two epoch boundaries
+                    a, b = next(ref), next(got)
+                    assert a[2] == b[2] == 0
+                    for x, y in zip(a[:2] + a[3:], b[:2] + b[3:]):
+                        assert x.dtype == y.dtype and x.shape == y.shape
+                        assert torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0))
+                stream.close()
+
+
+def test_rank_sharded_store_holds_a_quarter_and_draws_the_same_batches(tmp_path):
+    """Four ranks with resident data (round-4 review, 7b): each rank's store holds only the frames its samples of the epoch reference
+    — a quarter of the dataset when samples do not share frames — and yields bit for bit the minibatch sequence of the full
+    per-rank copy (DeviceFrameStore.batches(B, seed, rank, 4)), across an epoch boundary (the subset is re-uploaded per epoch)."""
+    import os
+    from video_dqn_amd.shards import FRAME_BYTES, DeviceFrameStore, RankShardedFrameStore
+    root = str(tmp_path / "shards")
+    n_samples, shard_frames = 32, 16
+    os.makedirs(root)
+    rng = np.random.default_rng(9)
+    n_frames = 2 * n_samples  # every sample has its own before / after frame
+    for s in range(n_frames // shard_frames):
+        mm = np.lib.format.open_memmap(os.path.join(root, f"frames_{s:05d}.npy"), mode="w+", dtype=np.uint8, shape=(shard_frames, 224, 224, 3))
+        mm[:] = rng.integers(0, 256, (shard_frames, 224, 224, 3), dtype=np.uint8)
+        mm.flush()
+    frames = rng.permutation(n_frames).reshape(n_samples, 2)
+    np.savez(os.path.join(root, "index.npz"), before=np.repeat(frames[:, :1], 4, axis=1), after=np.repeat(frames[:, 1:], 4, axis=1),
+             shard_frames=np.int64(shard_frames), n_frames=np.int64(n_frames), detector_score=rng.random((n_samples, 5)),
+             sparse_reward=rng.integers(0, 2, (n_samples, 5)), steps_to_reward=rng.random((n_samples, 5)),
+             inverse_actions=rng.integers(0, 3, n_samples), has_inverse_actions=np.int64(1), with_previous=np.int64(1))
+    world, B = 4, 2
+    full = DeviceFrameStore(root, "cpu", inverse_actions=True)
+    for rank in range(world):
+        ref = full.batches(B, 5, rank, world)
+        st = RankShardedFrameStore(root, "cpu", rank, world, threads=2, chunk_frames=5, inverse_actions=True)
+        got = st.batches(B, 5)
+        for k in range(2 * (n_samples // world // B) + 2):
+            a, b = next(ref), next(got)
+            for x, y in zip(a[:2] + a[3:], b[:2] + b[3:]):
+                assert x.shape == y.shape and torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0))
+            assert st.bytes() == full.bytes() // world == (n_frames // world) * FRAME_BYTES

@@ -8,8 +8,9 @@ job.  Writes one JSON record:
   resident : `python train_q_network.py <cfg>` with BATCH_SIZE 256, decoded-frame shards, DEVICE_RESIDENT_DATA on — tuples/s from the
              wall clock of the steps after a warm-up run of the same command (the process start, model build and shard upload are
              timed separately and reported, not hidden);
-  loader   : the same with DEVICE_RESIDENT_DATA off and NUM_WORKERS workers (the DataLoader path: worker -> shared memory -> pinned
-             memory -> H2D copy on the prefetch stream), for contrast;
+  loader   : the same with DEVICE_RESIDENT_DATA off: the STREAMING path (round 5: memory-mapped shards, native gather into pinned
+             staging buffers, H2D on a prefetch stream — shards.HostFrameStream);
+  dataloader: SHARD_INPUT 'dataloader' with NUM_WORKERS workers (rounds 1-4: worker -> shared memory -> pinned memory -> H2D), for contrast;
   bench    : `python bench.py --steps 100 --warmup 20` (resident 4-minibatch pool).
 The dataset is synthetic (random uint8 frames: nothing is decoded on either path, so the loader figure is an upper bound for
 real JPEG data)."""
@@ -24,12 +25,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def make_cfg(folder, shards, steps, resident, workers, batch):
+def make_cfg(folder, shards, steps, resident, workers, batch, shard_input="stream"):
     os.makedirs(folder, exist_ok=True)
     with open(os.path.join(folder, "config.yml"), "w") as f:
         f.write(f"DATASET: '{shards}'\nPANORAMA: False\nLOSS_CLIP: 'rect'\nARCHITECTURE: 'extra_capacity'\nLEARNING_RATE: 0.0001\nGAMMA: 0.99\n"
                 f"USE_INVERSE_ACTIONS: True\nCHECKPOINT_INTERVAL: 100000000\nNUM_STEPS: {steps}\nSEED: 4\nBATCH_SIZE: {batch}\n"
-                f"NUM_WORKERS: {workers}\nCOMPUTE_DTYPE: 'bf16'\nTARGET_UPDATE_INTERVAL: 1000\nDEVICE_RESIDENT_DATA: '{'on' if resident else 'off'}'\n")
+                f"NUM_WORKERS: {workers}\nCOMPUTE_DTYPE: 'bf16'\nTARGET_UPDATE_INTERVAL: 1000\nDEVICE_RESIDENT_DATA: '{'on' if resident else 'off'}'\n"
+                f"SHARD_INPUT: '{shard_input}'\n")
 
 
 def timed_run(folder):
@@ -78,9 +80,10 @@ def main():
     if not os.path.exists(os.path.join(shards, "index.npz")):
         make_shards(shards, n_frames=args.frames, shard_frames=1024, n_samples=args.samples)
     rec = {"batch": args.batch, "dataset": {"frames": args.frames, "samples": args.samples, "kind": "synthetic uint8 shards"}, "runs": {}}
-    for tag, resident, steps, workers in (("resident", True, args.steps, 0), ("loader", False, args.loader_steps, args.workers)):
+    for tag, resident, steps, workers, shard_input in (("resident", True, args.steps, 0, "stream"), ("loader", False, args.steps, 0, "stream"),
+                                                       ("dataloader", False, args.loader_steps, args.workers, "dataloader")):
         folder = os.path.join(args.work, f"exp_{tag}")
-        make_cfg(folder, shards, steps, resident, workers, args.batch)
+        make_cfg(folder, shards, steps, resident, workers, args.batch, shard_input)
         rc, t0, t1, stamps, tail = timed_run(folder)
         if rc != 0 or len(stamps) < 10:
             rec["runs"][tag] = {"rc": rc, "tail": tail}
@@ -101,8 +104,9 @@ def main():
     if line:
         b = json.loads(line[-1])
         rec["bench"] = {"tuples_per_s": b["value"], "ms_per_step": b["ms_per_step"]}
-        if "resident" in rec["runs"] and rec["runs"]["resident"].get("tuples_per_s"):
-            rec["resident_over_bench"] = round(rec["runs"]["resident"]["tuples_per_s"] / b["value"], 4)
+        for tag in ("resident", "loader"):
+            if tag in rec["runs"] and rec["runs"][tag].get("tuples_per_s"):
+                rec[f"{tag}_over_bench"] = round(rec["runs"][tag]["tuples_per_s"] / b["value"], 4)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(rec, f, indent=1)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", f"libvdqn{'_' + os.environ['VDQN_LIB'] if os.environ.get('VDQN_LIB') else ''}.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -133,6 +133,7 @@ _SIGS = {
     "vdqn_comm_rank": (C.c_int, [c_vp]),
     "vdqn_comm_size": (C.c_int, [c_vp]),
     "vdqn_comm_destroy": (C.c_int, [c_vp]),
+    "vdqn_host_gather": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32]),
 }
 COMM_UID_BYTES = 128
 EXPORTS = tuple(_SIGS)

@@ -11,7 +11,9 @@
 Keys added by this build (all optional, defaults reproduce the reference): BATCH_SIZE (the reference
 hard-codes 16, train_q_network.py:98), NUM_WORKERS (8), COMPUTE_DTYPE ('bf16' | 'f32'), NUM_FRAMES (0 = the
 reference's rule: 4 if PANORAMA or PREVIOUS_IMAGES else 1), SYNTHETIC_DATA (train on generated frames), DEVICE_RESIDENT_DATA ('auto' | 'on' | 'off': keep a decoded-frame shard
-dataset in HBM and gather minibatches on the device), SYNC_BN (ARCHITECTURE='basic' on several GPUs: global BatchNorm
+dataset in HBM and gather minibatches on the device), SHARD_INPUT ('stream' | 'dataloader': how a shard dataset that is NOT
+resident reaches the GPU — memory-mapped shards + native gather into pinned double buffers, or torch's DataLoader),
+HOST_GATHER_THREADS, SYNC_BN (ARCHITECTURE='basic' on several GPUs: global BatchNorm
 statistics, so N ranks equal the reference's single big batch; default True), DETERMINISTIC (run-to-run bit-identical
 updates — the reference's cudnn.deterministic = True, train_q_network.py:88-89 — at a small throughput cost), LOSS_KIND ('l2' = the reference's half
 squared TD error, train_q_network.py:167; 'huber' = smooth-L1, the option archs/HabitatDQNMultiAction.py:25 leaves open),
@@ -133,6 +135,9 @@ def get_cfg_defaults() -> CfgNode:
     c.SYNTHETIC_DATA = False
     c.SYNC_BN = True
     c.DEVICE_RESIDENT_DATA = "auto"
+    c.RANK_SHARDED_DATA = True    # resident data on several GPUs: every rank holds the frames of ITS samples of the epoch, not a full copy
+    c.SHARD_INPUT = "stream"      # decoded-frame shards that are not resident: 'stream' (HostFrameStream) | 'dataloader'
+    c.HOST_GATHER_THREADS = 0     # native threads of the streaming path's frame gather (0 = min(16, cores / 2))
     c.DETERMINISTIC = False
     c.LOSS_KIND = "l2"
     c.PRETRAINED_WEIGHTS = ""

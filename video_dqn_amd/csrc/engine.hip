@@ -29,7 +29,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 10; }
+extern "C" int vdqn_abi_version(void) { return 11; }
 
 namespace {
 

@@ -1517,6 +1517,8 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
   p.in2 = nullptr; p.wt2 = nullptr; p.bias2 = nullptr; p.out2 = nullptr;
   p.co2 = p.ldo2 = p.relu2 = p.ci2 = p.wt2_bytes = 0;
   p.wt_b = nullptr; p.bias_b = nullptr; p.m_split = 0x7fffffff;
+  static const int no_lean = [] { const char* e = getenv("VDQN_LEAN_EPILOGUE"); return (e && e[0] == '0') ? 1 : 0; }();
+  p.no_lean = no_lean;
   // grouped forward, decided per kernel below: `grp(bm)` arms it if the split is a multiple of that kernel's tile height
   auto grp = [&](int bm) {
     if (group_rows <= 0) return true;       // not a grouped call

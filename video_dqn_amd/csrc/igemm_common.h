@@ -46,6 +46,7 @@ struct IgemmParams {
   const void* wt_b;
   const float* bias_b;
   int m_split;
+  int no_lean;  // VDQN_LEAN_EPILOGUE=0 (A/B switch): the window kernels keep igemm_epilogue where the lean one would serve
 };
 
 constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (num_records <= 0x7fffffff)
@@ -201,6 +202,76 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
   }
 }
 
+
+// ---- lean forward epilogue of the 128 x 128 window kernels (round 5): bias + optional residual + optional ReLU -> bf16, whole
+// 16-byte vectors.  igemm_epilogue above serves every kernel and operand combination; in the persistent window kernels it cost
+// ~8 k cycles per tile (tools/stamp_s2.py, profiles/r05b_stamp_s2.txt): sixteen single-dword bias loads, 64-bit address arithmetic,
+// per-element branches of the ragged path, and hundreds of v_readlane reloads of spilled scalars.  Here: buffer loads / stores with
+// 32-bit offsets (a row behind rows_end gets an out-of-range offset: its loads return 0, its stores are dropped), the bias as four
+// 16-byte loads, every load issued before the first is used.  Same arithmetic in the same order as igemm_epilogue's vector path:
+// (acc + bias) + resid, max(., 0), round to bf16 — the same bits.
+// The caller guarantees: bf16, CPL = 16, ncol + 16 <= co, ldo % 8 == 0, M * ldo * 2 < 2^31, bias != nullptr and 16-byte aligned. ----
+struct LeanEpi {
+  __amdgpu_buffer_rsrc_t out, res, bias;
+  int ldo, relu, has_res;
+};
+__device__ __forceinline__ LeanEpi make_lean_epi(void* out, const void* resid, const float* bias, long long rows, int ldo, int co, int relu) {
+  LeanEpi e;
+  const int bytes = (int)(rows * ldo * 2);
+  e.out = __builtin_amdgcn_make_buffer_rsrc(out, 0, bytes, 0x00020000);
+  e.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(resid), 0, resid ? bytes : 0, 0x00020000);
+  e.bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, co * 4, 0x00020000);
+  e.ldo = ldo; e.relu = relu; e.has_res = resid != nullptr;
+  return e;
+}
+template <int WN>
+__device__ __forceinline__ void lean_epilogue_128(const LeanEpi& e, f32x4 (&acc)[4][128 / (16 * WN)], int m0, int n0, int rows_end, int tid) {
+  static_assert(WN == 2, "64 x 64 wave tiles: 16 consecutive channels per lane");
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int ncol = n0 + wc * 64 + g * 16;
+  u32x4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = __builtin_amdgcn_raw_buffer_load_b128(e.bias, ncol * 4 + 16 * q, 0, 0);
+  uint32_t off[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int m = m0 + wr * 64 + f * 16 + i16;
+    off[f] = m < rows_end ? (uint32_t)(m * e.ldo + ncol) * 2u : kOob;
+  }
+  u32x4 rv[4][2];
+  if (e.has_res) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      rv[f][0] = __builtin_amdgcn_raw_buffer_load_b128(e.res, (int)off[f], 0, 0);
+      rv[f][1] = __builtin_amdgcn_raw_buffer_load_b128(e.res, (int)off[f] + 16, 0, 0);
+    }
+  }
+  const float* bv = reinterpret_cast<const float*>(bq);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + bv[j * 4 + r];
+    if (e.has_res) {
+      const bf16raw* pr = reinterpret_cast<const bf16raw*>(rv[f]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] += bf16_to_f32(pr[k]);
+    }
+    if (e.relu) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    bf16raw ov[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ov[k] = f32_to_bf16(v[k]);
+    __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[0], e.out, (int)off[f], 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[1], e.out, (int)off[f] + 16, 0, 0);
+  }
+}
 
 #define VDQN_INTERLEAVE(N)                                  \
   if constexpr (sizeof(T) == 2) {                           \

@@ -103,35 +103,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const i32x4 rs_x = {__builtin_amdgcn_readfirstlane((int)(unsigned)x_ptr), __builtin_amdgcn_readfirstlane((int)((x_ptr >> 32) & 0xffff)),
                       __builtin_amdgcn_readfirstlane(p.x_bytes), 0x00020000};
   constexpr unsigned kOobW = 0x80000000u;
-  int l_row[NL];
-  uint32_t l_goff[NL], l_xoff[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const int q = tid + 256 * i;
-    l_row[i] = q / CPR;
-    const int ch = (q % CPR) ^ wg_swz<T, BT>(l_row[i]);
-    l_goff[i] = (uint32_t)((co0 + ch * E16) * (int)sizeof(T));
-    l_xoff[i] = (uint32_t)((ci0 + ch * E16) * (int)sizeof(T));
-  }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const uint32_t lds_wave = lds_base + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
   const uint32_t ldg_b = (uint32_t)p.ldg * (uint32_t)sizeof(T);
   const uint32_t pix_b = (uint32_t)p.pix_stride * (uint32_t)sizeof(T);
 
-  auto issue_tile = [&](int kb, int buf) {
+  // Staging state of this thread's NL 16-byte slots, carried from K-step to K-step (round 5).  Slot i stages pixel row
+  // pm = kb + l_row[i]; its output position (img, oh, ow) and byte offsets used to be rebuilt from pm at every K-step by two
+  // 64-bit-multiply divisions per slot — with 16 MFMAs per wave and K-step that was 11 vector instructions per MFMA, most of them
+  // quarter-rate multiplies (MFMA-busy 7.6 %, profiles/r04bf_pmc_mfma.json).  K-steps are issued in order, KP pixels apart, so
+  // the position advances by a FIXED (d_img, d_oh, d_ow) with at most one carry out of the column and one out of the row: adds,
+  // compares and selects only; the divisions run once per workgroup.
+  //   s_pm  pixel row (for the range test)         s_h, s_w  input row / column of tap (kr, ks): oh * stride - pad + kr, ...
+  //   s_gb  byte offset of the gy chunk            s_xb      byte offset of the x chunk of that tap (valid or not)
+  int s_pm[NL], s_h[NL], s_w[NL];
+  uint32_t s_gb[NL], s_xb[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int q = tid + 256 * i;
+    const int row = q / CPR;
+    const int ch = (q % CPR) ^ wg_swz<T, BT>(row);
+    const int pm = kbeg + row;
+    const uint32_t img = fastdiv((uint32_t)pm, p.d_howo);
+    const uint32_t rem = (uint32_t)pm - img * p.d_howo.div;
+    const uint32_t oh = fastdiv(rem, p.d_wo);
+    const uint32_t ow = rem - oh * p.d_wo.div;
+    s_pm[i] = pm;
+    s_h[i] = (int)oh * p.stride - p.pad + kr;
+    s_w[i] = (int)ow * p.stride - p.pad + ks;
+    s_gb[i] = (uint32_t)pm * ldg_b + (uint32_t)((co0 + ch * E16) * (int)sizeof(T));
+    s_xb[i] = (uint32_t)(((int)(img * (uint32_t)p.hi) + s_h[i]) * p.wi + s_w[i]) * pix_b + (uint32_t)((ci0 + ch * E16) * (int)sizeof(T));
+  }
+  // advance of KP pixels (scalars; rows and columns in INPUT units, i.e. times the stride)
+  const int adv_img = KP / (p.ho * p.wo), adv_rem = KP - adv_img * (p.ho * p.wo);
+  const int adv_oh = adv_rem / p.wo, adv_ow = adv_rem - adv_oh * p.wo;
+  const int adv_h = adv_oh * p.stride, adv_w = adv_ow * p.stride;
+  const int wrap_w = p.wo * p.stride, wrap_h = p.ho * p.stride;  // what a wrapping column / row loses
+  const int lim_w = wrap_w - p.pad + ks, lim_h = wrap_h - p.pad + kr;  // s_w >= lim_w <=> ow >= wo;  s_h >= lim_h <=> oh >= ho
+  const uint32_t adv_x = (uint32_t)((adv_img * p.hi + adv_h) * p.wi + adv_w) * pix_b;
+  const uint32_t car_ow = (uint32_t)((p.wi - p.wo) * p.stride) * pix_b;               // column wraps: ow -= wo, oh += 1
+  const uint32_t car_oh = (uint32_t)((p.hi - p.ho * p.stride) * p.wi) * pix_b;        // row wraps:    oh -= ho, img += 1
+  const uint32_t adv_g = (uint32_t)KP * ldg_b;
+
+  // stage the NEXT K-step of this workgroup (K-steps are staged in order) into buffer `buf`
+  auto issue_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int pm = kb + l_row[i];
-      const bool ok = pm < kend;
-      const uint32_t img = fastdiv((uint32_t)pm, p.d_howo);
-      const uint32_t rem = (uint32_t)pm - img * p.d_howo.div;
-      const uint32_t oh = fastdiv(rem, p.d_wo);
-      const uint32_t ow = rem - oh * p.d_wo.div;
-      const int h = (int)oh * p.stride - p.pad + kr;
-      const int w = (int)ow * p.stride - p.pad + ks;
-      const bool okx = ok && ((unsigned)h < (unsigned)p.hi) && ((unsigned)w < (unsigned)p.wi);
-      const uint32_t vg = ok ? (uint32_t)pm * ldg_b + l_goff[i] : kOobW;
-      const uint32_t vx = okx ? ((img * (uint32_t)p.hi + (uint32_t)h) * (uint32_t)p.wi + (uint32_t)w) * pix_b + l_xoff[i] : kOobW;
+      const bool ok = s_pm[i] < kend;
+      const bool okx = ok && ((unsigned)s_h[i] < (unsigned)p.hi) && ((unsigned)s_w[i] < (unsigned)p.wi);
+      const uint32_t vg = ok ? s_gb[i] : kOobW;
+      const uint32_t vx = okx ? s_xb[i] : kOobW;
       const uint32_t la = lds_wave + (uint32_t)(buf * (KP * RB) + i * 4096);
       const uint32_t lb = la + (uint32_t)(2 * KP * RB);
       asm volatile(
@@ -140,6 +161,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
           "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds"
           ::"v"(vg), "v"(vx), "s"(la), "s"(lb), "s"(rs_g), "s"(rs_x)
           : "memory");
+      // the slot's position KP pixels on
+      s_pm[i] += KP;
+      s_gb[i] += adv_g;
+      int w = s_w[i] + adv_w, h = s_h[i] + adv_h;
+      uint32_t xb = s_xb[i] + adv_x;
+      const bool c1 = w >= lim_w;
+      w -= c1 ? wrap_w : 0;
+      h += c1 ? p.stride : 0;
+      xb += c1 ? car_ow : 0u;
+      const bool c2 = h >= lim_h;
+      h -= c2 ? wrap_h : 0;
+      xb += c2 ? car_oh : 0u;
+      s_w[i] = w;
+      s_h[i] = h;
+      s_xb[i] = xb;
     }
   };
 
@@ -255,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     _Pragma("unroll") for (int u_ = 0; u_ < NSUB; ++u_) _Pragma("unroll") for (int f_ = 0; f_ < NFR; ++f_)          \
         asm volatile("" : "+v"(fa[CUR][u_][f_][0]), "+v"(fa[CUR][u_][f_][1]), "+v"(fb[CUR][u_][f_][0]), "+v"(fb[CUR][u_][f_][1])); \
     __builtin_amdgcn_s_barrier();                                                                                    \
-    if ((K) + 2 < nk) issue_tile(kbeg + ((K) + 2) * KP, (K) & 1);                                                    \
+    if ((K) + 2 < nk) issue_tile((K) & 1);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     /* unconditional (the last step reads a stale buffer): one block with the MFMAs, reads issued behind them */     \
     WG_LOAD(NXT, ((K) + 1) & 1)                                                                                      \
@@ -267,9 +303,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
-    issue_tile(kbeg, 0);
+    issue_tile(0);
     if (nk > 1) {
-      issue_tile(kbeg + KP, 1);
+      issue_tile(1);
       if constexpr (2 * NL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if constexpr (2 * NL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -286,12 +322,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #undef WG_MFMA
 #undef WG_STEP
   } else {
-    issue_tile(kbeg, 0);
+    issue_tile(0);
     for (int k = 0; k < nk; ++k) {
       const int buf = k & 1;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // tile k landed for every wave; every wave is done with tile k-1
-      if (k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
+      if (k + 1 < nk) issue_tile(buf ^ 1);
       compute(buf);
     }
   }

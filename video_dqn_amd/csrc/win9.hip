@@ -44,10 +44,13 @@ struct Win9Geom {
   static constexpr int Smem = kU_WinBase + 2 * WinStride;
 };
 
-template <int MODE, int BM>
-__global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, const int wrows, const FastDiv d_wo, const FastDiv d_howo, const uint32_t total_tiles, void* stamps) {
+template <int MODE, int BM, int WALK = 0>
+__global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, const int wrows, const FastDiv d_wo, const FastDiv d_howo, const uint32_t total_tiles, void* stamps,
+                                                          const int bal_rows) {
   static_assert(MODE == 0 || MODE == 1, "window kernel: forward or stride-1 data gradient");
   static_assert(BM == 128 || BM == 256, "tile rows");
+  constexpr bool BAL = WALK != 0;  // 1: the full tiles of every workgroup's row range, 2 (a second launch): their partial last tiles
+  static_assert(!BAL || (MODE == 0 && BM == 128), "balanced walk: forward, 128-row tiles");
   using T = bf16raw;  // (VDQN_INTERLEAVE keys on sizeof(T))
   using G = Win9Geom<BM>;
   constexpr int BN = 128, WN = 2;
@@ -62,15 +65,51 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   // Tiles of this workgroup.  The launch has either one workgroup per tile or (VDQN_WIN9_PERSIST) as many as the chip holds at
   // once, each walking several tiles: workgroups of XCD x = blockIdx & 7 own that XCD's contiguous range of logical tiles
   // (xcd_remap's ranges), workgroup j of the XCD takes tiles j, j + nb_x, j + 2 nb_x, ... of the range.
+  //
+  // BALANCED walk (WALK 1 + 2; round 5, forward without column sums): a launch of 3.06 rounds of resident workgroups costs four
+  // tile times with the static walk above (0.77 of its work per round: tools/bench_win9.py).  Here every
+  // workgroup owns ONE column tile and bal_rows consecutive output rows of it (M split evenly over the gridDim.x / tiles_n
+  // workgroups of a column, rounded up to 16).  WALK 1 walks the range's full 128-row tiles.  The rest of the range — fewer than 128
+  // rows — is the PARTIAL tile of WALK 2, a second launch of the same grid: a wave computes only the 16-row fragments that hold rows
+  // of the range (all four, one, or none: three copies of the K loop, chosen per wave) through the same barriers and DMA pieces, and
+  // the epilogue stores nothing behind the range's end.  (One kernel with both parts was built first: the extra loop copies pushed
+  // the allocator into spilling a few per-lane addresses inside the main K loop, and a scratch reload there returns only behind
+  // the LDS-DMA pieces issued before it — vmcnt retires in order — which cost 60 %: profiles/r05c_bench_win9_balanced_one_kernel.txt.)
+  // Workgroups of one XCD take the column tiles of the same row ranges (the activation rows stay in that L2).
   const uint32_t xcd = blockIdx.x & 7u;
   const uint32_t tq = total_tiles >> 3, tr = total_tiles & 7u;
   const uint32_t x_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;  // first logical tile of this XCD
   const uint32_t x_count = tq + (xcd < tr ? 1u : 0u);
   const uint32_t x_blocks = (gridDim.x >> 3) + (xcd < (gridDim.x & 7u) ? 1u : 0u);       // workgroups on this XCD
   uint32_t lt = blockIdx.x >> 3;                                                          // index inside the XCD's range
-  if (lt >= x_count) return;
-  int tile_n = (int)((x_first + lt) % (uint32_t)p.tiles_n), tile_m = (int)((x_first + lt) / (uint32_t)p.tiles_n);
-  int n0 = tile_n * BN, m0 = tile_m * BM;
+  int tile_n, tile_m, n0, m0;
+  int m_end = p.M;  // rows behind it are not this workgroup's (balanced walk: the end of its row range)
+  if constexpr (BAL) {
+    const uint32_t per_xcd = gridDim.x >> 3;                      // (the launcher makes the grid a multiple of 8 tiles_n)
+    const uint32_t j = blockIdx.x >> 3;
+    tile_n = (int)(j % (uint32_t)p.tiles_n);
+    const uint32_t k = xcd * (per_xcd / (uint32_t)p.tiles_n) + j / (uint32_t)p.tiles_n;  // row range of this workgroup
+    const long long mb = (long long)k * bal_rows;
+    if (mb >= p.M) return;
+    m0 = (int)mb;
+    m_end = (int)(mb + bal_rows < p.M ? mb + bal_rows : p.M);
+    const int full = (m_end - m0) / BM * BM;  // rows of the range in full tiles
+    if constexpr (WALK == 1) {
+      m_end = m0 + full;
+      if (full == 0) return;
+    } else {
+      m0 += full;
+      if (m0 >= m_end) return;
+    }
+    tile_m = m0 / BM;  // (column sums are kept off this walk; the grouped forward too)
+    n0 = tile_n * BN;
+  } else {
+    if (lt >= x_count) return;
+    tile_n = (int)((x_first + lt) % (uint32_t)p.tiles_n);
+    tile_m = (int)((x_first + lt) / (uint32_t)p.tiles_n);
+    n0 = tile_n * BN;
+    m0 = tile_m * BM;
+  }
   const int W = p.wo, H = p.ho, rows_total = p.M;
   const int lrow = tid >> 3;
   const int lchunk_a = (tid & 7) ^ (lrow & 7);
@@ -88,7 +127,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   const unsigned long long bb_ptr = (unsigned long long)(MODE == 0 && p.wt_b ? p.wt_b : p.wt);
   const i32x4 rs_b1 = {__builtin_amdgcn_readfirstlane((int)(unsigned)bb_ptr), __builtin_amdgcn_readfirstlane((int)((bb_ptr >> 32) & 0xffff)),
                        __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
-  const int m_split = MODE == 0 ? p.m_split : 0x7fffffff;
+  const int m_split = (MODE == 0 && !BAL) ? p.m_split : 0x7fffffff;
   i32x4 rs_b = m0 >= m_split ? rs_b1 : rs_b0;
 
   // ---- window rows staged by this thread: j = lrow + RPP i; rows past BM + 2 W + 2 (and pixels outside the tensor) are zero.
@@ -166,6 +205,11 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     }                                                                                                               \
   }
 
+  // forward tiles with bias (+ residual, ReLU) and nothing else take the lean epilogue (igemm_common.h); the grouped forward, f32
+  // copies, ragged rows and every data-gradient operand combination keep igemm_epilogue
+  const bool lean = MODE == 0 && !p.no_lean && p.vec_ok && p.out && !p.out_f32 && !p.colsum_part && !p.mask && p.bias && !p.wt_b &&
+                    (((uintptr_t)p.bias) & 15) == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
+  const LeanEpi le = make_lean_epi(p.out, p.resid, p.bias, (BAL || lean) ? p.M : 0, p.ldo, p.co, p.relu);
   f32x4 acc[4][NF];
   const int wr = wave / WN, wc = wave % WN;
   const int i16 = lane & 15, g = lane >> 4;
@@ -219,13 +263,13 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   u32x4 fa[2][2][4], fb[2][2][NF];  // [register set][K half][fragment]
 
   // fragments of the K-step with tap TAP_ in window buffer WBUF_ / weight buffer BBUF_ -> register set SET
-#define VDQN_LOAD_FRAGS(SET, TAP_, WBUF_, BBUF_)                                                                         \
+#define VDQN_LOAD_FRAGS_N(SET, TAP_, WBUF_, BBUF_, FCNT_)                                                                \
   {                                                                                                                      \
     constexpr int kr_ = (TAP_) / 3, ks_ = (TAP_) % 3;                                                                    \
     constexpr int ky_ = MODE == 0 ? kr_ : 2 - kr_, kx_ = MODE == 0 ? ks_ : 2 - ks_;                                      \
     constexpr uint32_t tb_ = (ky_ == 0 ? 1u : 0u) | (ky_ == 2 ? 2u : 0u) | (kx_ == 0 ? 4u : 0u) | (kx_ == 2 ? 8u : 0u);   \
     const unsigned char* wb_ = smem + kU_WinBase + (WBUF_)*kU_WinStride;                                                 \
-    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                                                   \
+    _Pragma("unroll") for (int f_ = 0; f_ < (FCNT_); ++f_) {                                                             \
       uint32_t a0_ = ab[TAP_];                                                                                           \
       if constexpr (tb_ != 0u) { /* an edge lane's tap leaves the image: read the zero row */                            \
         const bool z_ = (edge16 & (tb_ << (4 * f_))) != 0u;                                                              \
@@ -241,8 +285,10 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
       fb[SET][1][j_] = *reinterpret_cast<const u32x4*>(bt_ + j_ * 4 * 128 + bb1);                                        \
     }                                                                                                                    \
   }
-#define VDQN_MFMA_ALL(SET)                                                                                               \
-  _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_)                     \
+#define VDQN_LOAD_FRAGS(SET, TAP_, WBUF_, BBUF_) VDQN_LOAD_FRAGS_N(SET, TAP_, WBUF_, BBUF_, 4)
+#define VDQN_MFMA_ALL(SET) VDQN_MFMA_N(SET, 4)
+#define VDQN_MFMA_N(SET, FCNT_)                                                                                          \
+  _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int f_ = 0; f_ < (FCNT_); ++f_)               \
       _Pragma("unroll") for (int j_ = 0; j_ < NF; ++j_) {                                                                \
     acc[f_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[SET][h_][j_]),                   \
                                                           __builtin_bit_cast(bf16x8, fa[SET][h_][f_]), acc[f_][j_], 0, 0, 0); \
@@ -264,7 +310,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   // K-step U (0..17) of the iteration over chunks 2 it, 2 it + 1: tap U % 9 of chunk 2 it + U / 9.  Its fragments are in register
   // set U & 1 (read one step ago); it issues the staging of step U + 2 (weight buffer U & 1, just released; at tap 0 also that
   // chunk's window) and reads the fragments of step U + 1 underneath its own MFMAs.
-#define VDQN_USTEP(U)                                                                                                    \
+#define VDQN_USTEP(U, FCNT_)                                                                                             \
   {                                                                                                                      \
     constexpr int cur_ = (U)&1, nxt_ = cur_ ^ 1;                                                                         \
     constexpr int ti_ = ((U) + 2) % 9, ci_ = ((U) + 2) / 9; /* tap and chunk (relative to 2 it) of the step staged now */  \
@@ -291,9 +337,15 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     }                                                                                                                    \
     VDQN_ST(st_issue)                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
-    VDQN_LOAD_FRAGS(nxt_, tl_, cl_ & 1, nxt_) /* unconditional: the step behind the last one re-reads buffers that still exist */ \
-    VDQN_MFMA_ALL(cur_)                                                                                                  \
-    VDQN_INTERLEAVE(8 + 2 * NF)                                                                                          \
+    if constexpr ((FCNT_) == 4) {                                                                                        \
+      VDQN_LOAD_FRAGS(nxt_, tl_, cl_ & 1, nxt_) /* unconditional: the step behind the last one re-reads buffers that still exist */ \
+      VDQN_MFMA_ALL(cur_)                                                                                                \
+      VDQN_INTERLEAVE(8 + 2 * NF)                                                                                        \
+    } else if constexpr ((FCNT_) == 1) { /* partial tile of a balanced walk, a wave with at most 16 rows of the range: one activation fragment, 8 MFMAs */ \
+      VDQN_LOAD_FRAGS_N(nxt_, tl_, cl_ & 1, nxt_, 1)                                                                     \
+      VDQN_MFMA_N(cur_, 1)                                                                                               \
+      VDQN_INTERLEAVE(8)                                                                                                 \
+    } /* FCNT_ 0: a wave without rows of the range only takes part in the staging and the barriers */                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
 
@@ -308,51 +360,95 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   unsigned long long st_loop_end = 0;
 #endif
   for (;;) {  // tiles of this workgroup
+    if constexpr (WALK == 2) break;  // (the partial tile: behind the loop)
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     VDQN_LOAD_FRAGS(0, 0, 0, 0)  // the fragments of step 0
     // the next tile of this workgroup (if any): where its first window and weight tiles come from
+    // (balanced walk: the next 128 rows of the workgroup's range, same column tile, same weights)
     const uint32_t lt_nx = lt + x_blocks;
-    const bool has_nx = lt_nx < x_count;
-    const int tn_nx = has_nx ? (int)((x_first + lt_nx) % (uint32_t)p.tiles_n) : tile_n;
-    const int tm_nx = has_nx ? (int)((x_first + lt_nx) / (uint32_t)p.tiles_n) : tile_m;
-    const int q0_t = tm_nx * BM - W - 1 + lrow;
-    const uint32_t b_t = (uint32_t)(tn_nx * BN + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
-    const i32x4 rs_t = tm_nx * BM >= m_split ? rs_b1 : rs_b0;  // the next tile's weight set
-#pragma clang loop unroll(disable)
-    for (int it = 0; it < n_it; ++it) {
-      const int cc2 = 2 * it;            // first chunk of this iteration
-      const bool last_it = has_nx && it == n_it - 1;  // (without a next tile the steps behind the end stage this tile's chunk 2 it + 2: nobody reads it)
-      const int so_nx = last_it ? 0 : (cc2 + 2) * 128;
-      const int q_nx = last_it ? q0_t : q0;
-      const uint32_t b_nx = last_it ? b_t : b_off0;
-      const i32x4 rs_bn = last_it ? rs_t : rs_b;
-      VDQN_USTEP(0) VDQN_USTEP(1) VDQN_USTEP(2) VDQN_USTEP(3) VDQN_USTEP(4) VDQN_USTEP(5) VDQN_USTEP(6) VDQN_USTEP(7) VDQN_USTEP(8)
-      VDQN_USTEP(9) VDQN_USTEP(10) VDQN_USTEP(11) VDQN_USTEP(12) VDQN_USTEP(13) VDQN_USTEP(14) VDQN_USTEP(15) VDQN_USTEP(16) VDQN_USTEP(17)
-    }
+    const bool has_nx = BAL ? m0 + BM < m_end : lt_nx < x_count;
+    const int tn_nx = (BAL || !has_nx) ? tile_n : (int)((x_first + lt_nx) % (uint32_t)p.tiles_n);
+    const int tm_nx = (BAL || !has_nx) ? tile_m : (int)((x_first + lt_nx) / (uint32_t)p.tiles_n);
+    const int m0_nx = BAL ? (has_nx ? m0 + BM : m0) : tm_nx * BM;
+    const int q0_t = BAL ? 0 : m0_nx - W - 1 + lrow;
+    const uint32_t b_t = BAL ? b_off0 : (uint32_t)(tn_nx * BN + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
+    const i32x4 rs_t = m0_nx >= m_split ? rs_b1 : rs_b0;  // the next tile's weight set
+#define VDQN_ULOOP(FCNT_, NEXT_)                                                                                          \
+  _Pragma("clang loop unroll(disable)") for (int it = 0; it < n_it; ++it) {                                              \
+    const int cc2 = 2 * it; /* first chunk of this iteration */                                                          \
+    /* (without a next tile the steps behind the end stage this tile's chunk 2 it + 2: nobody reads it) */               \
+    const bool last_it = (NEXT_) && has_nx && it == n_it - 1;                                                            \
+    const int so_nx = last_it ? 0 : (cc2 + 2) * 128;                                                                     \
+    const int q_nx = BAL ? q0 + (last_it ? BM : 0) : (last_it ? q0_t : q0); /* (balanced walk: the next 128 rows) */        \
+    const uint32_t b_nx = last_it ? b_t : b_off0;                                                                        \
+    const i32x4 rs_bn = last_it ? rs_t : rs_b;                                                                           \
+    VDQN_USTEP(0, FCNT_) VDQN_USTEP(1, FCNT_) VDQN_USTEP(2, FCNT_) VDQN_USTEP(3, FCNT_) VDQN_USTEP(4, FCNT_) VDQN_USTEP(5, FCNT_)       \
+    VDQN_USTEP(6, FCNT_) VDQN_USTEP(7, FCNT_) VDQN_USTEP(8, FCNT_) VDQN_USTEP(9, FCNT_) VDQN_USTEP(10, FCNT_) VDQN_USTEP(11, FCNT_)     \
+    VDQN_USTEP(12, FCNT_) VDQN_USTEP(13, FCNT_) VDQN_USTEP(14, FCNT_) VDQN_USTEP(15, FCNT_) VDQN_USTEP(16, FCNT_) VDQN_USTEP(17, FCNT_) \
+  }
+    VDQN_ULOOP(4, true)
     VDQN_ST(st_comp)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two tiles staged behind the last step have landed (the next tile's
     __builtin_amdgcn_s_barrier();                     // K-steps 0 and 1: weight buffers 0, 1 and window buffer 0 stay untouched)
 #ifdef VDQN_STAMP
     st_loop_end = __builtin_amdgcn_s_memtime();
 #endif
-    // the epilogue's scratch (column sums) is window buffer 1: its last reader was step 16
-    igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem + kU_WinBase + kU_WinStride, m0, n0, tile_m, rows_total, p.howo, W, 0, 0,
-                                        m0 >= m_split ? p.bias_b : p.bias);
-    if (!has_nx) break;
+    // the epilogue's scratch (column sums) is window buffer 1: its last reader was step 16.  (m_end: rows behind the workgroup's
+    // range — or behind M — are not stored)
+    if constexpr (BAL) {  // (the launcher takes the balanced walk only for calls the lean epilogue serves)
+      lean_epilogue_128<WN>(le, acc, m0, n0, m_end, tid);
+    } else {
+      if (MODE == 0 && lean) lean_epilogue_128<WN>(le, acc, m0, n0, m_end, tid);
+      else igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem + kU_WinBase + kU_WinStride, m0, n0, tile_m, m_end, p.howo, W, 0, 0,
+                                               m0 >= m_split ? p.bias_b : p.bias);
+    }
+    if (!has_nx) {
+      m0 = m_end;  // (balanced walk: nothing is left for the section behind the loop)
+      break;
+    }
     lt = lt_nx;
-    tile_n = tn_nx; tile_m = tm_nx;
-    n0 = tile_n * BN; m0 = tile_m * BM;
-    q0 = q0_t;
+    tile_n = tn_nx; tile_m = BAL ? m0_nx / BM : tm_nx;
+    n0 = tile_n * BN; m0 = m0_nx;
+    q0 = BAL ? q0 + BM : q0_t;
     b_off0 = b_t;
     rs_b = rs_t;
     edge16 = edge_bits(m0);
   }
+  if constexpr (WALK == 2) {
+    // The partial last tile of a row range (m_end - m0 < 128 rows; its first two K-steps were staged by the prologue).  A wave
+    // computes all four of its 16-row fragments, ONE, or none — whichever hold rows of the range — in its own copy of the K loop;
+    // every copy runs the same barriers and DMA pieces.  Nothing follows, so nothing is staged ahead.
+    const int rows_wave = m_end - m0 - (wave_u / WN) * 64;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool has_nx = false;
+    const int q0_t = q0;
+    const uint32_t b_t = b_off0;
+    const i32x4 rs_t = rs_b;
+    if (rows_wave > 16) {
+      VDQN_LOAD_FRAGS(0, 0, 0, 0)
+      VDQN_ULOOP(4, false)
+    } else if (rows_wave > 0) {
+      VDQN_LOAD_FRAGS_N(0, 0, 0, 0, 1)
+      VDQN_ULOOP(1, false)
+    } else {
+      VDQN_ULOOP(0, false)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    lean_epilogue_128<WN>(le, acc, m0, n0, m_end, tid);
+  }
+#undef VDQN_ULOOP
 #undef VDQN_USTEP
 #undef VDQN_LOAD_FRAGS
 #undef VDQN_MFMA_ALL
+#undef VDQN_MFMA_N
+#undef VDQN_LOAD_FRAGS_N
 #undef VDQN_ISSUE_AW
 #undef VDQN_ISSUE_B
 #undef VDQN_DMA4
@@ -374,6 +470,9 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
 extern void* g_stamp_buffer;
 #endif
 
+static int g_win9_balanced_override = -1;
+extern "C" void vdqn_debug_set_win9_balanced(int v) { g_win9_balanced_override = v; }  // test hook (not part of include/vdqn.h)
+
 // entry used by vdqn_conv2d (igemm.hip): returns VDQN_OK or an error code
 template <int MODE, int BM>
 static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps) {
@@ -385,11 +484,42 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
   // (default: for launches of more than two rounds of resident workgroups — layer2 +5-7 %, layer3 at 512 frames +4 %; a launch of
   // 1.5 rounds loses 2-3 % to the static tile assignment; 2: always; profiles/r02o_win9u_persistent.txt)
   static const int persist = [] { const char* e = getenv("VDQN_WIN9_PERSIST"); return e ? atoi(e) : 1; }();
+  // VDQN_WIN9_BALANCED (round 5; default 0 = off): forward launches of more than one round of resident workgroups, without column
+  // sums and not grouped, split their rows EVENLY over the resident workgroups of each column tile (the kernel's balanced walk:
+  // full tiles in one launch, every range's partial last tile in a second) instead of dealing whole tiles.  Built against the
+  // partial rounds of the static walk (3.06 rounds cost 4 tile times) and MEASURED SLOWER: a partial tile with 1/16 of the MFMA work
+  // still takes 1.3-1.45 full tile times — the K-step is bound by its staging (18.7 KB of LDS-DMA per workgroup and step, one step of
+  // lead), not by the matrix work: layer3 at 512 frames 120.0 vs 107.6 us, layer2 160.6 vs 148.5 (profiles/r05d_bench_win9_*.txt,
+  // DESIGN.md section 6d).  1: on for launches of more than one round; 2: also smaller launches.  vdqn_debug_set_win9_balanced
+  // overrides the environment (tests).
+  static const int balanced_env = [] { const char* e = getenv("VDQN_WIN9_BALANCED"); return e ? atoi(e) : 0; }();
+  const int balanced = g_win9_balanced_override >= 0 ? g_win9_balanced_override : balanced_env;
   const unsigned resident = (unsigned)((BM == 128 ? 2 : 1) * vdqn_num_cus());
-  const unsigned grid = (BM == 128 && ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident))) ? resident : tiles;  // (256-row tiles: one workgroup per tile)
+  int bal_rows = 0;
+  unsigned grid = (BM == 128 && ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident))) ? resident : tiles;  // (256-row tiles: one workgroup per tile)
+  const bool lean_ok = !p.no_lean && p.vec_ok && p.out && !p.out_f32 && !p.mask && p.bias && (((uintptr_t)p.bias) & 15) == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
+  if (BM == 128 && MODE == 0 && balanced && lean_ok && !p.colsum_part && !p.wt_b && (tiles > resident || balanced >= 2) && p.tiles_n > 0 &&
+      resident % (8u * (unsigned)p.tiles_n) == 0 && resident / (unsigned)p.tiles_n >= 8u) {
+    const unsigned per_col = resident / (unsigned)p.tiles_n;       // workgroups (= row ranges) per column tile
+    bal_rows = (int)((((long long)p.M + per_col - 1) / per_col + 15) / 16 * 16);
+    grid = resident;
+  }
+  if constexpr (BM == 128 && MODE == 0) {
+    if (bal_rows > 0) {
+      vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM, 1>), (size_t)G::Smem);
+      vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM, 2>), (size_t)G::Smem);
+      if (bal_rows >= BM)
+        hipLaunchKernelGGL((win9u_kernel<MODE, BM, 1>), dim3(grid), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
+                           make_fastdiv((uint32_t)p.howo), tiles, stamps, bal_rows);
+      if (bal_rows % BM != 0 || p.M % bal_rows != 0)  // some range ends with a partial tile
+        hipLaunchKernelGGL((win9u_kernel<MODE, BM, 2>), dim3(grid), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
+                           make_fastdiv((uint32_t)p.howo), tiles, stamps, bal_rows);
+      return;
+    }
+  }
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM>), (size_t)G::Smem);
   hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
-                     make_fastdiv((uint32_t)p.howo), tiles, stamps);
+                     make_fastdiv((uint32_t)p.howo), tiles, stamps, 0);
 }
 
 int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {

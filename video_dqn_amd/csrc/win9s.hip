@@ -33,6 +33,8 @@ constexpr int kS_WinStride = kS_WinRows * 128;
 constexpr int kS_WinBase = 2 * kS_WtTile;   // LDS: [2 weight tiles][2 windows]
 constexpr int kS_Smem = kS_WinBase + 2 * kS_WinStride;
 constexpr int kS_WPass = kS_WinRows / 32;   // 5 staging passes per window
+constexpr int kSP_BiasCols = 512;            // win9sp_kernel: the layer's biases (3x3 and sibling) live in LDS behind the windows
+constexpr int kSP_Smem = kS_Smem + 2 * kSP_BiasCols * 4;
 
 // step s (0..8) of a chunk: tap index kr * 3 + ks, plane (a, b), shift class (dy, dx), window buffer
 struct S2Step { int tap, a, b, dy, dx, wbuf; };
@@ -520,6 +522,44 @@ __global__ __launch_bounds__(256, 2) void win9sp_kernel(const IgemmParams p, con
     VDQN_P_BODY(cur_, VDQN_P_LOAD_FRAGS(nxt_, CPK == 1 ? 1 : (((D) + 1) & 1), 0, 0, nxt_))                         \
   }
 
+  // ---- lean epilogue (round 5).  The shared igemm_epilogue cost 8.1 k cycles per call here (stamps, profiles/r05b_stamp_s2.txt:
+  // 38 % of a layer2.0 tile in two calls): sixteen bias loads from global memory with their latency exposed, 64-bit address
+  // arithmetic, generic branches.  This kernel's calls have bias + ReLU only and whole 16-byte vectors, so: the layer's biases are
+  // staged in LDS once per workgroup, the stores are buffer stores with 32-bit offsets (rows behind M get an out-of-range offset and
+  // are dropped).  Same arithmetic, same bits. ----
+  float* sBias = reinterpret_cast<float*>(smem + kS_Smem);  // [2][kSP_BiasCols]: 3x3, sibling
+  for (int i = tid; i < p.co && i < kSP_BiasCols; i += 256) {
+    sBias[i] = p.bias ? p.bias[i] : 0.f;
+    if constexpr (SIB) sBias[kSP_BiasCols + i] = p.bias2 ? p.bias2[i] : 0.f;
+  }
+  const bool lean = !p.no_lean && p.vec_ok && !p.resid && !p.out_f32 && !p.colsum_part && !p.mask && p.out && p.co <= kSP_BiasCols &&
+                    (long long)p.M * p.ldo * 2 < 0x7fffffffLL && (!SIB || (long long)p.M * p.ldo2 * 2 < 0x7fffffffLL);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, lean ? (int)((long long)p.M * p.ldo * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out2 =
+      __builtin_amdgcn_make_buffer_rsrc(SIB ? p.out2 : p.out, 0, (lean && SIB) ? (int)((long long)p.M * p.ldo2 * 2) : 0, 0x00020000);
+  auto lean_epilogue = [&](const __amdgpu_buffer_rsrc_t rsrc, const int ldo, const int relu, const float* sb) {
+    const int ncol = n0 + wc * (BN / WN) + g * CPL;
+    float bv[CPL];
+#pragma unroll
+    for (int e4 = 0; e4 < CPL / 4; ++e4) *reinterpret_cast<float4*>(bv + 4 * e4) = *reinterpret_cast<const float4*>(sb + ncol + 4 * e4);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int m = m0 + wr * 64 + f * 16 + i16;
+      const uint32_t off = m < rows_total ? (uint32_t)(m * ldo + ncol) * 2u : kOob;
+      bf16raw ov[CPL];
+#pragma unroll
+      for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[f][j][r] + bv[j * 4 + r];
+          if (relu) v = fmaxf(v, 0.f);
+          ov[j * 4 + r] = f32_to_bf16(v);
+        }
+      __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[0], rsrc, (int)off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[1], rsrc, (int)off + 16, 0, 0);
+    }
+  };
+
   IgemmParams q = p;  // the sibling's epilogue: its bias, output and ReLU flag; no residual, mask, f32 copy or column sums
   if constexpr (SIB) {
     q.bias = p.bias2; q.out = p.out2; q.relu = p.relu2; q.co = p.co2; q.ldo = p.ldo2;
@@ -568,7 +608,8 @@ __global__ __launch_bounds__(256, 2) void win9sp_kernel(const IgemmParams p, con
     __builtin_amdgcn_s_barrier();
     VDQN_PST(st_bnd)
     // (the epilogue's LDS scratch serves column sums only, which the dispatch keeps off this kernel)
-    igemm_epilogue<T, BM, BN, 0, WN>(p, acc, smem + kS_WinBase, m0, n0, tile_m, rows_total, p.howo, Wo, 0, 0, p.bias);
+    if (lean) lean_epilogue(r_out, p.ldo, p.relu, sBias);
+    else igemm_epilogue<T, BM, BN, 0, WN>(p, acc, smem + kS_WinBase, m0, n0, tile_m, rows_total, p.howo, Wo, 0, 0, p.bias);
     VDQN_PST(st_epi1)
     if constexpr (SIB) {
 #pragma unroll
@@ -584,7 +625,8 @@ __global__ __launch_bounds__(256, 2) void win9sp_kernel(const IgemmParams p, con
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       VDQN_PST(st_bnd)
-      igemm_epilogue<T, BM, BN, 0, WN>(q, acc, smem + kS_WinBase, m0, n0, tile_m, rows_total, p.howo, Wo, 0, 0, q.bias);
+      if (lean) lean_epilogue(r_out2, p.ldo2, p.relu2, sBias + kSP_BiasCols);
+      else igemm_epilogue<T, BM, BN, 0, WN>(q, acc, smem + kS_WinBase, m0, n0, tile_m, rows_total, p.howo, Wo, 0, 0, q.bias);
       VDQN_PST(st_epi2)
     }
     if (!has_nx) break;
@@ -637,12 +679,12 @@ static void launch_win9sp(const IgemmParams& p, unsigned tiles, int tiles_n, hip
   static const int persist = [] { const char* e = getenv("VDQN_S2WIN_PERSIST"); return e ? atoi(e) : 1; }();
   const unsigned resident = 2u * (unsigned)vdqn_num_cus();
   const unsigned grid = ((persist == 1 && tiles > resident) || (persist >= 2 && tiles > 2 * resident)) ? resident : tiles;
-  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9sp_kernel<CPK, SIB>), (size_t)kS_Smem);
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9sp_kernel<CPK, SIB>), (size_t)kSP_Smem);
   void* stamps = nullptr;
 #ifdef VDQN_STAMP
   stamps = g_stamp_buffer;
 #endif
-  hipLaunchKernelGGL((win9sp_kernel<CPK, SIB>), dim3(grid), dim3(256), kS_Smem, stream, p, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), tiles, tiles_n,
+  hipLaunchKernelGGL((win9sp_kernel<CPK, SIB>), dim3(grid), dim3(256), kSP_Smem, stream, p, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), tiles, tiles_n,
                      stamps);
 }
 

@@ -274,6 +274,215 @@ class DeviceFrameStore:
             print("reset iterator")
 
 
+class RankShardedFrameStore:
+    """HBM-resident frames under data parallelism WITHOUT a full copy per rank (round-4 review: eight ranks each holding the whole
+    dataset).  Rank r draws the samples perm_e[r::world] of epoch e (the loader's DistributedSampler split, train_q_network.py:98,114 on
+    one GPU); at the start of every epoch it uploads exactly the frames those samples reference — gathered from the memory-mapped
+    shards by ``vdqn_host_gather`` into a pinned staging buffer, chunk by chunk — and gathers its minibatches from that resident
+    subset.  The minibatch sequence is bit for bit that of ``DeviceFrameStore.batches(B, seed, rank, world)``.  Memory per rank: the
+    distinct frames referenced by 1/world of the samples — 1/world of the dataset when samples do not share frames, more when
+    they do (with PREVIOUS_IMAGES every sample references eight frames of its episode: a random quarter of the samples touches most
+    frames; the trainer then falls back to the streaming path if the subset does not fit)."""
+
+    def __init__(self, location, device, rank: int, world_size: int, threads: int = 0, chunk_frames: int = 1024, **flags):
+        from . import _lib
+        ds = ShardDataset(location, **flags)
+        self.flags = ds
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.rank, self.world = int(rank), int(world_size)
+        self.nf = 4 if ds.previous_images else 1
+        self.n = len(ds)
+        self._maps = [np.load(p, mmap_mode="r") for p in ds._paths]
+        self._base = np.array([m.ctypes.data for m in self._maps], dtype=np.uint64)
+        self._shard_frames = ds.shard_frames
+        self._before = np.ascontiguousarray(ds.before[:, :self.nf].astype(np.int64))
+        self._after = np.ascontiguousarray(ds.after[:, :self.nf].astype(np.int64))
+        lab = DeviceFrameStore._labels(ds, np.arange(self.n))
+        self.act, self.rew, self.term, self.gt, self.valid = (x.to(self.device) for x in lab)
+        self.threads = int(threads) if threads else max(1, min(16, (os.cpu_count() or 2) // 2))
+        self._lib = _lib.load()
+        self._chunk = int(chunk_frames)
+        stage = torch.empty((self._chunk, 224, 224, 3), dtype=torch.uint8)
+        self._stage = stage.pin_memory() if self.cuda else stage
+        self.frames = torch.empty((0, 224, 224, 3), dtype=torch.uint8, device=self.device)
+        self.resident_frames = 0
+        self.total_frames = sum(m.shape[0] for m in self._maps)
+
+    def __len__(self):
+        return self.n
+
+    def bytes(self):
+        """Bytes of frames resident on this rank for the current epoch."""
+        return self.resident_frames * FRAME_BYTES
+
+    def _load_epoch(self, idx: np.ndarray):
+        fb, fa = self._before[idx], self._after[idx]
+        need = np.unique(np.concatenate([fb.reshape(-1), fa.reshape(-1)]))
+        if self.frames.shape[0] < need.shape[0]:
+            self.frames = torch.empty((need.shape[0], 224, 224, 3), dtype=torch.uint8, device=self.device)
+        addr = self._base[need // self._shard_frames] + (need % self._shard_frames).astype(np.uint64) * np.uint64(FRAME_BYTES)
+        for lo in range(0, need.shape[0], self._chunk):
+            a = np.ascontiguousarray(addr[lo:lo + self._chunk])
+            if self._lib.vdqn_host_gather(self._stage.data_ptr(), a.ctypes.data, a.shape[0], FRAME_BYTES, self.threads) != 0:
+                raise RuntimeError("vdqn_host_gather failed")
+            self.frames[lo:lo + a.shape[0]].copy_(self._stage[:a.shape[0]], non_blocking=False)  # (blocking: the staging buffer is reused)
+        self.resident_frames = int(need.shape[0])
+        self._b_local = torch.from_numpy(np.searchsorted(need, fb)).to(self.device)  # [per_rank, nf] positions inside the resident subset
+        self._a_local = torch.from_numpy(np.searchsorted(need, fa)).to(self.device)
+        self._idx_dev = torch.from_numpy(idx).to(self.device)
+
+    def batches(self, batch_size: int, seed: int):
+        """Endless stream of device batches — DeviceFrameStore.batches(batch_size, seed, rank, world)'s sequence."""
+        per_rank = (self.n // self.world // batch_size) * batch_size
+        if per_rank == 0:
+            raise ValueError(f"dataset of {self.n} samples is smaller than one global batch ({batch_size} x {self.world})")
+        epoch = 0
+        while True:
+            g = torch.Generator(device="cpu")
+            g.manual_seed(seed + epoch)
+            idx = torch.randperm(self.n, generator=g)[self.rank::self.world][:per_rank].numpy()
+            self._load_epoch(idx)
+            for lo in range(0, per_rank, batch_size):
+                sl = slice(lo, lo + batch_size)
+                b = self.frames.index_select(0, self._b_local[sl].reshape(-1))
+                a = self.frames.index_select(0, self._a_local[sl].reshape(-1))
+                if self.nf > 1:
+                    b = b.view(batch_size, self.nf, 224, 224, 3)
+                    a = a.view(batch_size, self.nf, 224, 224, 3)
+                i = self._idx_dev[sl]
+                yield (b, a, 0, self.act.index_select(0, i), self.rew.index_select(0, i), self.term.index_select(0, i),
+                       self.valid.index_select(0, i), self.gt.index_select(0, i))
+            epoch += 1
+            print("reset iterator")
+
+
+class HostFrameStream:
+    """Streaming input path for decoded-frame shards that do NOT fit in HBM ("per-rank mmap + pinned
+    double-buffer H2D"; replaces dataloaders/q_learning_real.py:55-73 under torch's DataLoader, train_q_network.py:98,114).
+
+    No worker processes and no shared-memory hop: the shards stay memory-mapped in THIS process; a producer thread computes each
+    minibatch's frame addresses (the PREVIOUS_IMAGES gather is index arithmetic on the shard index), has ``vdqn_host_gather``
+    (include/vdqn.h; a few native threads, GIL released) copy the frames ONCE from the page cache into one of ``depth`` pinned
+    staging buffers, and queues the host-to-device copy on a prefetch stream; the training loop finds the batch on the device
+    with an event to wait for.  Minibatch order and content are those of ``DeviceFrameStore.batches`` for the same seed (one
+    seeded permutation per epoch, rank r takes perm[r::world], drop_last), bit for bit — tests/test_shards_cpu.py."""
+
+    def __init__(self, location, device, batch_size: int, seed: int, rank: int = 0, world_size: int = 1, threads: int = 0, depth: int = 3,
+                 **flags):
+        import ctypes
+        import queue
+        import threading
+        from . import _lib
+        ds = ShardDataset(location, **flags)
+        self.flags = ds
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.B, self.seed, self.rank, self.world = int(batch_size), int(seed), int(rank), int(world_size)
+        self.nf = 4 if ds.previous_images else 1
+        self.n = len(ds)
+        self.per_rank = (self.n // self.world // self.B) * self.B
+        if self.per_rank == 0:
+            raise ValueError(f"dataset of {self.n} samples is smaller than one global batch ({self.B} x {self.world})")
+        self._maps = [np.load(p, mmap_mode="r") for p in ds._paths]
+        self._base = np.array([m.ctypes.data for m in self._maps], dtype=np.uint64)  # address of frame 0 of every shard
+        self._shard_frames = ds.shard_frames
+        self._before = np.ascontiguousarray(ds.before[:, :self.nf].astype(np.int64))
+        self._after = np.ascontiguousarray(ds.after[:, :self.nf].astype(np.int64))
+        lab = DeviceFrameStore._labels(ds, np.arange(self.n))
+        self.act, self.rew, self.term, self.gt, self.valid = (x.to(self.device) for x in lab)
+        self.threads = int(threads) if threads else max(1, min(16, (os.cpu_count() or 2) // 2))
+        self._lib, self._C = _lib.load(), ctypes
+        frames = 2 * self.B * self.nf  # before + after
+        self._slots = []
+        for _ in range(max(2, int(depth))):
+            t = torch.empty((frames, 224, 224, 3), dtype=torch.uint8)
+            self._slots.append(t.pin_memory() if self.cuda else t)
+        self._slot_free = [None] * len(self._slots)  # event behind the last host-to-device copy that read the slot
+        self._stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._q = queue.Queue(maxsize=len(self._slots) - 1)
+        self._stop = False
+        self._err = None
+        self._thread = threading.Thread(target=self._produce, name="vdqn-host-frame-stream", daemon=True)
+        self._thread.start()
+
+    def __len__(self):
+        return self.n
+
+    def _perm(self, epoch: int) -> np.ndarray:
+        g = torch.Generator(device="cpu")
+        g.manual_seed(self.seed + epoch)
+        return torch.randperm(self.n, generator=g)[self.rank::self.world][:self.per_rank].numpy()
+
+    def _addresses(self, idx: np.ndarray) -> np.ndarray:
+        fr = np.concatenate([self._before[idx].reshape(-1), self._after[idx].reshape(-1)])
+        return self._base[fr // self._shard_frames] + (fr % self._shard_frames).astype(np.uint64) * np.uint64(FRAME_BYTES)
+
+    def _produce(self):
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            epoch, k = 0, 0
+            while not self._stop:
+                perm = self._perm(epoch)
+                for lo in range(0, self.per_rank, self.B):
+                    if self._stop:
+                        return
+                    idx = perm[lo:lo + self.B]
+                    slot = k % len(self._slots)
+                    k += 1
+                    if self._slot_free[slot] is not None:
+                        self._slot_free[slot].synchronize()  # the copy that read this staging buffer last has finished
+                    buf = self._slots[slot]
+                    addr = np.ascontiguousarray(self._addresses(idx))
+                    rc = self._lib.vdqn_host_gather(buf.data_ptr(), addr.ctypes.data, addr.shape[0], FRAME_BYTES, self.threads)
+                    if rc != 0:
+                        raise RuntimeError("vdqn_host_gather failed")
+                    idx_t = torch.from_numpy(idx)
+                    if self.cuda:
+                        with torch.cuda.stream(self._stream):
+                            dev = buf.to(self.device, non_blocking=True)
+                            idx_d = idx_t.to(self.device, non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(self._stream)
+                        self._slot_free[slot] = ev
+                    else:
+                        dev, idx_d, ev = buf.clone(), idx_t, None
+                    self._q.put((dev, idx_d, ev))
+                epoch += 1
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer, which re-raises it
+            self._err = e
+            self._q.put(None)
+
+    def batches(self):
+        """Endless stream of device batches, the tuple of DeviceFrameStore.gather: (before, after, 0, act, rew, term, valid, gt)."""
+        half = self.B * self.nf
+        while True:
+            item = self._q.get()
+            if item is None:
+                raise RuntimeError("the host frame stream stopped") from self._err
+            dev, idx, ev = item
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                dev.record_stream(cur)  # allocated on the prefetch stream, consumed on the compute stream
+                idx.record_stream(cur)
+            b, a = dev[:half], dev[half:]
+            if self.nf > 1:
+                b = b.view(self.B, self.nf, 224, 224, 3)
+                a = a.view(self.B, self.nf, 224, 224, 3)
+            yield (b, a, 0, self.act.index_select(0, idx), self.rew.index_select(0, idx), self.term.index_select(0, idx),
+                   self.valid.index_select(0, idx), self.gt.index_select(0, idx))
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except Exception:  # noqa: BLE001 - queue.Empty
+            pass
+
+
 def collate_batches(items):
     """collate_fn for ShardDataset.__getitems__: the fetch already produced the collated batch."""
     return items[0]

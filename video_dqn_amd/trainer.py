@@ -137,6 +137,7 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
     B = int(config.BATCH_SIZE)
     params = {"batch_size": B, "num_workers": int(config.NUM_WORKERS), "drop_last": True}
     store = None  # DeviceFrameStore when the decoded frames live in HBM
+    stream = None  # HostFrameStream when they are streamed from memory-mapped shards
     if config.SYNTHETIC_DATA or config.DATASET in ("none", "synthetic"):
         nf = config.NUM_FRAMES or (4 if (config.PANORAMA or config.PREVIOUS_IMAGES) else 1)
         dataset = SyntheticTupleDataset(length=max(4 * B * world_size, 1024), num_frames=nf,
@@ -157,10 +158,25 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                 resident = n_frames * 224 * 224 * 3 + (32 << 30) < free
                 if world_size > 1:  # one decision for the whole job: a rank on the loader path would draw from a different
                     resident = agree_all(resident, device=config.device)  # sharding of the epoch than the resident ones
-            if resident:
+            if resident and world_size > 1 and bool(getattr(config, "RANK_SHARDED_DATA", True)):
+                # N ranks: each holds only the frames its samples of the current epoch reference (re-uploaded per epoch), not a full
+                # copy of the dataset; same minibatch sequence as the full per-rank copy
+                from .shards import RankShardedFrameStore
+                store = RankShardedFrameStore(config.DATASET, config.device, rank, world_size,
+                                              threads=int(getattr(config, "HOST_GATHER_THREADS", 0)), **kw)
+                log(f"dataset resident in HBM, sharded by rank: the frames of this rank's samples are uploaded per epoch "
+                    f"(dataset: {store.total_frames * 224 * 224 * 3 / 2**30:.2f} GiB)")
+            elif resident:
                 from .shards import DeviceFrameStore
                 store = DeviceFrameStore(config.DATASET, config.device, **kw)
                 log(f"dataset resident in HBM: {store.bytes() / 2**30:.2f} GiB of frames")
+            elif str(getattr(config, "SHARD_INPUT", "stream")).lower() == "stream":
+                # the frames do not fit (or residency is off): memory-mapped shards, native gather into pinned double buffers,
+                # host-to-device copies on a prefetch stream — same minibatch sequence as the resident store
+                from .shards import HostFrameStream
+                stream = HostFrameStream(config.DATASET, config.device, B, config.SEED, rank, world_size,
+                                         threads=int(getattr(config, "HOST_GATHER_THREADS", 0)), **kw)
+                log(f"dataset streamed from memory-mapped shards: {stream.threads} gather threads, {len(stream._slots)} pinned staging buffers")
         else:
             dataset = QLearningRealDataset(config.DATASET, as_uint8=True, **kw)
         log(f"Load data from {config.DATASET}")
@@ -190,7 +206,10 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
     if world_size > 1 and config.ARCHITECTURE != "extra_capacity" and getattr(config, "SYNC_BN", True):
         model.engine.set_bn_sync(world_size)  # train-mode BatchNorm over the global batch, as the single-GPU reference sees it
     if store is not None:  # minibatches are gathered on the device; no loader, no host copies
-        iterator = store.batches(B, config.SEED, rank, world_size)
+        from .shards import RankShardedFrameStore as _RS
+        iterator = store.batches(B, config.SEED) if isinstance(store, _RS) else store.batches(B, config.SEED, rank, world_size)
+    elif stream is not None:
+        iterator = stream.batches()
     else:
         iterator = DevicePrefetcher(loopLoader(loader, on_reset=(sampler.set_epoch if sampler else None)), model.engine.device)
     os.makedirs(f"{config.folder}/models", exist_ok=True)
@@ -281,4 +300,6 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
     if pending is not None:
         consume(pending)
     torch.cuda.synchronize()
+    if stream is not None:
+        stream.close()
     return model, stepper, running_loss
