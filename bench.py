@@ -226,7 +226,8 @@ def main():
     if world > 1 and not ec:
         net.set_bn_sync(world)  # 'basic': global BatchNorm statistics (N ranks == one big batch)
     stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=args.target_update_interval,
-                    world_size=world, allreduce=(comm.launch if comm else None), loss_kind=args.loss_kind)
+                    world_size=world, allreduce=(comm.launch if comm else None), loss_kind=args.loss_kind,
+                    allreduce_wait=(comm.wait_last if comm else None))
 
     # synthetic minibatches, resident in HBM before the timed region: uint8 frames (normalise fused into packing).
     # `--pool` distinct ones are used round-robin so that a step does not find its frames in the Infinity Cache.

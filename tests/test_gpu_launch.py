@@ -35,6 +35,19 @@ def _bench(args, **env):
 SMALL = ["--ramp-seconds", "0", "--batch", "8", "--steps", "3", "--warmup", "1", "--windows", "1", "--profile-steps", "1", "--no-cpu-baseline", "--pool", "2"]
 
 
+def test_per_bucket_adam_under_an_exchange_is_the_same_update():
+    """VDQN_DIST_EARLY_ADAM=1 (round-4 review 7a): with a gradient exchange, stage 0 / stage 1 are updated behind THEIR bucket on a stream
+    of their own instead of behind the last bucket.  One rank through RCCL, deterministic f32: the master parameters after three
+    updates carry the same SHA-256 as without the switch and as the run without any exchange."""
+    det = ["--dtype", "f32", "--deterministic", "--params-digest", "--batch", "4", "--steps", "3", "--warmup", "0", "--windows", "1", "--ramp-seconds", "0",
+           "--profile-steps", "1", "--no-cpu-baseline", "--pool", "1"]
+    a = _bench(["--gpus", "1", "--force-dist"] + det, VDQN_DIST_EARLY_ADAM="1")
+    b = _bench(["--gpus", "1", "--force-dist"] + det)
+    c = _bench(["--gpus", "1"] + det)
+    assert a["params_sha256"] is not None and a["params_sha256"] == b["params_sha256"] == c["params_sha256"]
+    assert a["loss"] == b["loss"] == c["loss"]
+
+
 def test_bench_self_launches_two_ranks_without_torchrun():
     out = _bench(["--gpus", "2", "--backend", "gloo"] + SMALL, VDQN_BENCH_SINGLE_DEVICE="1")
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"

@@ -9,6 +9,7 @@
 #   pmc            rocprofv3 --pmc passes (MFMA busy, LDS conflicts, HBM traffic): tools/pmc_mfma.sh
 #   records        the other configurations of BASELINE.json and the mode records: tools/records_round.sh
 #   ab:<a>@<b>     alternating bench runs of two environments, e.g. ab:new:@old:VDQN_SKINNY=0,VDQN_WGRAD_STREAMS=1
+#   abd:<a>@<b>    the same with bench.py --force-dist (one rank through RCCL: the exchange's stream ordering on one GPU)
 #   e2e            the trainer-loop throughput record next to bench.py: tools/trainer_e2e.py
 #   head           per-launch times of the Q-head's layers: tools/bench_head.py
 #   diag:<script>  python tools/<script>.py (diag_bf16_emulation, diag_basic_outlier, ...), output captured
@@ -36,6 +37,7 @@ PY
     pmc)     timeout 600 bash tools/pmc_mfma.sh "$TAG" > "$O/pmc.log" 2>&1; tail -24 "$O/pmc.log" ;;
     records) timeout 1800 bash tools/records_round.sh "$TAG" > "$O/records.log" 2>&1; tail -16 "$O/records.log" | cut -c1-220 ;;
     ab)      a=${arg%%@*}; b=${arg#*@}; timeout 900 python tools/ab_env.py --rounds 3 "$a" "$b" > "$O/ab_${a%%:*}_${b%%:*}.txt" 2>&1; grep -A3 "medians" "$O/ab_${a%%:*}_${b%%:*}.txt" ;;
+    abd)     a=${arg%%@*}; b=${arg#*@}; timeout 900 python tools/ab_env.py --rounds 3 --bench-args "--force-dist" "$a" "$b" > "$O/abd_${a%%:*}_${b%%:*}.txt" 2>&1; grep -A3 "medians" "$O/abd_${a%%:*}_${b%%:*}.txt" ;;
     e2e)     timeout 1500 python tools/trainer_e2e.py --out "$O/trainer_e2e.json" > "$O/trainer_e2e.log" 2>&1; tail -2 "$O/trainer_e2e.log" | cut -c1-600 ;;
     head)    timeout 300 python tools/bench_head.py >> "$O/bench_head.txt" 2>&1; tail -1 "$O/bench_head.txt" ;;
     diag)    timeout 900 python "tools/${arg%% *}.py" ${arg#* } > "$O/${arg%% *}.txt" 2>&1; tail -3 "$O/${arg%% *}.txt" | cut -c1-300 ;;

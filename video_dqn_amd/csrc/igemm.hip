@@ -546,6 +546,29 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
     igemm_epilogue<T, BM, BN, MODE, WN>(q, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw, q.bias);
     return;
   }
+  if constexpr (MODE == 2 && sizeof(T) == 2 && BM == 128 && WN == 2) {
+    // stride-2 data gradient, bf16: the lean epilogue (igemm_common.h) — these tiles have 2-8 K-steps, the shared epilogue was as
+    // long as their K loop.  Class-local row -> output pixel as in igemm_epilogue.
+    const bool lean_d = !p.no_lean && p.vec_ok && p.out && !p.out_f32 && !p.bias && p.co % BN == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
+    if (lean_d) {
+      const LeanEpiD led = make_lean_epi_d(p.out, p.resid, p.mask, p.colsum_part, p.M, p.ldo, p.co);
+      const int ncol = n0 + wc * (BN / WN) + g * CPL;
+      uint32_t off[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int m = m0 + wr * 64 + f * 16 + i16;
+        const bool ok = m < rows_total && ncol < p.co;
+        const int mm = ok ? m : m0;
+        const int img = mm / pix_per_img;
+        const int rem = mm - img * pix_per_img;
+        const int ohc = rem / row_w;
+        const int mo = (img * p.ho + 2 * ohc + cls_ph) * p.wo + 2 * (rem - ohc * row_w) + cls_pw;
+        off[f] = ok ? (uint32_t)(mo * p.ldo + ncol) * 2u : kOob;
+      }
+      lean_epilogue_dgrad<NF>(led, acc, reinterpret_cast<float*>(smem), off, n0, tile_m, tid);
+      return;
+    }
+  }
   igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw, grp_b ? p.bias_b : p.bias);
 }
 

@@ -273,6 +273,109 @@ __device__ __forceinline__ void lean_epilogue_128(const LeanEpi& e, f32x4 (&acc)
   }
 }
 
+// The data-gradient form: gx = mask > 0 ? (acc + resid) : 0 -> bf16, and the per-tile column sums of what was stored (the bias /
+// BatchNorm-shift gradient of the layer below): igemm_epilogue's arithmetic (its `+ 0.f` for the absent bias included: -0 -> +0)
+// with buffer loads / stores.  scratch: 2 x 128 floats of LDS no wave still reads.
+struct LeanEpiD {
+  __amdgpu_buffer_rsrc_t out, res, msk;
+  float* colsum_part;
+  int ldo, has_res, has_msk, co;
+};
+__device__ __forceinline__ LeanEpiD make_lean_epi_d(void* out, const void* resid, const void* mask, float* colsum_part, long long rows, int ldo, int co) {
+  LeanEpiD e;
+  const int bytes = (int)(rows * ldo * 2);
+  e.out = __builtin_amdgcn_make_buffer_rsrc(out, 0, bytes, 0x00020000);
+  e.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(resid), 0, resid ? bytes : 0, 0x00020000);
+  e.msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mask), 0, mask ? bytes : 0, 0x00020000);
+  e.colsum_part = colsum_part;
+  e.ldo = ldo; e.has_res = resid != nullptr; e.has_msk = mask != nullptr; e.co = co;
+  return e;
+}
+// NF = 16-wide channel fragments per wave (4: 128-column tiles, 2: 64-column tiles; WN = 2 waves along N either way).  off[f]: byte
+// offset of the lane's pixel f in out / resid / mask at channel ncol, kOob for rows that do not exist.
+template <int NF>
+__device__ __forceinline__ void lean_epilogue_dgrad(const LeanEpiD& e, f32x4 (&acc)[4][NF], float* scratch, const uint32_t (&off)[4], int n0, int tile_m, int tid) {
+  constexpr int CPL = 4 * NF, BN = 32 * NF, V = CPL / 8;  // channels per lane, tile columns, 16-byte vectors per pixel
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i16 = lane & 15, g = lane >> 4;
+  u32x4 rv[4][V], mv[4][V];
+  if (e.has_res) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int q = 0; q < V; ++q) rv[f][q] = __builtin_amdgcn_raw_buffer_load_b128(e.res, (int)off[f] + 16 * q, 0, 0);
+  }
+  if (e.has_msk) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int q = 0; q < V; ++q) mv[f][q] = __builtin_amdgcn_raw_buffer_load_b128(e.msk, (int)off[f] + 16 * q, 0, 0);
+  }
+  float cs[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) cs[k] = 0.f;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    float v[CPL];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + 0.f;
+    if (e.has_res) {
+      const bf16raw* pr = reinterpret_cast<const bf16raw*>(rv[f]);
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) v[k] += bf16_to_f32(pr[k]);
+    }
+    if (e.has_msk) {
+      const bf16raw* pm = reinterpret_cast<const bf16raw*>(mv[f]);
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) v[k] = (bf16_to_f32(pm[k]) > 0.f) ? v[k] : 0.f;
+    }
+    bf16raw ov[CPL];
+    const float live = off[f] != kOob ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      ov[k] = f32_to_bf16(v[k]);
+      cs[k] += live * bf16_to_f32(ov[k]);
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[q], e.out, (int)off[f] + 16 * q, 0, 0);
+  }
+  if (e.colsum_part) {  // uniform: the 16 pixel-lanes of every channel, then the two wave rows through LDS (igemm_epilogue's order)
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      float t = cs[k];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      t += __shfl_xor(t, 8, 64);
+      cs[k] = t;
+    }
+    __syncthreads();
+    if (i16 == 0) {
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) scratch[wr * BN + wc * (BN / 2) + g * CPL + k] = cs[k];
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < e.co) e.colsum_part[(size_t)tile_m * e.ldo + n0 + tid] = scratch[tid] + scratch[BN + tid];
+  }
+}
+template <int WN>
+__device__ __forceinline__ void lean_epilogue_dgrad_128(const LeanEpiD& e, f32x4 (&acc)[4][128 / (16 * WN)], float* scratch, int m0, int n0, int tile_m,
+                                                        int rows_end, int tid) {
+  static_assert(WN == 2, "64 x 64 wave tiles: 16 consecutive channels per lane");
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ncol = n0 + (wave & 1) * 64 + (lane >> 4) * 16;
+  uint32_t off[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int m = m0 + (wave >> 1) * 64 + f * 16 + (lane & 15);
+    off[f] = m < rows_end ? (uint32_t)(m * e.ldo + ncol) * 2u : kOob;
+  }
+  lean_epilogue_dgrad<4>(e, acc, scratch, off, n0, tile_m, tid);
+}
+
 #define VDQN_INTERLEAVE(N)                                  \
   if constexpr (sizeof(T) == 2) {                           \
     _Pragma("unroll") for (int g_ = 0; g_ < (N); ++g_) {    \

@@ -207,8 +207,10 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
 
   // forward tiles with bias (+ residual, ReLU) and nothing else take the lean epilogue (igemm_common.h); the grouped forward, f32
   // copies, ragged rows and every data-gradient operand combination keep igemm_epilogue
-  const bool lean = MODE == 0 && !p.no_lean && p.vec_ok && p.out && !p.out_f32 && !p.colsum_part && !p.mask && p.bias && !p.wt_b &&
+  const bool lean = MODE == 0 && !p.no_lean && p.co % BN == 0 && p.vec_ok && p.out && !p.out_f32 && !p.colsum_part && !p.mask && p.bias && !p.wt_b &&
                     (((uintptr_t)p.bias) & 15) == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
+  const bool lean_d = MODE == 1 && BM == 128 && !p.no_lean && p.vec_ok && p.out && !p.out_f32 && !p.bias && p.co % BN == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
+  const LeanEpiD led = make_lean_epi_d(p.out, p.resid, p.mask, p.colsum_part, lean_d ? p.M : 0, p.ldo, p.co);
   const LeanEpi le = make_lean_epi(p.out, p.resid, p.bias, (BAL || lean) ? p.M : 0, p.ldo, p.co, p.relu);
   f32x4 acc[4][NF];
   const int wr = wave / WN, wc = wave % WN;
@@ -402,6 +404,8 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
       lean_epilogue_128<WN>(le, acc, m0, n0, m_end, tid);
     } else {
       if (MODE == 0 && lean) lean_epilogue_128<WN>(le, acc, m0, n0, m_end, tid);
+      else if (MODE == 1 && BM == 128 && lean_d)
+        lean_epilogue_dgrad_128<WN>(led, acc, reinterpret_cast<float*>(smem + kU_WinBase + kU_WinStride), m0, n0, tile_m, m_end, tid);
       else igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem + kU_WinBase + kU_WinStride, m0, n0, tile_m, m_end, p.howo, W, 0, 0,
                                                m0 >= m_split ? p.bias_b : p.bias);
     }
@@ -497,7 +501,7 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
   const unsigned resident = (unsigned)((BM == 128 ? 2 : 1) * vdqn_num_cus());
   int bal_rows = 0;
   unsigned grid = (BM == 128 && ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident))) ? resident : tiles;  // (256-row tiles: one workgroup per tile)
-  const bool lean_ok = !p.no_lean && p.vec_ok && p.out && !p.out_f32 && !p.mask && p.bias && (((uintptr_t)p.bias) & 15) == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
+  const bool lean_ok = !p.no_lean && p.co % 128 == 0 && p.vec_ok && p.out && !p.out_f32 && !p.mask && p.bias && (((uintptr_t)p.bias) & 15) == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
   if (BM == 128 && MODE == 0 && balanced && lean_ok && !p.colsum_part && !p.wt_b && (tiles > resident || balanced >= 2) && p.tiles_n > 0 &&
       resident % (8u * (unsigned)p.tiles_n) == 0 && resident / (unsigned)p.tiles_n >= 8u) {
     const unsigned per_col = resident / (unsigned)p.tiles_n;       // workgroups (= row ranges) per column tile

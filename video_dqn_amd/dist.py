@@ -63,6 +63,12 @@ class BucketAllReduce:
         self.bucket_bytes.append(grad_slice.numel() * grad_slice.element_size())
         self._works.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def wait_last(self) -> None:
+        """Order the CURRENT stream behind the most recently launched bucket (a consumer of that bucket alone — the per-bucket
+        optimiser update of TDStepper(dist_early_adam=True) — on a stream of its own; `finish` still joins everything)."""
+        if self._works:
+            self._works[-1].wait()
+
     def finish(self) -> None:
         for w in self._works:
             w.wait()
@@ -129,6 +135,10 @@ class CAbiBucketAllReduce:
         ev = torch.cuda.Event()
         ev.record(st)
         self._events.append(ev)
+
+    def wait_last(self) -> None:
+        if self._events:
+            torch.cuda.current_stream().wait_event(self._events[-1])
 
     def finish(self) -> None:
         cur = torch.cuda.current_stream()

@@ -27,6 +27,8 @@ DTYPES = {"f32": _lib.VDQN_F32, "fp32": _lib.VDQN_F32, "float32": _lib.VDQN_F32,
 
 # VDQN_EARLY_ADAM=0: `TDStepper.step` runs the whole optimiser update behind the backward pass (one launch)
 _EARLY_ADAM = os.environ.get("VDQN_EARLY_ADAM", "1") != "0"
+# VDQN_DIST_EARLY_ADAM=1: under a gradient exchange, stage 0 / 1 are updated behind their own bucket (TDStepper.allreduce_wait)
+_DIST_EARLY_ADAM = os.environ.get("VDQN_DIST_EARLY_ADAM", "0") == "1"
 # VDQN_EARLY_FOLD=1 (off by default): stage 0 / stage 1 weights are folded for the NEXT update right behind their early Adam, so that
 # update starts with a 0.7 M-parameter fold instead of a 12.4 M one.  Measured on alternating runs it is 0.6 % SLOWER (5.747 against
 # 5.712 ms, profiles/r04g_ab_early_fold_two_stream_packs.txt): at the start of an update the fold already runs beside the two input
@@ -289,7 +291,7 @@ class TDStepper:
     def __init__(self, net: NetEngine, batch: int, lr: float, gamma: float, clip_rect: bool, linear: bool = False,
                  remove_before_reward: bool = False, train_on_ground_truth: bool = False, value_learning: bool = False,
                  target_update_interval: int = 8000, betas=(0.9, 0.999), eps: float = 1e-8, world_size: int = 1,
-                 allreduce=None, loss_kind: str = "l2", grouped_forward: Optional[bool] = None, allreduce_loss=None):
+                 allreduce=None, loss_kind: str = "l2", grouped_forward: Optional[bool] = None, allreduce_loss=None, allreduce_wait=None):
         net._need_gpu()
         self.net, self.B = net, batch
         self.lib = net.lib
@@ -307,6 +309,12 @@ class TDStepper:
         # callable(loss) or None: called once per update behind the LAST gradient bucket, on the gradient stream — the exchange
         # sums the ranks' loss shares there, so the compute stream never waits for a 4-byte collective (dist.launch_loss)
         self.allreduce_loss = allreduce_loss
+        # callable() or None: orders the current stream behind the bucket launched last (dist.wait_last).  With VDQN_DIST_EARLY_ADAM=1
+        # the optimiser update of stage 0 / stage 1 then runs behind ITS bucket on a stream of its own, under the rest of the backward
+        # pass, instead of behind the last bucket (off by default: DESIGN.md section 7 has the measurement)
+        self.allreduce_wait = allreduce_wait
+        self._post_stream = None
+        self._post_used = False
         dev = net.device
         nt = net.trainable_numel
         with torch.cuda.device(dev):
@@ -444,6 +452,16 @@ class TDStepper:
                         self.allreduce(self.grads[b:e], stage)
                         if stage == 2 and self.allreduce_loss is not None:
                             self.allreduce_loss(self.loss)
+                    if _DIST_EARLY_ADAM and stage < 2 and self.allreduce_wait is not None and n.extra_capacity:
+                        b4, e4 = (b + 3) // 4 * 4, e // 4 * 4
+                        if e4 > b4:
+                            if self._post_stream is None:
+                                self._post_stream = torch.cuda.Stream(device=n.device)
+                            with torch.cuda.stream(self._post_stream):
+                                self.allreduce_wait()  # this bucket's collective, nothing else
+                                self._adam_range(b4, e4, self.adam_step + 1)
+                            self._adam_done.append((b4, e4))
+                            self._post_used = True
                 elif early_adam and stage < 2:
                     b, e = self.stage_ranges[stage]
                     b, e = (b + 3) // 4 * 4, e // 4 * 4  # vdqn_adam wants 16-byte aligned ranges; the rest is left to optimizer_step
@@ -499,6 +517,9 @@ class TDStepper:
         done = sorted(getattr(self, "_adam_done", []))
         self._adam_done = []
         with torch.cuda.device(n.device):
+            if self._post_used:  # per-bucket updates under an exchange ran on their own stream: join it
+                torch.cuda.current_stream().wait_stream(self._post_stream)
+                self._post_used = False
             pos = 0  # everything of [0, trainable_numel) that `forward_backward(early_adam=True)` has not updated already
             for b, e in done + [(n.trainable_numel, n.trainable_numel)]:
                 if b > pos:

@@ -378,6 +378,8 @@ class HostFrameStream:
         self.flags = ds
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
+        if self.cuda and self.device.index is None:  # the producer thread needs an explicit device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.B, self.seed, self.rank, self.world = int(batch_size), int(seed), int(rank), int(world_size)
         self.nf = 4 if ds.previous_images else 1
         self.n = len(ds)

@@ -202,7 +202,7 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                         train_on_ground_truth=config.TRAIN_ON_GROUND_TRUTH, value_learning=config.VALUE_LEARNING,
                         target_update_interval=config.TARGET_UPDATE_INTERVAL, world_size=world_size,
                         allreduce=(comm.launch if comm else None), loss_kind=getattr(config, "LOSS_KIND", "l2"),
-                        allreduce_loss=(comm.launch_loss if comm else None))
+                        allreduce_loss=(comm.launch_loss if comm else None), allreduce_wait=(comm.wait_last if comm else None))
     if world_size > 1 and config.ARCHITECTURE != "extra_capacity" and getattr(config, "SYNC_BN", True):
         model.engine.set_bn_sync(world_size)  # train-mode BatchNorm over the global batch, as the single-GPU reference sees it
     if store is not None:  # minibatches are gathered on the device; no loader, no host copies
