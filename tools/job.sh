@@ -13,7 +13,7 @@
 #   e2e            the trainer-loop throughput record next to bench.py: tools/trainer_e2e.py
 #   head           per-launch times of the Q-head's layers: tools/bench_head.py
 #   diag:<script>  python tools/<script>.py (diag_bf16_emulation, diag_basic_outlier, ...), output captured
-#   tool:<out>:<K=V,K=V>:<script> [args]   python tools/<script>.py under the given environment, output in <out>.txt
+#   tool:<out>:<K=V,K=V>:<script>[+arg+arg]   python tools/<script>.py [args] under the given environment, output in <out>.txt
 set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -41,8 +41,8 @@ PY
     e2e)     timeout 1500 python tools/trainer_e2e.py --out "$O/trainer_e2e.json" > "$O/trainer_e2e.log" 2>&1; tail -2 "$O/trainer_e2e.log" | cut -c1-600 ;;
     head)    timeout 300 python tools/bench_head.py >> "$O/bench_head.txt" 2>&1; tail -1 "$O/bench_head.txt" ;;
     diag)    timeout 900 python "tools/${arg%% *}.py" ${arg#* } > "$O/${arg%% *}.txt" 2>&1; tail -3 "$O/${arg%% *}.txt" | cut -c1-300 ;;
-    tool)    out=${arg%%:*}; rest=${arg#*:}; envs=${rest%%:*}; cmd=${rest#*:}
-             ( IFS=,; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; timeout 900 python "tools/${cmd%% *}.py" $( [ "$cmd" != "${cmd#* }" ] && echo ${cmd#* } ) ) > "$O/$out.txt" 2>&1
+    tool)    out=${arg%%:*}; rest=${arg#*:}; envs=${rest%%:*}; cmd=${rest#*:}; cmd=${cmd//+/ }  # ('+' stands for a space in the script's arguments)
+             ( IFS=,; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS; timeout 900 python "tools/${cmd%% *}.py" $( [ "$cmd" != "${cmd#* }" ] && echo ${cmd#* } ) ) > "$O/$out.txt" 2>&1
              tail -4 "$O/$out.txt" | cut -c1-400 ;;
     *)       echo "unknown recipe $recipe"; exit 2 ;;
   esac

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--dump", action="store_true")
     ap.add_argument("--updates", type=int, default=3)
+    ap.add_argument("--force-dist", action="store_true", help="one rank through RCCL: the three gradient buckets are all-reduced (bench.py --force-dist); "
+                                                               "VDQN_DIST_EARLY_ADAM=1 then updates stage 0 / 1 behind their own bucket")
     args = ap.parse_args()
     from video_dqn_amd import _lib, synth
     from video_dqn_amd.engine import NetEngine, TDStepper
@@ -32,7 +34,17 @@ def main():
     B = args.batch
     net = NetEngine(3, 5, 1, True, "bf16", 2 * B, device=dev)
     net.load_tensors(synth.make_state_dict(4, extra_capacity=True, num_frames=1))
-    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=10 ** 9)
+    comm = None
+    if args.force_dist:
+        import torch.distributed as dist
+        from video_dqn_amd.dist import BucketAllReduce
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        comm = BucketAllReduce(1, force=True)
+    stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, target_update_interval=10 ** 9,
+                    allreduce=(comm.launch if comm else None), allreduce_wait=(comm.wait_last if comm else None))
+    fin = comm.finish if comm else None
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     b_ = torch.randint(0, 256, (B, 1, 224, 224, 3), dtype=torch.uint8, device=dev, generator=g)
@@ -40,11 +52,11 @@ def main():
     act = torch.randint(0, 3, (B,), dtype=torch.int64, device=dev, generator=g)
     rew = (torch.rand((B, 5), device=dev, generator=g) < 0.05).float()
     for _ in range(300):
-        stp.step(b_, a_, 0, act, rew, rew)
+        stp.step(b_, a_, 0, act, rew, rew, finish_allreduce=fin)
     torch.cuda.synchronize()
     _lib.profile_enable(True)
     for _ in range(args.updates):
-        stp.step(b_, a_, 0, act, rew, rew)
+        stp.step(b_, a_, 0, act, rew, rew, finish_allreduce=fin)
     torch.cuda.synchronize()
     raw = C.CDLL(_lib.LIB_PATH)
     buf = (Span * 4096)()

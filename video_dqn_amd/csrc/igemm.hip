@@ -1232,6 +1232,35 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     }
   };
 
+  // Forward (round 5): the next tile's window is issued in four parts between the MFMAs of this tile's K loop (pieces 2 q, 2 q + 1 at
+  // half-step 2 + 4 q) instead of eight pieces in a burst at the tile's top: conv64 forward 0.812 -> 0.784 ms per update
+  // (profiles/r05h_ab_conv64_spread_dma.txt).  The data-gradient instances keep the burst: with the parts inside their K loop two
+  // of them spill six registers there and lose 10 % (0.351 -> 0.387).  -DVDQN_C64_SPREAD=0 / =2: never / both modes (A/B builds).
+  auto issue_window_part = [&](int tl, int buf, int part) {
+    const int q0 = tl * 128 - W - 1;
+    const uint32_t v0 = (uint32_t)(q0 + lrow + 32 * (2 * part)) * 128u + (uint32_t)(lchunk * 16);
+    const uint32_t v1 = v0 + 32u * 128u;
+    const uint32_t l_ = lds_wave + (uint32_t)(buf * kC64WinBytes) + (uint32_t)(2 * part * PSTR);
+    if (part < 3) {
+      asm volatile(
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, 0 offen lds\n\t"
+          "s_add_u32 m0, %2, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds"
+          ::"v"(v0), "v"(v1), "s"(l_), "s"(rs_a), "n"(PSTR)
+          : "memory", "scc");
+    } else {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(v0), "s"(l_), "s"(rs_a) : "memory");
+      if (wave_u < 3) {
+        const uint32_t l2_ = l_ + (uint32_t)PSTR;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(v1), "s"(l2_), "s"(rs_a) : "memory");
+      }
+    }
+  };
+  (void)issue_window_part;
+#ifndef VDQN_C64_SPREAD
+#define VDQN_C64_SPREAD 1
+#endif
+  constexpr bool kSpread = VDQN_C64_SPREAD == 2 || (VDQN_C64_SPREAD == 1 && MODE == 0);
+  const uint32_t c64_adv_oh = (uint32_t)((16 / W) % H), c64_adv_ow = (uint32_t)(16 - (16 / W) * W);  // (whole images drop out of the position)
   int t = g_bid, buf = 0;
   if (t < g_tiles) issue_window(g_first + (int)xcd_remap((uint32_t)t, (uint32_t)g_tiles), 0);
   for (; t < g_tiles; t += g_blocks, buf ^= 1) {
@@ -1249,7 +1278,11 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     unsigned long long* st_row = (p.pool_out && st_k < 16) ? reinterpret_cast<unsigned long long*>(p.pool_out) + ((size_t)blockIdx.x * 16 + st_k) * 8 : nullptr;
     if (st_row && tid == 0) { st_row[0] = st_w0; st_row[1] = __builtin_amdgcn_s_memtime(); }
 #endif
-    if (t + g_blocks < g_tiles) issue_window(g_first + (int)xcd_remap((uint32_t)(t + g_blocks), (uint32_t)g_tiles), buf ^ 1);
+    const bool c64_has_nx = t + g_blocks < g_tiles;
+    const int c64_tl_nx = c64_has_nx ? g_first + (int)xcd_remap((uint32_t)(t + g_blocks), (uint32_t)g_tiles) : 0;
+    if constexpr (!kSpread) {
+      if (c64_has_nx) issue_window(c64_tl_nx, buf ^ 1);
+    }
 #ifdef VDQN_STAMP
     if (st_row && tid == 0) st_row[2] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1258,13 +1291,23 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(held_cs), r_cs, (int)held_cs_off, 0, 0);
 
     // edge bits of this lane's four pixels (one nibble each, one register): 1 top row, 2 bottom row, 4 left column, 8 right column
+    // (the position of pixel f = 0 by division, the three others 16 pixels on each: adds, compares and selects — round 5)
     uint32_t edge = 0u;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const uint32_t m = (uint32_t)(m0 + wr * 64 + f * 16 + i16);
+    {
+      const uint32_t m = (uint32_t)(m0 + wr * 64 + i16);
       const uint32_t rem = m - fastdiv(m, d_howo) * d_howo.div;
-      const uint32_t oh = fastdiv(rem, d_wo), ow = rem - oh * d_wo.div;
-      edge |= ((oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u)) << (4 * f);
+      uint32_t oh = fastdiv(rem, d_wo), ow = rem - oh * d_wo.div;
+      const uint32_t adv_oh = c64_adv_oh, adv_ow = c64_adv_ow;  // 16 pixels = adv_oh rows + adv_ow columns
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        edge |= ((oh == 0 ? 1u : 0u) | (oh == (uint32_t)H - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)W - 1 ? 8u : 0u)) << (4 * f);
+        ow += adv_ow;
+        oh += adv_oh;
+        const bool c1 = ow >= (uint32_t)W;
+        ow -= c1 ? (uint32_t)W : 0u;
+        oh += c1 ? 1u : 0u;
+        oh -= oh >= (uint32_t)H ? (uint32_t)H : 0u;  // (into the next image: at most once, adv_oh < H)
+      }
     }
     f32x4 acc[4][2];
 #pragma unroll
@@ -1322,9 +1365,15 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     }                                                                                                                       \
   }
     // one pipelined half-step: reads of HS + 1 (4, or 6 with LDS weights) spread over the 8 MFMAs of HS
+#define VDQN_C64_SPREAD_ISSUE(HS)                                                                                           \
+    if constexpr (kSpread && ((HS)&3) == 2 && (HS) < 16) {                                                                  \
+      if (c64_has_nx) issue_window_part(c64_tl_nx, buf ^ 1, (HS) >> 2);                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    }
 #define VDQN_C64_STEP(HS)                                                                                                   \
   {                                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    VDQN_C64_SPREAD_ISSUE(HS)                                                                                               \
     if constexpr ((HS) == 2 * kC64LoadTap) {                                                                                \
       if constexpr (HAS_RES) {                                                                                              \
         _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) rv[f_] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)off[f_], 0, 0); \
@@ -1356,6 +1405,7 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     VDQN_C64_STEP(6) VDQN_C64_STEP(7) VDQN_C64_STEP(8) VDQN_C64_STEP(9) VDQN_C64_STEP(10) VDQN_C64_STEP(11)
     VDQN_C64_STEP(12) VDQN_C64_STEP(13) VDQN_C64_STEP(14) VDQN_C64_STEP(15) VDQN_C64_STEP(16) VDQN_C64_STEP(17)
 #undef VDQN_C64_STEP
+#undef VDQN_C64_SPREAD_ISSUE
 #undef VDQN_C64_MMA
 #undef VDQN_C64_LOAD
 #ifdef VDQN_STAMP

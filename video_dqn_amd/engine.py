@@ -28,7 +28,10 @@ DTYPES = {"f32": _lib.VDQN_F32, "fp32": _lib.VDQN_F32, "float32": _lib.VDQN_F32,
 # VDQN_EARLY_ADAM=0: `TDStepper.step` runs the whole optimiser update behind the backward pass (one launch)
 _EARLY_ADAM = os.environ.get("VDQN_EARLY_ADAM", "1") != "0"
 # VDQN_DIST_EARLY_ADAM=1: under a gradient exchange, stage 0 / 1 are updated behind their own bucket (TDStepper.allreduce_wait)
-_DIST_EARLY_ADAM = os.environ.get("VDQN_DIST_EARLY_ADAM", "0") == "1"
+_DIST_EARLY_ADAM = os.environ.get("VDQN_DIST_EARLY_ADAM", "0") in ("1", "2", "3")
+# diagnostic values (one rank only — they are wrong with more): 2 = the same without waiting for the bucket's collective (is the wait
+# the cost?), 3 = waiting for it, but without the Adam launch (is the extra kernel the cost?)
+_DIST_EARLY_ADAM_MODE = os.environ.get("VDQN_DIST_EARLY_ADAM", "0")
 # VDQN_EARLY_FOLD=1 (off by default): stage 0 / stage 1 weights are folded for the NEXT update right behind their early Adam, so that
 # update starts with a 0.7 M-parameter fold instead of a 12.4 M one.  Measured on alternating runs it is 0.6 % SLOWER (5.747 against
 # 5.712 ms, profiles/r04g_ab_early_fold_two_stream_packs.txt): at the start of an update the fold already runs beside the two input
@@ -458,9 +461,14 @@ class TDStepper:
                             if self._post_stream is None:
                                 self._post_stream = torch.cuda.Stream(device=n.device)
                             with torch.cuda.stream(self._post_stream):
-                                self.allreduce_wait()  # this bucket's collective, nothing else
-                                self._adam_range(b4, e4, self.adam_step + 1)
-                            self._adam_done.append((b4, e4))
+                                if _DIST_EARLY_ADAM_MODE != "2":
+                                    self.allreduce_wait()  # this bucket's collective, nothing else
+                                else:  # (diagnostic: ordered behind the gradient stream only)
+                                    torch.cuda.current_stream().wait_stream(self._grad_stream)
+                                if _DIST_EARLY_ADAM_MODE != "3":
+                                    self._adam_range(b4, e4, self.adam_step + 1)
+                            if _DIST_EARLY_ADAM_MODE != "3":
+                                self._adam_done.append((b4, e4))
                             self._post_used = True
                 elif early_adam and stage < 2:
                     b, e = self.stage_ranges[stage]
