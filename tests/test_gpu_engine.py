@@ -730,7 +730,12 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_SPLIT_ONLINE": "1"},       # online forward as two half-batch passes on two streams
     {"VDQN_FUSE_POOL_BWD": "0"},      # max-pool backward + stem weight gradient as two launches
     {"VDQN_WIN9_BM256": "2"},         # 256-row tiles of the nine-tap window kernel
-    {"VDQN_FUSE_DS": "3"},            # 1x1 downsample fused into its sibling 3x3/2 in the forward pass too
+    {"VDQN_FUSE_DS": "1"},            # round 4's default: the 1x1 downsample as its own forward launch (fused in the data gradient only)
+    {"VDQN_FUSE_DS": "7"},            # fused in the forward pass on the generic kernel too (f32 engines)
+    {"VDQN_LEAN_EPILOGUE": "0"},      # the window kernels on the shared igemm_epilogue (round 4) instead of the lean ones
+    {"VDQN_S2WIN_PERSIST": "0"},      # stride-2 plane-window kernel: one workgroup per tile (no tile walk)
+    {"VDQN_S2WIN_PERSIST": "-1", "VDQN_FUSE_DS": "1"},  # ... and round 4's kernel for it
+    {"VDQN_WIN9_BALANCED": "2"},      # balanced row walk of the nine-tap window kernel (two launches per convolution)
     {"VDQN_GROUPED_FWD": "1"},        # online and target forward as one chain of grouped launches
     {"VDQN_GROUPED_FWD": "1", "VDQN_GROUPED_LAUNCH": "0"},  # grouped forward, every layer through the internal two-launch fall-back
     {"VDQN_WIN9_MFMA32": "1"},        # nine-tap window kernel on 32x32x16 MFMAs (win9m.hip)

@@ -224,31 +224,36 @@ __device__ __forceinline__ LeanEpi make_lean_epi(void* out, const void* resid, c
   e.ldo = ldo; e.relu = relu; e.has_res = resid != nullptr;
   return e;
 }
+// The loads of a tile's epilogue (bias, residual) and the offsets, split from the arithmetic so that a kernel can issue them before
+// its last K-step's MFMAs have drained (win9u_kernel: in place of the fragment reads nobody uses in a tile's last step).
+struct LeanPre {
+  u32x4 bq[4], rv[4][2];
+  uint32_t off[4];
+};
 template <int WN>
-__device__ __forceinline__ void lean_epilogue_128(const LeanEpi& e, f32x4 (&acc)[4][128 / (16 * WN)], int m0, int n0, int rows_end, int tid) {
+__device__ __forceinline__ void lean_prefetch_128(const LeanEpi& e, LeanPre& pre, int m0, int n0, int rows_end, int tid) {
   static_assert(WN == 2, "64 x 64 wave tiles: 16 consecutive channels per lane");
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int i16 = lane & 15, g = lane >> 4;
   const int ncol = n0 + wc * 64 + g * 16;
-  u32x4 bq[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) bq[q] = __builtin_amdgcn_raw_buffer_load_b128(e.bias, ncol * 4 + 16 * q, 0, 0);
-  uint32_t off[4];
+  for (int q = 0; q < 4; ++q) pre.bq[q] = __builtin_amdgcn_raw_buffer_load_b128(e.bias, ncol * 4 + 16 * q, 0, 0);
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const int m = m0 + wr * 64 + f * 16 + i16;
-    off[f] = m < rows_end ? (uint32_t)(m * e.ldo + ncol) * 2u : kOob;
+    pre.off[f] = m < rows_end ? (uint32_t)(m * e.ldo + ncol) * 2u : kOob;
   }
-  u32x4 rv[4][2];
   if (e.has_res) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      rv[f][0] = __builtin_amdgcn_raw_buffer_load_b128(e.res, (int)off[f], 0, 0);
-      rv[f][1] = __builtin_amdgcn_raw_buffer_load_b128(e.res, (int)off[f] + 16, 0, 0);
+      pre.rv[f][0] = __builtin_amdgcn_raw_buffer_load_b128(e.res, (int)pre.off[f], 0, 0);
+      pre.rv[f][1] = __builtin_amdgcn_raw_buffer_load_b128(e.res, (int)pre.off[f] + 16, 0, 0);
     }
   }
-  const float* bv = reinterpret_cast<const float*>(bq);
+}
+__device__ __forceinline__ void lean_finish_128(const LeanEpi& e, f32x4 (&acc)[4][4], const LeanPre& pre) {
+  const float* bv = reinterpret_cast<const float*>(pre.bq);
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     float v[16];
@@ -257,7 +262,7 @@ __device__ __forceinline__ void lean_epilogue_128(const LeanEpi& e, f32x4 (&acc)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + bv[j * 4 + r];
     if (e.has_res) {
-      const bf16raw* pr = reinterpret_cast<const bf16raw*>(rv[f]);
+      const bf16raw* pr = reinterpret_cast<const bf16raw*>(pre.rv[f]);
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] += bf16_to_f32(pr[k]);
     }
@@ -268,9 +273,15 @@ __device__ __forceinline__ void lean_epilogue_128(const LeanEpi& e, f32x4 (&acc)
     bf16raw ov[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) ov[k] = f32_to_bf16(v[k]);
-    __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[0], e.out, (int)off[f], 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[1], e.out, (int)off[f] + 16, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[0], e.out, (int)pre.off[f], 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(ov)[1], e.out, (int)pre.off[f] + 16, 0, 0);
   }
+}
+template <int WN>
+__device__ __forceinline__ void lean_epilogue_128(const LeanEpi& e, f32x4 (&acc)[4][128 / (16 * WN)], int m0, int n0, int rows_end, int tid) {
+  LeanPre pre;
+  lean_prefetch_128<WN>(e, pre, m0, n0, rows_end, tid);
+  lean_finish_128(e, acc, pre);
 }
 
 // The data-gradient form: gx = mask > 0 ? (acc + resid) : 0 -> bf16, and the per-tile column sums of what was stored (the bias /
