@@ -12,5 +12,5 @@ def test_window_kernels_have_no_scratch_access_inside_mfma_loops():
     scratch accesses (tools/check_spills.py compiles the sources to ISA and scans them)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_spills
-    for src in ("win9.hip", "win9s.hip"):
+    for src in ("win9.hip", "win9s.hip", "win9d.hip"):
         assert check_spills.check(src) == [], src

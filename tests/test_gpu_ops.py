@@ -719,3 +719,57 @@ def test_nine_tap_window_kernel_balanced_walk(case):
         lib.vdqn_debug_set_win9_balanced(-1)
     assert torch.equal(bal, one)
     assert relerr(one.float().cpu().permute(0, 3, 1, 2), F.relu(F.conv2d(x, w, b, 1, 1) + res)) < TOL[dtype]
+
+
+S2D_CASES = [  # n, ci (of the forward conv = columns of the gradient), planes (gy channels), h, pretend-CUs
+    (6, 64, 128, 28, 4), (3, 64, 128, 56, 4), (9, 128, 256, 28, 4), (20, 128, 256, 14, 5), (33, 256, 512, 14, 4), (70, 256, 512, 8, 4),
+    (2, 64, 128, 4, 4), (1, 128, 256, 6, 4), (5, 192, 384, 12, 4),
+]
+
+
+@pytest.mark.parametrize("sib", [True, False])
+@pytest.mark.parametrize("case", S2D_CASES)
+def test_stride2_data_gradient_plane_window_kernel(case, sib):
+    """win9d_kernel (round 5): the data gradient of a 3x3 / stride-2 convolution as four stride-1 convolutions over the gy image, one
+    per output-parity class, run as four accumulation phases of a persistent tile with one staged gy window per (class, chunk); the
+    block's 1x1 / stride-2 downsample gradient (sib) as extra K-steps of class (0,0).  gx = mask * (dgrad3x3(g_h) [+ dgrad1x1(g_o)] +
+    resid) against torch; column sums against the stored gradient; and — with the device pretended to have 4-20 CUs — tile walks
+    of up to 15 tiles per workgroup, with every class of a tile in one workgroup or the classes split into groups over the
+    workgroups of an XCD, bit-identical to one tile per workgroup."""
+    from video_dqn_amd import ops, _lib
+    n, ci, co, h, cus = case
+    dtype = torch.bfloat16
+    ho = h // 2
+    w1 = q(rnd(72, "w1", (co, ci, 3, 3), -0.1, 0.1), dtype)
+    w2 = q(rnd(73, "w2", (co, ci, 1, 1), -0.2, 0.2), dtype)
+    g_h = q(rnd(75, "gh", (n, co, ho, ho)), dtype)
+    g_o = q(rnd(76, "go", (n, co, ho, ho)), dtype)
+    xact = q(rnd(77, "xa", (n, ci, h, h)), dtype)
+    res = q(rnd(78, "res", (n, ci, h, h)), dtype)
+    ref = F.grad.conv2d_input((n, ci, h, h), w1, g_h, 2, 1) + res
+    if sib:
+        ref = ref + F.grad.conv2d_input((n, ci, h, h), w2, g_o, 2, 0)
+    ref = ref * (xact > 0)
+    wd1 = w1.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)  # [ci][3][3][co]
+    wd2 = w2.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)  # [ci][1][1][co]
+    kw = dict(ho=h, wo=h, co=ci, r=3, s=3, stride=2, pad=1, mode=1, mask=nhwc(xact, dtype), resid=nhwc(res, dtype), want_colsum=True)
+    if sib:
+        kw.update(wt2=wd2, in2=nhwc(g_o, dtype))
+    lib = _lib.load()
+    lib.vdqn_debug_set_s2d_split(0)  # one workgroup per tile, every class in it
+    try:
+        one, part = ops.conv2d(nhwc(g_h, dtype), wd1, **kw)
+        torch.cuda.synchronize()
+        # (pretend CUs, split): tile walks of the all-classes path, of the class-group split (5 and 3 workgroups per XCD: groups of
+        # 2:2:1 and 1:1:1), and what the launcher picks by chain length on the real device
+        for pretend, split in ((cus, 0), (20, 1), (12, 1), (0, 1), (0, -1)):
+            lib.vdqn_debug_set_num_cus(pretend)
+            lib.vdqn_debug_set_s2d_split(split)
+            walk, part_w = ops.conv2d(nhwc(g_h, dtype), wd1, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(walk, one) and torch.equal(part_w, part), (pretend, split)
+    finally:
+        lib.vdqn_debug_set_num_cus(0)
+        lib.vdqn_debug_set_s2d_split(-2)
+    assert relerr(one.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    assert relerr(part.sum(0).cpu(), one.float().cpu().sum((0, 1, 2))) < 1e-4

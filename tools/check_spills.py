@@ -44,7 +44,7 @@ def check(src, min_mfma=8):
 
 
 def main():
-    srcs = sys.argv[1:] or ["win9.hip", "win9s.hip"]
+    srcs = sys.argv[1:] or ["win9.hip", "win9s.hip", "win9d.hip"]
     rc = 0
     for s in srcs:
         bad = check(s)

@@ -29,6 +29,9 @@ def tag_of(kernel_name: str):
     m = re.search(r"skinny_kernel<(\d+), (\d+), (true|false)", kernel_name)
     if m:  # the Q-head's skinny GEMMs (forward and data-gradient launches share a symbol)
         return "skinny<bf16,conv>" if m[3] == "true" else f"skinny<bf16,{m[1]}x{m[2]}>"
+    m = re.search(r"win9d_kernel<(\d+)", kernel_name)
+    if m:  # plane-window kernel of the stride-2 data gradients
+        return f"igemm_s2win<bf16,{32 * int(m[1])},dgrad>"
     m = re.search(r"win9sp?_kernel", kernel_name)
     if m:  # plane-window kernel of the stride-2 3x3 forward convolutions
         return "igemm_s2win<bf16,128,fwd>"

@@ -29,7 +29,9 @@
 
 int vdqn_stem_bf16(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int n_img, int n_idx_img, hipStream_t st);  // stem.hip
 int vdqn_launch_win9s(const void* igemm_params, hipStream_t stream);                                                              // win9s.hip
-int vdqn_win9s_supports(int cpk, int has_sib);                                                                                    // win9s.hip
+int vdqn_win9s_supports(int cpk, int has_sib);
+int vdqn_launch_win9d(const void* igemm_params, hipStream_t stream);                                                              // win9d.hip
+int vdqn_win9d_supports(int ci, int co, int has_sib, int ci2);                                                                    // win9d.hip                                                                                    // win9s.hip
 int vdqn_launch_win9m(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9m.hip
 int vdqn_launch_win9u(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9.hip
 
@@ -1707,6 +1709,15 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
       (!has_sib || (a->co2 == a->co && p.vec_ok && !a->out_f32 && !a->resid))) {
     if (group_rows > 0) return VDQN_OK;  // no grouped form: the caller runs the two row ranges as two launches of THIS kernel (same bits as two passes)
     return vdqn_launch_win9s(&p, st);
+  }
+  // data gradient of 3x3 / stride 2 / pad 1 over an even-sized image, bf16: the plane-window kernel (win9d.hip, round 5;
+  // VDQN_S2DGRAD_WIN=0 keeps the generic parity-class tiles)
+  static const int use_s2dwin = [] { const char* e = getenv("VDQN_S2DGRAD_WIN"); return e ? atoi(e) : 1; }();
+  if (use_s2dwin && mode == 2 && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->pad == 1 && a->ho == 2 * a->hi && a->wo == 2 * a->wi &&
+      a->wi >= 2 && a->wi <= 28 && a->pix_stride == a->ci && p.vec_ok && a->out && !a->out_f32 && !a->bias && !p.no_lean &&
+      p.in_bytes < 0x7fffffffLL && (long long)p.M * a->ldo * 2 < 0x7fffffffLL && (long long)a->co * p.ktot * 2 < 0x7fffffffLL &&
+      vdqn_win9d_supports(a->ci, a->co, has_sib, a->ci2)) {
+    return vdqn_launch_win9d(&p, st);
   }
   static const long long min256 = [] { const char* e = getenv("VDQN_BM256_MIN_ROWS"); return e ? atoll(e) : 256ll * 1024; }();
   if (bn == 64 && mode != 2 && p.M >= min256 && !has_sib) {
