@@ -104,8 +104,16 @@ typedef struct vdqn_conv_args {
   const void* wt_b;
   const float* bias_b;
   int32_t split_img;
+  /* Optional scratch for the split-K remainder of the bf16 nine-tap window kernel (3x3 / stride 1 / 128+ channels, mode 0 / 1):
+   * with it, the tiles behind a launch's last WHOLE round of resident workgroups are split along K over all workgroups and their
+   * f32 partial tiles summed here in a fixed order (csrc/win9.hip) — results are reproducible for a given call shape, but a split
+   * tile's f32 sum is associated differently from the unsplit kernel's.  vdqn_conv2d_splitk_workspace_bytes() bytes serve any
+   * call; the buffer needs no initialisation; calls that may run CONCURRENTLY need separate buffers.  NULL / too small = unsplit. */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
 } vdqn_conv_args;
 int vdqn_conv2d(const vdqn_conv_args* a, void* stream);
+int64_t vdqn_conv2d_splitk_workspace_bytes(void);
 /* rows of `out` covered by one entry of colsum_part for this call (what sizes that buffer): 128, or the row tile of the skinny
  * GEMM kernels that take the Q-head's bf16 linear layers (archs/HabitatDQNMultiAction.py:31; csrc/skinny.hip) */
 int32_t vdqn_conv2d_colsum_rows(const vdqn_conv_args* a);

@@ -773,3 +773,69 @@ def test_stride2_data_gradient_plane_window_kernel(case, sib):
         lib.vdqn_debug_set_s2d_split(-2)
     assert relerr(one.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
     assert relerr(part.sum(0).cpu(), one.float().cpu().sum((0, 1, 2))) < 1e-4
+
+
+SK_CASES = [  # n, channels, h, pretend-CUs (resident workgroups = 2 x CUs, a multiple of 8)
+    (6, 256, 14, 8),     # 20 tiles on 16 slots: 4 remainder tiles, one per XCD, two workgroups x 2 chunks each
+    (7, 256, 14, 12),    # 22 tiles on 24 slots ... no whole round: unsplit; kept as the "nothing to split" case
+    (16, 256, 14, 12),   # 50 tiles on 24 slots: 2 remainder tiles of 4 chunks over 3 workgroups per XCD: runs of 1, 1, 2 (odd runs)
+    (5, 128, 28, 8),     # layer2: 2 chunks per tile, 31 tiles on 16 slots: 15 remainder tiles, runs of 1-2 chunks, whole and half tiles
+    (40, 512, 7, 8),     # layer4: 8 chunks per tile, 64 tiles (4 column tiles) on 16 slots: no remainder -> unsplit
+    (43, 512, 7, 8),     # 68 tiles: 4 remainder tiles x 8 chunks over 2 workgroups per XCD: 4 chunks each
+    (45, 512, 7, 20),    # 72 tiles on 40 slots: 32 remainder tiles over 5 workgroups per XCD: runs that cross tiles, up to 3 parts per tile
+    (24, 128, 28, 20),   # 147 tiles on 40 slots: 27 remainder tiles of 2 chunks
+]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("case", SK_CASES)
+def test_nine_tap_window_kernel_split_k_remainder(case, mode):
+    """win9u_kernel<.., 3> (round 5): the tiles behind a launch's last WHOLE round of resident workgroups are split along K — each
+    workgroup of an XCD takes an equal run of the remainder's channel chunks, writes its f32 partial tile to the caller's scratch and
+    the last arriver of a tile adds the parts in part order and runs the epilogue.  Against the unsplit kernel (same bf16 outputs up
+    to the re-association of one f32 sum: a few last-bit differences at most), against torch, twice in a row bit-identically, and from a
+    scratch buffer full of garbage (the first launch clears the arrival counters).  Forward (bias + residual + ReLU) and data
+    gradient (mask + residual + column sums)."""
+    from video_dqn_amd import ops, _lib
+    n, c, h, cus = case
+    dtype = torch.bfloat16
+    lib = _lib.load()
+    x = q(rnd(81, "x", (n, c, h, h)), dtype)
+    w = q(rnd(82, "w", (c, c, 3, 3), -0.05, 0.05), dtype)
+    res = q(rnd(84, "res", (n, c, h, h)), dtype)
+    if mode == 0:
+        b = rnd(83, "b", (c,))
+        kw = dict(ho=h, wo=h, co=c, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
+        wt = krsc(w, dtype)
+        ref = F.relu(F.conv2d(x, w, b, 1, 1) + res)
+    else:
+        xact = q(rnd(85, "xa", (n, c, h, h)), dtype)
+        kw = dict(ho=h, wo=h, co=c, r=3, s=3, stride=1, pad=1, mode=1, mask=nhwc(xact, dtype), resid=nhwc(res, dtype), want_colsum=True)
+        wt = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)  # [ci][3][3][co]
+        ref = (F.grad.conv2d_input((n, c, h, h), w, x, 1, 1) + res) * (xact > 0)
+    ws = torch.empty(ops.splitk_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    lib.vdqn_debug_set_num_cus(cus)
+    lib.vdqn_debug_set_win9_splitk(2)  # split whenever there is a whole round and a remainder (the launcher's default also asks that it pays)
+    try:
+        plain = ops.conv2d(nhwc(x, dtype), wt, **kw)
+        torch.cuda.synchronize()
+        ws.fill_(0xA5)
+        a = ops.conv2d(nhwc(x, dtype), wt, splitk_ws=ws[:ops.splitk_workspace_bytes()], **kw)
+        torch.cuda.synchronize()
+        counters = ws[:4096].clone()
+        b2 = ops.conv2d(nhwc(x, dtype), wt, splitk_ws=ws[:ops.splitk_workspace_bytes()], **kw)
+        torch.cuda.synchronize()
+    finally:
+        lib.vdqn_debug_set_num_cus(0)
+        lib.vdqn_debug_set_win9_splitk(-1)
+    if mode == 1:
+        (plain, part_p), (a, part_a), (b2, part_b) = plain, a, b2
+        assert torch.equal(part_a, part_b)
+        assert relerr(part_a.sum(0).cpu(), a.float().cpu().sum((0, 1, 2))) < 1e-4
+    assert torch.equal(a, b2)
+    tiles = ((n * h * h + 127) // 128) * (c // 128)
+    if tiles > 2 * cus and tiles % (2 * cus) != 0:
+        assert (counters.view(torch.int32) == 0).all()  # every split tile was finished by its last arriver, which cleared its counter
+    d = (a.float() - plain.float()).abs()
+    assert (d > 0).float().mean().item() < 0.02 and relerr(a.float().cpu(), plain.float().cpu()) < 2e-3
+    assert relerr(a.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]

@@ -36,7 +36,10 @@ def check(src, min_mfma=8):
             seg.append(line)
             if "s_barrier" in line:
                 mf = sum("v_mfma" in l for l in seg)
-                sc = sum("scratch_" in l for l in seg)
+                # (accesses behind the segment's last matrix instruction are loop-exit code: the segment of a loop's final step
+                # runs on to the first barrier behind the loop)
+                last = max((i for i, l in enumerate(seg) if "v_mfma" in l), default=-1)
+                sc = sum("scratch_" in l for l in seg[:last + 1])
                 if mf >= min_mfma and sc:
                     bad.append((name, k, mf, sc))
                 seg, k = [], k + 1

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", f"libvdqn{'_' + os.environ['VDQN_LIB'] if os.environ.get('VDQN_LIB') else ''}.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -26,7 +26,8 @@ class ConvArgs(C.Structure):
                 ("mode", c_i32), ("relu", c_i32), ("dtype", c_i32),
                 ("in2", c_vp), ("wt2", c_vp), ("bias2", c_vp), ("out2", c_vp),
                 ("co2", c_i32), ("ldo2", c_i32), ("relu2", c_i32), ("ci2", c_i32),
-                ("wt_b", c_vp), ("bias_b", c_vp), ("split_img", c_i32)]
+                ("wt_b", c_vp), ("bias_b", c_vp), ("split_img", c_i32),
+                ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64)]
 
 
 class WgradArgs(C.Structure):
@@ -80,6 +81,7 @@ _SIGS = {
     "vdqn_profile_collect": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "vdqn_conv2d": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
     "vdqn_conv2d_colsum_rows": (c_i32, [C.POINTER(ConvArgs)]),
+    "vdqn_conv2d_splitk_workspace_bytes": (c_i64, []),
     "vdqn_conv2d_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
     "vdqn_conv2d_wgrad_workspace_bytes": (c_i64, [C.POINTER(WgradArgs)]),
     "vdqn_pack_input": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp]),

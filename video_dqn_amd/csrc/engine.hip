@@ -29,7 +29,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 11; }
+extern "C" int vdqn_abi_version(void) { return 12; }
 
 namespace {
 
@@ -81,6 +81,7 @@ struct ActLayout {
   // ARCHITECTURE='basic' only: pooled features, raw (pre-BatchNorm) conv outputs, per-layer BatchNorm work areas
   int64_t avg, r_c1, r_h[8], r_o[8], r_ds[8], bnw[kMaxLayers], bnw_begin, bnw_bytes, bn_sync;
   int64_t bn_det = -1, bn_det_bytes = 0;  // deterministic mode ('basic'): per-block partial sums of the train-mode BatchNorm kernels
+  int64_t sk = -1, sk_bytes = 0;          // scratch of the window kernel's split-K remainder (vdqn_conv_args.splitk_ws): one per pass
   int64_t total;
 };
 struct BwdLayout {
@@ -89,6 +90,7 @@ struct BwdLayout {
   int64_t p_l1, p_l0, p_f8, p_o[8], p_h[8], p_pool;  // per-128-row-tile column sums written by the dgrad epilogues
   int64_t g_avg, g_or[8], g_dsr[8];  // 'basic' only: gradient of the pooled features / of the raw conv2, downsample outputs
   int64_t det_ws, det_ws_bytes;      // deterministic mode: the weight-gradient kernels' partial copies (one layer at a time)
+  int64_t sk = -1, sk_bytes = 0;     // scratch of the window kernel's split-K remainder (data-gradient chain)
   int64_t total;
 };
 
@@ -714,6 +716,11 @@ void build_layers(vdqn_net* net) {
   }
 }
 
+// The split-K remainder of the nine-tap window kernel (win9.hip) changes how the f32 sum of a split tile is associated, by call
+// shape: the deterministic mode — whose contract includes "one 2B pass == two B passes == a grouped pass, bit for bit" — keeps the
+// unsplit kernel; f32 engines never reach that kernel.
+bool net_splitk(const vdqn_net* net);
+
 ActLayout act_layout(const vdqn_net* net, int n_samples) {
   const int64_t F = net->cfg.num_frames, n = (int64_t)n_samples * F, e = net->esz;
   ActLayout L;
@@ -771,6 +778,10 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
       L.bn_det = take(L.bn_det_bytes);
     }
   }
+  if (net_splitk(net)) {
+    L.sk_bytes = vdqn_conv2d_splitk_workspace_bytes();
+    L.sk = take(L.sk_bytes);
+  }
   L.total = off;
   return L;
 }
@@ -782,6 +793,8 @@ int64_t wgrad_max_imgs(const vdqn_net* net, const Layer& L);
 // lets one half of a batch run through forward_impl on its own stream
 ActLayout shift_layout(const vdqn_net* net, ActLayout A, int first) {
   const int64_t F = net->cfg.num_frames, e = net->esz, s = first;
+  A.sk = -1;  // (the half that runs beside the unshifted one must not share its split-K scratch)
+  A.sk_bytes = 0;
   A.t_in += s * F * 115 * 115 * 16 * e;
   A.pool += s * F * 56 * 56 * 64 * e;
   A.idx += s * F * 56 * 56 * 64;
@@ -862,6 +875,10 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
       if (b % 2 == 0 && b > 0) L.g_dsr[b] = take(n * sp * sp * planes * e);
     }
   }
+  if (net_splitk(net)) {
+    L.sk_bytes = vdqn_conv2d_splitk_workspace_bytes();
+    L.sk = take(L.sk_bytes);
+  }
   L.total = off;
   return L;
 }
@@ -921,7 +938,22 @@ int fuse_ds_mask() {
   return m;
 }
 bool fuse_ds() { return (fuse_ds_mask() & 1) != 0; }
+bool net_splitk(const vdqn_net* net) {
+  static const bool on = [] { const char* e = getenv("VDQN_WIN9_SPLITK"); return !(e && e[0] == '0'); }();
+  return on && net->cfg.dtype == VDQN_BF16 && !net->cfg.deterministic;
+}
 bool fuse_ds_fwd(int dtype) { return (fuse_ds_mask() & 2) != 0 && (dtype == VDQN_BF16 || (fuse_ds_mask() & 4) != 0); }
+
+// scratch of the pass being enqueued (forward_impl / the backward stages set it around their launches; the host enqueues one pass
+// at a time, and two passes that may RUN concurrently — online and target forward, forward halves on two streams — never share one)
+thread_local void* g_sk_ws = nullptr;
+thread_local int64_t g_sk_bytes = 0;
+struct SkScope {
+  void* prev_ws;
+  int64_t prev_bytes;
+  SkScope(void* ws, int64_t bytes) : prev_ws(g_sk_ws), prev_bytes(g_sk_bytes) { g_sk_ws = ws; g_sk_bytes = ws ? bytes : 0; }
+  ~SkScope() { g_sk_ws = prev_ws; g_sk_bytes = prev_bytes; }
+};
 
 // packed_b / split_units: grouped forward — units [split_units, n_units) run with the second network's packed weights
 int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* in, void* out, int n_units, const void* resid,
@@ -947,6 +979,7 @@ int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, c
   a.stride = L.kind == K_CONV1_S2D ? 1 : L.stride;
   a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
   a.mode = 0; a.relu = relu; a.dtype = net->cfg.dtype;
+  a.splitk_ws = g_sk_ws; a.splitk_ws_bytes = g_sk_bytes;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
   if (sib) {  // the block's 1x1 / stride-2 downsample (BatchNorm folded, no ReLU): second output of the same launch
     a.wt2 = packed + sib->wf_off;
@@ -976,6 +1009,7 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
   a.ho = L.hi; a.wo = L.wi; a.co = L.k_ci; a.ldo = L.k_ci;
   a.r = L.k_r; a.s = L.k_s; a.stride = L.stride; a.pad = L.pad;
   a.mode = 1; a.relu = 0; a.dtype = net->cfg.dtype;
+  a.splitk_ws = g_sk_ws; a.splitk_ws_bytes = g_sk_bytes;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
   if (sib) {  // + the data gradient of the block's 1x1 / stride-2 downsample, accumulated in the same tiles
     a.in2 = sib_gy;
@@ -1043,6 +1077,7 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
   // stream; `st` waits for that event in front of the first such layer (vdqn_net_td_forward folds them beside the stem)
   const int n = n_samples * net->cfg.num_frames;
   const int dt = net->cfg.dtype;
+  const SkScope sk_scope_(A.sk >= 0 ? acts + A.sk : nullptr, A.sk_bytes);
   const int n_a = packed_b ? split_samples * net->cfg.num_frames : n;  // frames of the first range
   // grad_samples >= 0: only the first grad_samples samples will see a backward pass — the stem skips the arg-max bytes of the
   // max-pool for the rest (the s' rows and the target pass of a TD update: 2/3 of its frames; VDQN_STEM_NOIDX=0 writes them all)
@@ -1647,6 +1682,7 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   const unsigned char* pk = (const unsigned char*)a->packed_online;
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
+  const SkScope sk_scope_(W.sk >= 0 ? bw + W.sk : nullptr, W.sk_bytes);
   bool split_conv1 = false;  // stage 2, extra_capacity: conv1's weight gradient is unfolded separately (see below)
   int pr_l1 = 128, pr_l0 = 128, pr_f8 = 128;  // row granularity of the head's column-sum partials (stage 0)
 

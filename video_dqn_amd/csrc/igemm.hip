@@ -33,6 +33,7 @@ int vdqn_win9s_supports(int cpk, int has_sib);
 int vdqn_launch_win9d(const void* igemm_params, hipStream_t stream);                                                              // win9d.hip
 int vdqn_win9d_supports(int ci, int co, int has_sib, int ci2);                                                                    // win9d.hip                                                                                    // win9s.hip
 int vdqn_launch_win9m(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9m.hip
+extern "C" int64_t vdqn_conv2d_splitk_workspace_bytes(void);                                                                       // win9.hip
 int vdqn_launch_win9u(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9.hip
 
 #include "igemm_common.h"
@@ -1594,6 +1595,11 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
   p.wt_b = nullptr; p.bias_b = nullptr; p.m_split = 0x7fffffff;
   static const int no_lean = [] { const char* e = getenv("VDQN_LEAN_EPILOGUE"); return (e && e[0] == '0') ? 1 : 0; }();
   p.no_lean = no_lean;
+  p.sk_cnt = nullptr; p.sk_slab = nullptr;
+  if (a->splitk_ws && a->splitk_ws_bytes >= vdqn_conv2d_splitk_workspace_bytes() && (((uintptr_t)a->splitk_ws) & 255) == 0) {
+    p.sk_cnt = reinterpret_cast<unsigned*>(a->splitk_ws);
+    p.sk_slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a->splitk_ws) + 4096);
+  }
   // grouped forward, decided per kernel below: `grp(bm)` arms it if the split is a multiple of that kernel's tile height
   auto grp = [&](int bm) {
     if (group_rows <= 0) return true;       // not a grouped call

@@ -47,6 +47,10 @@ struct IgemmParams {
   const float* bias_b;
   int m_split;
   int no_lean;  // VDQN_LEAN_EPILOGUE=0 (A/B switch): the window kernels keep igemm_epilogue where the lean one would serve
+  // split-K remainder of the nine-tap window kernel (vdqn_conv_args.splitk_ws; win9.hip): 4 KiB of per-tile arrival counters, then
+  // f32 partial tiles of 128 x 128
+  unsigned* sk_cnt;
+  float* sk_slab;
 };
 
 constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (num_records <= 0x7fffffff)

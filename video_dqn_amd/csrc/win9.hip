@@ -49,8 +49,10 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
                                                           const int bal_rows) {
   static_assert(MODE == 0 || MODE == 1, "window kernel: forward or stride-1 data gradient");
   static_assert(BM == 128 || BM == 256, "tile rows");
-  constexpr bool BAL = WALK != 0;  // 1: the full tiles of every workgroup's row range, 2 (a second launch): their partial last tiles
+  constexpr bool BAL = WALK == 1 || WALK == 2;  // 1: the full tiles of every workgroup's row range, 2 (a second launch): their partial last tiles
+  constexpr bool SK = WALK == 3;                // the launch's REMAINDER tiles (behind its whole rounds), split along K: see the SK section below
   static_assert(!BAL || (MODE == 0 && BM == 128), "balanced walk: forward, 128-row tiles");
+  static_assert(!SK || BM == 128, "split-K remainder: 128-row tiles");
   using T = bf16raw;  // (VDQN_INTERLEAVE keys on sizeof(T))
   using G = Win9Geom<BM>;
   constexpr int BN = 128, WN = 2;
@@ -103,8 +105,18 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     }
     tile_m = m0 / BM;  // (column sums are kept off this walk; the grouped forward too)
     n0 = tile_n * BN;
+  } else if constexpr (SK) {
+    // (remainder launch: total_tiles = the remainder's tile count, bal_rows = the index of its first tile; the items of this
+    // workgroup are worked out in the SK section — start from the XCD's first remainder tile so that everything below is defined)
+    if (x_count == 0) return;
+    tile_n = (int)(((uint32_t)bal_rows + x_first) % (uint32_t)p.tiles_n);
+    tile_m = (int)(((uint32_t)bal_rows + x_first) / (uint32_t)p.tiles_n);
+    n0 = tile_n * BN;
+    m0 = tile_m * BM;
   } else {
     if (lt >= x_count) return;
+    // (a launch of whole rounds in front of a split-K remainder launch clears that launch's arrival counters)
+    if (p.sk_cnt && blockIdx.x == 0 && tid < 256) reinterpret_cast<uint4*>(p.sk_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
     tile_n = (int)((x_first + lt) % (uint32_t)p.tiles_n);
     tile_m = (int)((x_first + lt) / (uint32_t)p.tiles_n);
     n0 = tile_n * BN;
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   const unsigned long long bb_ptr = (unsigned long long)(MODE == 0 && p.wt_b ? p.wt_b : p.wt);
   const i32x4 rs_b1 = {__builtin_amdgcn_readfirstlane((int)(unsigned)bb_ptr), __builtin_amdgcn_readfirstlane((int)((bb_ptr >> 32) & 0xffff)),
                        __builtin_amdgcn_readfirstlane(p.wt_bytes), 0x00020000};
-  const int m_split = (MODE == 0 && !BAL) ? p.m_split : 0x7fffffff;
+  const int m_split = (MODE == 0 && !BAL && !SK) ? p.m_split : 0x7fffffff;
   i32x4 rs_b = m0 >= m_split ? rs_b1 : rs_b0;
 
   // ---- window rows staged by this thread: j = lrow + RPP i; rows past BM + 2 W + 2 (and pixels outside the tensor) are zero.
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
       uint32_t a0_ = ab[TAP_];                                                                                           \
       if constexpr (tb_ != 0u) { /* an edge lane's tap leaves the image: read the zero row */                            \
         const bool z_ = (edge16 & (tb_ << (4 * f_))) != 0u;                                                              \
+        if constexpr (SK) asm volatile("" : "+v"(zs[f_])); /* (the remainder kernel has no room for 36 hoisted zero-row addresses) */ \
         a0_ = z_ ? ((a0_ & 255u) | zs[f_]) : a0_;                                                                        \
       }                                                                                                                  \
       const uint32_t a1_ = a0_ ^ 64u;                                                                                    \
@@ -349,6 +362,123 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
       VDQN_INTERLEAVE(8)                                                                                                 \
     } /* FCNT_ 0: a wave without rows of the range only takes part in the staging and the barriers */                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+
+
+  if constexpr (SK) {
+    // ---- split-K remainder (round 5) ----
+    // A launch of T tiles on `resident` workgroup slots costs ceil(T / resident) tile times although its last round only fills
+    // T mod resident of the slots (3.06 rounds: 4 tile times).  The launcher therefore runs the whole rounds as one launch of the
+    // kernel above and the r remaining tiles here: per XCD their r_x * cpk channel chunks (a chunk = nine K-steps) are dealt in
+    // equal contiguous runs to the XCD's workgroups, so a workgroup computes one or two ITEMS = (tile, chunks [c0, c1)).  An item
+    // that is a whole tile ends in the ordinary epilogue.  Otherwise the workgroup stores its f32 accumulators as part
+    // (w - w_first) of the tile in the scratch slab and bumps the tile's arrival counter; the LAST workgroup to arrive adds the
+    // parts IN PART ORDER (its own from the slab too: the sum does not depend on who arrives last) and runs the epilogue.
+    // Nobody waits for anybody, so it does not matter which workgroups are resident at the same time.  All parts of a tile are
+    // written and read inside one XCD; the counter operation is an agent-scope release / acquire all the same.
+    const uint32_t xb = gridDim.x >> 3, w = blockIdx.x >> 3;  // (the grid is a multiple of 8)
+    const uint32_t ucpk = (uint32_t)cpk;
+    const uint32_t U = x_count * ucpk;
+    const uint32_t u_beg = (uint32_t)(((unsigned long long)w * U) / xb), u_end = (uint32_t)(((unsigned long long)(w + 1) * U) / xb);
+    // workgroup that holds chunk u of the XCD's run: the largest w' with floor(w' U / xb) <= u
+    auto wg_of = [&](uint32_t u) { return (uint32_t)((((unsigned long long)(u + 1) * xb + U - 1) / U) - 1); };
+    __shared__ uint32_t sk_flag;
+    uint32_t u = u_beg;
+    while (u < u_end) {
+      const uint32_t j = u / ucpk;  // tile (index inside the XCD's remainder range)
+      const int c0 = (int)(u - j * ucpk);
+      const uint32_t t_end = (j + 1) * ucpk;
+      const int c1 = (int)((u_end < t_end ? u_end : t_end) - j * ucpk);
+      u = j * ucpk + (uint32_t)c1;
+      const uint32_t tile = (uint32_t)bal_rows + x_first + j;
+      tile_n = (int)(tile % (uint32_t)p.tiles_n);
+      tile_m = (int)(tile / (uint32_t)p.tiles_n);
+      n0 = tile_n * BN;
+      m0 = tile_m * BM;
+      q0 = m0 - W - 1 + lrow;
+      b_off0 = (uint32_t)(n0 + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
+      edge16 = edge_bits(m0);
+      __syncthreads();  // the previous item's LDS reads (its epilogue's scratch, the flag) are done
+      // the item's K-steps 0 and 1: window of chunk c0, weight tiles of taps 0 and 1
+      VDQN_ISSUE_B(0, c0 * 128, b_off0, rs_b)
+      VDQN_ISSUE_AW(0, c0 * 128, q0)
+      VDQN_ISSUE_B(1, tap_k + c0 * 128, b_off0, rs_b)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf) acc[f][jf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      VDQN_LOAD_FRAGS(0, 0, 0, 0)
+      const int n_ch = c1 - c0;
+      {
+        const uint32_t b_nx = b_off0;  // (behind a chunk pair: the item's next chunk — or chunks nobody reads)
+        const i32x4 rs_bn = rs_b;
+        const int q_nx = q0;
+        // the 18-step body over chunk pairs; a run with an odd chunk count leaves it after its last chunk's nine steps (what steps
+        // 7 and 8 staged ahead is read by nobody)
+        _Pragma("clang loop unroll(disable)") for (int it = 0; 2 * it < n_ch; ++it) {
+          const int cc2 = c0 + 2 * it;
+          const int so_nx = (cc2 + 2) * 128;
+          VDQN_USTEP(0, 4) VDQN_USTEP(1, 4) VDQN_USTEP(2, 4) VDQN_USTEP(3, 4) VDQN_USTEP(4, 4) VDQN_USTEP(5, 4)
+          VDQN_USTEP(6, 4) VDQN_USTEP(7, 4) VDQN_USTEP(8, 4)
+          if (2 * it + 1 >= n_ch) break;
+          VDQN_USTEP(9, 4) VDQN_USTEP(10, 4) VDQN_USTEP(11, 4)
+          VDQN_USTEP(12, 4) VDQN_USTEP(13, 4) VDQN_USTEP(14, 4) VDQN_USTEP(15, 4) VDQN_USTEP(16, 4) VDQN_USTEP(17, 4)
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      bool finish = true;
+      if (c0 != 0 || c1 != cpk) {
+        const uint32_t w_first = wg_of(j * ucpk), w_last = wg_of(t_end - 1);
+        const uint32_t n_parts = w_last - w_first + 1, part = w - w_first;
+        // part q of tile j sits in slot w_first + j + q of the XCD's 2 xb slots ((workgroup, tile) pairs are strictly ordered)
+        float4* slab = reinterpret_cast<float4*>(p.sk_slab) + ((size_t)xcd * 2 * xb + w_first + j) * (size_t)(BM * BN / 4);
+        float4* mine = slab + (size_t)part * (BM * BN / 4) + tid;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int jf = 0; jf < NF; ++jf) mine[(f * NF + jf) * G::NT] = make_float4(acc[f][jf][0], acc[f][jf][1], acc[f][jf][2], acc[f][jf][3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          unsigned* cnt = p.sk_cnt + xcd * 128u + j;
+          const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          if (old == n_parts - 1) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (clean for the next launch)
+          sk_flag = old;
+        }
+        __syncthreads();
+        finish = sk_flag == n_parts - 1;
+        if (finish) {
+          const float4* src = slab + tid;
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int jf = 0; jf < NF; ++jf) {
+              const float4 v = src[(f * NF + jf) * G::NT];
+              acc[f][jf] = (f32x4){v.x, v.y, v.z, v.w};
+            }
+          for (uint32_t q = 1; q < n_parts; ++q) {
+            src += BM * BN / 4;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+              for (int jf = 0; jf < NF; ++jf) {
+                const float4 v = src[(f * NF + jf) * G::NT];
+                acc[f][jf] += (f32x4){v.x, v.y, v.z, v.w};
+              }
+          }
+        }
+      }
+      if (finish) {
+        if (MODE == 0 && lean) lean_epilogue_128<WN>(le, acc, m0, n0, m_end, tid);
+        else if (MODE == 1 && lean_d)
+          lean_epilogue_dgrad_128<WN>(led, acc, reinterpret_cast<float*>(smem + kU_WinBase + kU_WinStride), m0, n0, tile_m, m_end, tid);
+        else igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem + kU_WinBase + kU_WinStride, m0, n0, tile_m, m_end, p.howo, W, 0, 0, p.bias);
+      }
+    }
+    return;
   }
 
   // prologue of the workgroup's FIRST tile: K-steps 0 and 1 (window of chunk 0, weight tiles of taps 0 and 1)
@@ -474,6 +604,14 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
 extern void* g_stamp_buffer;
 #endif
 
+static int g_win9_splitk_override = -1;
+extern "C" void vdqn_debug_set_win9_splitk(int v) { g_win9_splitk_override = v; }  // test hook (not part of include/vdqn.h): -1 = VDQN_WIN9_SPLITK
+static int splitk_env() {
+  static const int v = [] { const char* e = getenv("VDQN_WIN9_SPLITK"); return e ? atoi(e) : 1; }();
+  return v;
+}
+// bytes of vdqn_conv_args.splitk_ws that serve any call: 4 KiB of arrival counters + two 128 x 128 f32 parts per resident workgroup
+extern "C" int64_t vdqn_conv2d_splitk_workspace_bytes(void) { return (int64_t)4096 + (int64_t)2 * 2 * vdqn_num_cus() * (128 * 128 * 4); }
 static int g_win9_balanced_override = -1;
 extern "C" void vdqn_debug_set_win9_balanced(int v) { g_win9_balanced_override = v; }  // test hook (not part of include/vdqn.h)
 
@@ -521,8 +659,32 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
       return;
     }
   }
+  // Split-K remainder (VDQN_WIN9_SPLITK, default 1; needs vdqn_conv_args.splitk_ws): the launch's whole rounds of `resident` tiles run
+  // as before, the r tiles behind them as a second launch whose workgroups each take an equal run of the remainder's channel
+  // chunks (win9u_kernel<.., 3>).  Taken when the longest run (+ ~6 K-steps for the second launch, the items' own prologues and the
+  // reduction of the parts) is shorter than the tile it replaces.
+  if constexpr (BM == 128) {
+    const int splitk = g_win9_splitk_override >= 0 ? g_win9_splitk_override : splitk_env();
+    const unsigned whole = tiles / resident * resident, rem = tiles - whole;
+    const int cpk = p.ci / 64;
+    if (splitk && p.sk_cnt && p.sk_slab && !p.wt_b && whole > 0 && rem > 0 && resident % 8u == 0 && resident / 8u <= 64u) {
+      const unsigned run = (rem * (unsigned)cpk + resident - 1) / resident;  // chunks of the longest run
+      if (splitk >= 2 || 9 * run + 6 < 9u * (unsigned)cpk + 3) {
+        const unsigned grid1 = ((persist == 1 && whole > 2 * resident) || (persist >= 2 && whole > resident)) ? resident : whole;
+        vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM>), (size_t)G::Smem);
+        vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM, 3>), (size_t)G::Smem);
+        hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid1), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
+                           make_fastdiv((uint32_t)p.howo), whole, stamps, 0);
+        hipLaunchKernelGGL((win9u_kernel<MODE, BM, 3>), dim3(resident), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
+                           make_fastdiv((uint32_t)p.howo), rem, stamps, (int)whole);
+        return;
+      }
+    }
+  }
+  IgemmParams q = p;
+  q.sk_cnt = nullptr;  // (no remainder launch behind this one: nothing to clear)
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM>), (size_t)G::Smem);
-  hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid), dim3(G::NT), G::Smem, stream, p, wrows, make_fastdiv((uint32_t)p.wo),
+  hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid), dim3(G::NT), G::Smem, stream, q, wrows, make_fastdiv((uint32_t)p.wo),
                      make_fastdiv((uint32_t)p.howo), tiles, stamps, 0);
 }
 
