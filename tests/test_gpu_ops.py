@@ -1,6 +1,8 @@
 """Per-kernel parity: every HIP operator (through the C ABI) against the torch-CPU fp32 op it replaces.
 f32 mode gates at 1e-3 relative (north_star tolerance); bf16 mode is checked against the same reference with
 bf16-rounded operands at a bf16-appropriate tolerance."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -797,6 +799,8 @@ def test_nine_tap_window_kernel_split_k_remainder(case, mode):
     scratch buffer full of garbage (the first launch clears the arrival counters).  Forward (bias + residual + ReLU) and data
     gradient (mask + residual + column sums)."""
     from video_dqn_amd import ops, _lib
+    if os.environ.get("VDQN_WIN9_MFMA32") == "1":
+        pytest.skip("the 32x32x16 variant of the window kernel (win9m.hip) has no split-K remainder")
     n, c, h, cus = case
     dtype = torch.bfloat16
     lib = _lib.load()
@@ -837,5 +841,5 @@ def test_nine_tap_window_kernel_split_k_remainder(case, mode):
     if tiles > 2 * cus and tiles % (2 * cus) != 0:
         assert (counters.view(torch.int32) == 0).all()  # every split tile was finished by its last arriver, which cleared its counter
     d = (a.float() - plain.float()).abs()
-    assert (d > 0).float().mean().item() < 0.02 and relerr(a.float().cpu(), plain.float().cpu()) < 2e-3
+    assert (d > 0).float().mean().item() < 0.02 and relerr(a.float().cpu(), plain.float().cpu()) < 5e-3  # (one bf16 step of the largest outputs)
     assert relerr(a.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]

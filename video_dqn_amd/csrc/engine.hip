@@ -939,7 +939,7 @@ int fuse_ds_mask() {
 }
 bool fuse_ds() { return (fuse_ds_mask() & 1) != 0; }
 bool net_splitk(const vdqn_net* net) {
-  static const bool on = [] { const char* e = getenv("VDQN_WIN9_SPLITK"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = getenv("VDQN_WIN9_SPLITK"); return e && e[0] != '0'; }();  // (off by default: measured slower)
   return on && net->cfg.dtype == VDQN_BF16 && !net->cfg.deterministic;
 }
 bool fuse_ds_fwd(int dtype) { return (fuse_ds_mask() & 2) != 0 && (dtype == VDQN_BF16 || (fuse_ds_mask() & 4) != 0); }

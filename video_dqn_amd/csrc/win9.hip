@@ -382,7 +382,9 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     const uint32_t u_beg = (uint32_t)(((unsigned long long)w * U) / xb), u_end = (uint32_t)(((unsigned long long)(w + 1) * U) / xb);
     // workgroup that holds chunk u of the XCD's run: the largest w' with floor(w' U / xb) <= u
     auto wg_of = [&](uint32_t u) { return (uint32_t)((((unsigned long long)(u + 1) * xb + U - 1) / U) - 1); };
-    __shared__ uint32_t sk_flag;
+    // (the arrival flag lives in weight buffer 0, free behind an item's K loop: a static __shared__ word on top of the 80 KB of
+    // dynamic LDS would cost the second workgroup of the CU)
+    volatile uint32_t* const sk_flag = reinterpret_cast<volatile uint32_t*>(smem);
     uint32_t u = u_beg;
     while (u < u_end) {
       const uint32_t j = u / ucpk;  // tile (index inside the XCD's remainder range)
@@ -435,39 +437,53 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
         const uint32_t n_parts = w_last - w_first + 1, part = w - w_first;
         // part q of tile j sits in slot w_first + j + q of the XCD's 2 xb slots ((workgroup, tile) pairs are strictly ordered)
         float4* slab = reinterpret_cast<float4*>(p.sk_slab) + ((size_t)xcd * 2 * xb + w_first + j) * (size_t)(BM * BN / 4);
-        float4* mine = slab + (size_t)part * (BM * BN / 4) + tid;
+        // The hand-off follows MI355X_MICROARCH.md's fence-free form: EVERY store of a part is an sc1 store (written through to the
+        // memory side, the line dropped from this XCD's L2), drained (vmcnt(0) per wave, then the workgroup barrier) before the
+        // counter; EVERY load of a part is an sc1 load (never served by an L1 / a foreign L2).  An agent-scope release instead
+        // writes back ALL dirty lines of the XCD's L2 — with 512 workgroups doing it at the end of a launch that cost more than
+        // the split saved (profiles/r05v_bench_conv_splitk_fences.txt).
+        // (scalar base + one 32-bit per-lane offset: sixteen 64-bit per-lane pointers would not fit beside the accumulators)
+        const float4* const mine_u = slab + (size_t)part * (BM * BN / 4);
+        const uint32_t lane_off = (uint32_t)tid * 16u;
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
-          for (int jf = 0; jf < NF; ++jf) mine[(f * NF + jf) * G::NT] = make_float4(acc[f][jf][0], acc[f][jf][1], acc[f][jf][2], acc[f][jf][3]);
+          for (int jf = 0; jf < NF; ++jf) {
+            const uint32_t vo = lane_off + (uint32_t)((f * NF + jf) * G::NT * 16);
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(vo), "v"(acc[f][jf]), "s"(mine_u) : "memory");
+          }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
           unsigned* cnt = p.sk_cnt + xcd * 128u + j;
-          const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (old == n_parts - 1) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (clean for the next launch)
-          sk_flag = old;
+          *sk_flag = old;
         }
         __syncthreads();
-        finish = sk_flag == n_parts - 1;
+        finish = *sk_flag == n_parts - 1;
         if (finish) {
-          const float4* src = slab + tid;
-#pragma unroll
-          for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int jf = 0; jf < NF; ++jf) {
-              const float4 v = src[(f * NF + jf) * G::NT];
-              acc[f][jf] = (f32x4){v.x, v.y, v.z, v.w};
-            }
-          for (uint32_t q = 1; q < n_parts; ++q) {
-            src += BM * BN / 4;
+          const float4* src = slab;  // (uniform)
+          for (uint32_t q = 0; q < n_parts; ++q) {
+            // all sixteen loads of a part in flight before the one wait (the fragment registers are dead here): with four per wait
+            // the eight round trips to the memory side cost a tile's last arriver ~12 us
+            f32x4 v[4][NF];
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
               for (int jf = 0; jf < NF; ++jf) {
-                const float4 v = src[(f * NF + jf) * G::NT];
-                acc[f][jf] += (f32x4){v.x, v.y, v.z, v.w};
+                const uint32_t vo = lane_off + (uint32_t)((f * NF + jf) * G::NT * 16);
+                asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v[f][jf]) : "v"(vo), "s"(src) : "memory");
               }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+              for (int jf = 0; jf < NF; ++jf) {
+                asm volatile("" : "+v"(v[f][jf]));  // (the values arrive behind the wait above)
+                acc[f][jf] = q == 0 ? v[f][jf] : acc[f][jf] + v[f][jf];
+              }
+            src += BM * BN / 4;
           }
         }
       }
@@ -607,7 +623,7 @@ extern void* g_stamp_buffer;
 static int g_win9_splitk_override = -1;
 extern "C" void vdqn_debug_set_win9_splitk(int v) { g_win9_splitk_override = v; }  // test hook (not part of include/vdqn.h): -1 = VDQN_WIN9_SPLITK
 static int splitk_env() {
-  static const int v = [] { const char* e = getenv("VDQN_WIN9_SPLITK"); return e ? atoi(e) : 1; }();
+  static const int v = [] { const char* e = getenv("VDQN_WIN9_SPLITK"); return e ? atoi(e) : 0; }();
   return v;
 }
 // bytes of vdqn_conv_args.splitk_ws that serve any call: 4 KiB of arrival counters + two 128 x 128 f32 parts per resident workgroup
@@ -659,10 +675,16 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
       return;
     }
   }
-  // Split-K remainder (VDQN_WIN9_SPLITK, default 1; needs vdqn_conv_args.splitk_ws): the launch's whole rounds of `resident` tiles run
-  // as before, the r tiles behind them as a second launch whose workgroups each take an equal run of the remainder's channel
-  // chunks (win9u_kernel<.., 3>).  Taken when the longest run (+ ~6 K-steps for the second launch, the items' own prologues and the
-  // reduction of the parts) is shorter than the tile it replaces.
+  // Split-K remainder (VDQN_WIN9_SPLITK=1; default 0 = off; needs vdqn_conv_args.splitk_ws): the launch's whole rounds of `resident`
+  // tiles run as before, the r tiles behind them as a second launch whose workgroups each take an equal run of the remainder's
+  // channel chunks (win9u_kernel<.., 3>).  Taken when the longest run (+ ~6 K-steps for the second launch, the items' own
+  // prologues and the reduction of the parts) is shorter than the tile it replaces; 2: whenever there is a whole round and a
+  // remainder.  Built against the partial last rounds of the static walk and MEASURED SLOWER (rocprofv3 kernel trace,
+  // profiles/r05w_splitk_kernel_trace.txt): the last round of the unsplit launch is cheap already — its few workgroups run alone on
+  // their CUs at about twice the K-step rate of a full chip (layer3 at 512 frames: 4 rounds in 110 us where 3 whole rounds take
+  // 96.5) — while the remainder launch pays ~7 us of start-up, hand-off (64 KB of sc1 stores per part, a counter, the last
+  // arriver's reads) and epilogue on top of its K-steps: 15.6 us against ~13.5 for layer3 at 512 frames, 62.5 against ~53 for
+  // layer4 at 512 (272 remainder tiles: every workgroup holds two partial items), 49.6 against ~30 for layer3's data gradient.
   if constexpr (BM == 128) {
     const int splitk = g_win9_splitk_override >= 0 ? g_win9_splitk_override : splitk_env();
     const unsigned whole = tiles / resident * resident, rem = tiles - whole;
