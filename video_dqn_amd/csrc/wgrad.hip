@@ -287,11 +287,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
 #define WG_STEP(K, CUR, NXT)                                                                                         \
   {                                                                                                                  \
+    VDQN_GST(gst_comp)                                                                                               \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                      \
+    VDQN_GST(gst_wait)                                                                                               \
     _Pragma("unroll") for (int u_ = 0; u_ < NSUB; ++u_) _Pragma("unroll") for (int f_ = 0; f_ < NFR; ++f_)          \
         asm volatile("" : "+v"(fa[CUR][u_][f_][0]), "+v"(fa[CUR][u_][f_][1]), "+v"(fb[CUR][u_][f_][0]), "+v"(fb[CUR][u_][f_][1])); \
     __builtin_amdgcn_s_barrier();                                                                                    \
+    VDQN_GST(gst_bar)                                                                                                \
     if ((K) + 2 < nk) issue_tile((K) & 1);                                                                           \
+    VDQN_GST(gst_issue)                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     /* unconditional (the last step reads a stale buffer): one block with the MFMAs, reads issued behind them */     \
     WG_LOAD(NXT, ((K) + 1) & 1)                                                                                      \
@@ -303,6 +307,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
+#ifdef VDQN_STAMP
+    // diagnostic build (tools/stamp_wgrad.py generic): s_memtime around the phases of every K-step, summed by thread 0
+    unsigned long long gst_wait = 0, gst_bar = 0, gst_issue = 0, gst_comp = 0;
+    const unsigned long long gst_begin = __builtin_amdgcn_s_memtime(), gst_rt_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long gst_t = gst_begin;
+#define VDQN_GST(ACC) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ACC += n_ - gst_t; gst_t = n_; }
+#else
+#define VDQN_GST(ACC)
+#endif
     issue_tile(0);
     if (nk > 1) {
       issue_tile(1);
@@ -314,10 +327,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
     __builtin_amdgcn_s_barrier();
     WG_LOAD(0, 0)
+#ifdef VDQN_STAMP
+    gst_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = 0; k < nk; k += 2) {
       WG_STEP(k, 0, 1)
       if (k + 1 < nk) WG_STEP(k + 1, 1, 0)
     }
+    VDQN_GST(gst_comp)
+#ifdef VDQN_STAMP
+    if (p.stamps && tid == 0) {  // (the epilogue's end is not stamped: o[2] = loop end)
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 16;
+      o[0] = gst_begin; o[1] = gst_t; o[2] = gst_t;
+      o[3] = gst_wait; o[4] = gst_bar; o[5] = gst_issue; o[6] = gst_comp; o[7] = (unsigned long long)nk;
+      o[8] = gst_rt_begin; o[9] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+#undef VDQN_GST
 #undef WG_LOAD
 #undef WG_MFMA
 #undef WG_STEP
@@ -1000,7 +1026,8 @@ constexpr int kSpSmem = 2 * kSpPoolRow + kSpGy + kSpX;  // 76416 bytes: two work
 
 __global__ __launch_bounds__(256, 2) void stem_wgrad_pool_kernel(const bf16raw* __restrict__ g_pool, const uint8_t* __restrict__ idx,
                                                                  const bf16raw* __restrict__ x, float* __restrict__ dw, int pairs_per_block,
-                                                                 int blocks_per_img, int gp_bytes, int idx_bytes, int x_bytes, float* __restrict__ ws) {
+                                                                 int blocks_per_img, int gp_bytes, int idx_bytes, int x_bytes, float* __restrict__ ws,
+                                                                 void* stamps) {
   using T = bf16raw;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sPool = smem;                       // [2][kSpPoolRow]: pooled row r lives in slot r & 1
@@ -1135,15 +1162,29 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_pool_kernel(const bf16raw* 
   for (int f = 0; f < 4; ++f) offa[f] = row * 128 + (((((f * 16) >> 3) + (pp >> 1)) ^ sz) << 4) + ((pp & 1) << 3);
   const int offb = row * 32 + pp * 8;
 
+#ifdef VDQN_STAMP
+  // diagnostic build (tools/stamp_wgrad.py stem): per step — wait + barrier [A] | packed-row DMA issue + tile build + its waits |
+  // barrier [B] | pooled-row DMA issue + 128 MFMAs per wave (issue side)
+  unsigned long long pst_a = 0, pst_build = 0, pst_b = 0, pst_mfma = 0;
+  const unsigned long long pst_begin = __builtin_amdgcn_s_memtime(), pst_rt_begin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long pst_t = pst_begin;
+#define VDQN_PST(ACC) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ACC += n_ - pst_t; pst_t = n_; }
+#else
+#define VDQN_PST(ACC)
+#endif
   issue_pool(k0);
   issue_pool(k0 + 1);
   for (int k = k0; k < k1; ++k) {
+    VDQN_PST(pst_mfma)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // [A] pooled rows k, k + 1 are in LDS; every wave is done with the tiles and the packed rows of step k - 1
+    VDQN_PST(pst_a)
     issue_x(k);
     build(k);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    VDQN_PST(pst_build)
     __builtin_amdgcn_s_barrier();  // [B] tiles built, packed rows landed; pooled row k is no longer read
+    VDQN_PST(pst_b)
     if (k + 1 < k1) issue_pool(k + 2);
 #pragma unroll 1
     for (int hr = 0; hr < 2; ++hr) {
@@ -1174,6 +1215,17 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_pool_kernel(const bf16raw* 
       }
     }
   }
+  VDQN_PST(pst_mfma)
+#ifdef VDQN_STAMP
+  if (stamps && tid == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(stamps) + (size_t)blockIdx.x * 16;
+    o[0] = pst_begin; o[1] = pst_t; o[2] = pst_t;
+    o[3] = pst_a; o[4] = pst_b; o[5] = pst_build; o[6] = pst_mfma; o[7] = (unsigned long long)(k1 - k0);
+    o[8] = pst_rt_begin; o[9] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+#undef VDQN_PST
+  (void)stamps;
   // C layout: col (lane & 15) -> kx*16 + c, row ((lane >> 4) * 4 + reg) -> co
 #pragma unroll
   for (int f = 0; f < 4; ++f)
@@ -1444,8 +1496,12 @@ extern "C" int vdqn_stem_wgrad_pool(const void* g_pool, const uint8_t* idx, cons
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&stem_wgrad_pool_kernel), (size_t)kSpSmem);
   const double M = (double)n_img * 112 * 112;
   vdqn_prof_begin("wgrad_stem_pool<bf16>", 2.0 * M * 64 * 147, (double)gp_bytes + (double)idx_bytes + (double)x_bytes + 4.0 * 64 * 256, st);
+  void* stamps = nullptr;
+#ifdef VDQN_STAMP
+  { extern void* g_stamp_buffer; stamps = g_stamp_buffer; }
+#endif
   hipLaunchKernelGGL(stem_wgrad_pool_kernel, dim3(grid), dim3(256), kSpSmem, st, (const bf16raw*)g_pool, idx, (const bf16raw*)t_in, dw, ppb, bpi, (int)gp_bytes,
-                     (int)idx_bytes, (int)x_bytes, ws);
+                     (int)idx_bytes, (int)x_bytes, ws, stamps);
   vdqn_prof_end(st);
   VDQN_LAUNCH_CHECK();
   if (ws) {
