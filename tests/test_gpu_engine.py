@@ -729,7 +729,8 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
 @pytest.mark.parametrize("env", [
     {"VDQN_SPLIT_ONLINE": "1"},       # online forward as two half-batch passes on two streams
     {"VDQN_FUSE_POOL_BWD": "0"},      # max-pool backward + stem weight gradient as two launches
-    {"VDQN_WIN9_BM256": "2"},         # 256-row tiles of the nine-tap window kernel
+    {"VDQN_WIN9_BM256": "2"},         # 256-row tiles of the nine-tap window kernel everywhere
+    {"VDQN_WIN9_BM256": "0", "VDQN_WIN9_PERSIST256": "0"},  # ... nowhere (rounds 1-4), and their round-4 form: one workgroup per tile
     {"VDQN_FUSE_DS": "1"},            # round 4's default: the 1x1 downsample as its own forward launch (fused in the data gradient only)
     {"VDQN_FUSE_DS": "7"},            # fused in the forward pass on the generic kernel too (f32 engines)
     {"VDQN_LEAN_EPILOGUE": "0"},      # the window kernels on the shared igemm_epilogue (round 4) instead of the lean ones

@@ -609,6 +609,21 @@ def test_nine_tap_window_kernel_nonsquare(geom):
     assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
 
 
+def test_nine_tap_kernel_256_row_tiles():
+    """win9u_kernel<MODE, 256>: 256-row tiles on eight waves, one workgroup per CU, persistent above one round since round 5 (the
+    launcher picks them by the launch's round count: VDQN_WIN9_BM256=3; 2 = always).  The operator tests that reach the kernel —
+    layer2-4 geometries, edge geometries, persistent multi-tile launches with a pretended CU count (bit-identical to one workgroup
+    per tile), forward with residual + ReLU, data gradient with mask and column sums — run in a child process with every launch on
+    256-row tiles."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "(nine_tap and not both_mfma and not 256_row and not split_k and not balanced) or (test_conv_forward and bfloat16) or (test_conv_dgrad and bfloat16)"],
+                       env=dict(os.environ, VDQN_WIN9_BM256="2"), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("mfma32", ["0", "1"])
 def test_nine_tap_kernels_both_mfma_shapes(mfma32):
     """The nine-tap window kernel exists on 16x16x32 MFMAs (win9.hip) and on 32x32x16 MFMAs (win9m.hip: other fragment layout,
@@ -620,7 +635,7 @@ def test_nine_tap_kernels_both_mfma_shapes(mfma32):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "(nine_tap and not both_mfma) or (test_conv_forward and bfloat16) or (test_conv_dgrad and bfloat16)"],
+                        "-k", "(nine_tap and not both_mfma and not 256_row) or (test_conv_forward and bfloat16) or (test_conv_dgrad and bfloat16)"],
                        env=dict(os.environ, VDQN_WIN9_MFMA32=mfma32), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
 
@@ -713,12 +728,14 @@ def test_nine_tap_window_kernel_balanced_walk(case):
     torch.cuda.synchronize()
     lib.vdqn_debug_set_num_cus(cus)
     lib.vdqn_debug_set_win9_balanced(1)  # (off by default since it measured slower: DESIGN.md section 6d)
+    lib.vdqn_debug_set_win9_bm256(0)     # (the walk exists for 128-row tiles)
     try:
         bal = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), **kw)
         torch.cuda.synchronize()
     finally:
         lib.vdqn_debug_set_num_cus(0)
         lib.vdqn_debug_set_win9_balanced(-1)
+        lib.vdqn_debug_set_win9_bm256(-1)
     assert torch.equal(bal, one)
     assert relerr(one.float().cpu().permute(0, 3, 1, 2), F.relu(F.conv2d(x, w, b, 1, 1) + res)) < TOL[dtype]
 
@@ -801,6 +818,7 @@ def test_nine_tap_window_kernel_split_k_remainder(case, mode):
     from video_dqn_amd import ops, _lib
     if os.environ.get("VDQN_WIN9_MFMA32") == "1":
         pytest.skip("the 32x32x16 variant of the window kernel (win9m.hip) has no split-K remainder")
+    # (the launcher's own choice of 256-row tiles — which have no split-K remainder either — is switched off for this test's calls)
     n, c, h, cus = case
     dtype = torch.bfloat16
     lib = _lib.load()
@@ -820,6 +838,7 @@ def test_nine_tap_window_kernel_split_k_remainder(case, mode):
     ws = torch.empty(ops.splitk_workspace_bytes(), dtype=torch.uint8, device=DEV)
     lib.vdqn_debug_set_num_cus(cus)
     lib.vdqn_debug_set_win9_splitk(2)  # split whenever there is a whole round and a remainder (the launcher's default also asks that it pays)
+    lib.vdqn_debug_set_win9_bm256(0)   # (128-row tiles: the 256-row form has no split-K remainder)
     try:
         plain = ops.conv2d(nhwc(x, dtype), wt, **kw)
         torch.cuda.synchronize()
@@ -832,6 +851,7 @@ def test_nine_tap_window_kernel_split_k_remainder(case, mode):
     finally:
         lib.vdqn_debug_set_num_cus(0)
         lib.vdqn_debug_set_win9_splitk(-1)
+        lib.vdqn_debug_set_win9_bm256(-1)
     if mode == 1:
         (plain, part_p), (a, part_a), (b2, part_b) = plain, a, b2
         assert torch.equal(part_a, part_b)

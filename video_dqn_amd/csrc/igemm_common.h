@@ -295,6 +295,7 @@ struct LeanEpiD {
   __amdgpu_buffer_rsrc_t out, res, msk;
   float* colsum_part;
   int ldo, has_res, has_msk, co;
+  int rows;  // rows of `out` (the last 256-row tile of a launch may hold one 128-row half only: one column-sum entry)
 };
 __device__ __forceinline__ LeanEpiD make_lean_epi_d(void* out, const void* resid, const void* mask, float* colsum_part, long long rows, int ldo, int co) {
   LeanEpiD e;
@@ -304,11 +305,14 @@ __device__ __forceinline__ LeanEpiD make_lean_epi_d(void* out, const void* resid
   e.msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mask), 0, mask ? bytes : 0, 0x00020000);
   e.colsum_part = colsum_part;
   e.ldo = ldo; e.has_res = resid != nullptr; e.has_msk = mask != nullptr; e.co = co;
+  e.rows = (int)rows;
   return e;
 }
 // NF = 16-wide channel fragments per wave (4: 128-column tiles, 2: 64-column tiles; WN = 2 waves along N either way).  off[f]: byte
 // offset of the lane's pixel f in out / resid / mask at channel ncol, kOob for rows that do not exist.
-template <int NF>
+// NWR = wave rows of the workgroup (2: 128-row tiles; 4: 256-row tiles, whose two 128-row halves write entries 2 tile_m and 2 tile_m + 1
+// of the column sums; scratch: NWR x BN floats)
+template <int NF, int NWR = 2>
 __device__ __forceinline__ void lean_epilogue_dgrad(const LeanEpiD& e, f32x4 (&acc)[4][NF], float* scratch, const uint32_t (&off)[4], int n0, int tile_m, int tid) {
   constexpr int CPL = 4 * NF, BN = 32 * NF, V = CPL / 8;  // channels per lane, tile columns, 16-byte vectors per pixel
   const int lane = tid & 63, wave = tid >> 6;
@@ -373,10 +377,16 @@ __device__ __forceinline__ void lean_epilogue_dgrad(const LeanEpiD& e, f32x4 (&a
       for (int k = 0; k < CPL; ++k) scratch[wr * BN + wc * (BN / 2) + g * CPL + k] = cs[k];
     }
     __syncthreads();
-    if (tid < BN && n0 + tid < e.co) e.colsum_part[(size_t)tile_m * e.ldo + n0 + tid] = scratch[tid] + scratch[BN + tid];
+    if constexpr (NWR == 2) {
+      if (tid < BN && n0 + tid < e.co) e.colsum_part[(size_t)tile_m * e.ldo + n0 + tid] = scratch[tid] + scratch[BN + tid];
+    } else {
+      const int half = tid / BN, col = tid - half * BN;
+      if (tid < (NWR / 2) * BN && n0 + col < e.co && (tile_m * (NWR / 2) + half) * 128 < e.rows)
+        e.colsum_part[(size_t)(tile_m * (NWR / 2) + half) * e.ldo + n0 + col] = scratch[2 * half * BN + col] + scratch[(2 * half + 1) * BN + col];
+    }
   }
 }
-template <int WN>
+template <int WN, int NWR = 2>
 __device__ __forceinline__ void lean_epilogue_dgrad_128(const LeanEpiD& e, f32x4 (&acc)[4][128 / (16 * WN)], float* scratch, int m0, int n0, int tile_m,
                                                         int rows_end, int tid) {
   static_assert(WN == 2, "64 x 64 wave tiles: 16 consecutive channels per lane");
@@ -388,7 +398,7 @@ __device__ __forceinline__ void lean_epilogue_dgrad_128(const LeanEpiD& e, f32x4
     const int m = m0 + (wave >> 1) * 64 + f * 16 + (lane & 15);
     off[f] = m < rows_end ? (uint32_t)(m * e.ldo + ncol) * 2u : kOob;
   }
-  lean_epilogue_dgrad<4>(e, acc, scratch, off, n0, tile_m, tid);
+  lean_epilogue_dgrad<4, NWR>(e, acc, scratch, off, n0, tile_m, tid);
 }
 
 #define VDQN_INTERLEAVE(N)                                  \

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
   // copies, ragged rows and every data-gradient operand combination keep igemm_epilogue
   const bool lean = MODE == 0 && !p.no_lean && p.co % BN == 0 && p.vec_ok && p.out && !p.out_f32 && !p.colsum_part && !p.mask && p.bias && !p.wt_b &&
                     (((uintptr_t)p.bias) & 15) == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
-  const bool lean_d = MODE == 1 && BM == 128 && !p.no_lean && p.vec_ok && p.out && !p.out_f32 && !p.bias && p.co % BN == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
+  const bool lean_d = MODE == 1 && !p.no_lean && p.vec_ok && p.out && !p.out_f32 && !p.bias && p.co % BN == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
   const LeanEpiD led = make_lean_epi_d(p.out, p.resid, p.mask, p.colsum_part, lean_d ? p.M : 0, p.ldo, p.co);
   const LeanEpi le = make_lean_epi(p.out, p.resid, p.bias, (BAL || lean) ? p.M : 0, p.ldo, p.co, p.relu);
   f32x4 acc[4][NF];
@@ -550,8 +550,8 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
       lean_epilogue_128<WN>(le, acc, m0, n0, m_end, tid);
     } else {
       if (MODE == 0 && lean) lean_epilogue_128<WN>(le, acc, m0, n0, m_end, tid);
-      else if (MODE == 1 && BM == 128 && lean_d)
-        lean_epilogue_dgrad_128<WN>(led, acc, reinterpret_cast<float*>(smem + kU_WinBase + kU_WinStride), m0, n0, tile_m, m_end, tid);
+      else if (MODE == 1 && lean_d)
+        lean_epilogue_dgrad_128<WN, BM / 64>(led, acc, reinterpret_cast<float*>(smem + kU_WinBase + kU_WinStride), m0, n0, tile_m, m_end, tid);
       else igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem + kU_WinBase + kU_WinStride, m0, n0, tile_m, m_end, p.howo, W, 0, 0,
                                                m0 >= m_split ? p.bias_b : p.bias);
     }
@@ -620,6 +620,8 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
 extern void* g_stamp_buffer;
 #endif
 
+static int g_win9_bm256_override = -1;
+extern "C" void vdqn_debug_set_win9_bm256(int v) { g_win9_bm256_override = v; }  // test hook: -1 = VDQN_WIN9_BM256
 static int g_win9_splitk_override = -1;
 extern "C" void vdqn_debug_set_win9_splitk(int v) { g_win9_splitk_override = v; }  // test hook (not part of include/vdqn.h): -1 = VDQN_WIN9_SPLITK
 static int splitk_env() {
@@ -654,7 +656,9 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
   const int balanced = g_win9_balanced_override >= 0 ? g_win9_balanced_override : balanced_env;
   const unsigned resident = (unsigned)((BM == 128 ? 2 : 1) * vdqn_num_cus());
   int bal_rows = 0;
-  unsigned grid = (BM == 128 && ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident))) ? resident : tiles;  // (256-row tiles: one workgroup per tile)
+  // (256-row tiles, one workgroup per CU: persistent above one round — VDQN_WIN9_PERSIST256=0: one workgroup per tile, as before round 5)
+  static const int persist256 = [] { const char* e = getenv("VDQN_WIN9_PERSIST256"); return e ? atoi(e) : 1; }();
+  unsigned grid = ((BM == 128 || persist256) && ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident) || (BM == 256 && persist256 && tiles > resident))) ? resident : tiles;
   const bool lean_ok = !p.no_lean && p.co % 128 == 0 && p.vec_ok && p.out && !p.out_f32 && !p.mask && p.bias && (((uintptr_t)p.bias) & 15) == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
   if (BM == 128 && MODE == 0 && balanced && lean_ok && !p.colsum_part && !p.wt_b && (tiles > resident || balanced >= 2) && p.tiles_n > 0 &&
       resident % (8u * (unsigned)p.tiles_n) == 0 && resident / (unsigned)p.tiles_n >= 8u) {
@@ -712,10 +716,23 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
 
 int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
   const IgemmParams& p = *reinterpret_cast<const IgemmParams*>(pv);
-  // VDQN_WIN9_BM256: 1 = 256-row tiles wherever the launch has more 128-row tiles than the chip holds at once (two per CU),
-  // 2 = always, 0 = never
-  static const int bm256 = [] { const char* e = getenv("VDQN_WIN9_BM256"); return e ? atoi(e) : 0; }();
-  const bool big = bm256 == 2 || (bm256 == 1 && (long long)p.tiles_m * p.tiles_n > 2ll * vdqn_num_cus());
+  // VDQN_WIN9_BM256: 256-row tiles (eight waves, ONE workgroup per CU: a K-step stages 16 KB of weights for 256 rows instead of
+  // for 128 — 21 instead of 37 KB per CU and step).  Per K-step they are the faster form from four channel chunks on, but a launch
+  // of r rounds costs them ceil(r) full rounds, while the 128-row tiles' last partial round is cheap (its workgroups run alone on
+  // their CUs): measured per layer and batch (profiles/r05z_bench_conv_*.txt) they win where the fractional part of
+  // r = tiles / resident is >= ~0.5 (layer4 at 256 / 512 frames: +4 / +8 %, layer3 at 256 / 768: +6 / +7 %) and lose where it is small
+  // (layer3 at 512 frames, 3.06 rounds: -9 %; layer4 at 768, 2.30: -9 %) and on layer2 (two chunks) everywhere.
+  // 3 (default) = by that rule, 2 = always, 1 = wherever the launch has more 128-row tiles than the chip holds at once, 0 = never
+  static const int bm256_env = [] { const char* e = getenv("VDQN_WIN9_BM256"); return e ? atoi(e) : 3; }();
+  const int bm256 = g_win9_bm256_override >= 0 ? g_win9_bm256_override : bm256_env;
+  bool big = bm256 == 2 || (bm256 == 1 && (long long)p.tiles_m * p.tiles_n > 2ll * vdqn_num_cus());
+  // (the data gradient's 256-row tiles got the lean epilogue with this rule: on the shared igemm_epilogue they measured 0.617 vs
+  // 0.612 ms in the update although the bare kernel is 3-5 % faster, profiles/r06a_ab_bm256_auto_vs_128.txt)
+  if (bm256 == 3 && p.ci >= 256 && !p.wt_b) {
+    const double r = (double)p.tiles_m * p.tiles_n / (2.0 * vdqn_num_cus());  // rounds of the 128-row tiles (p.tiles_m counts those)
+    const double frac = r - (double)(long long)r;
+    big = r >= 0.7 && frac >= 0.45;
+  }
   void* stamps = nullptr;
 #ifdef VDQN_STAMP
   stamps = g_stamp_buffer;
