@@ -195,6 +195,40 @@ def test_conv_wgrad(case, dtype, splitk):
     assert relerr(db.cpu()[:co], gy.sum((0, 2, 3))) < TOL_F32OUT[dtype]
 
 
+S2W_CASES = [  # n, ci, co, h (even): 3x3 / stride 2 / pad 1 with 128+ channels on both sides -> wgrad_win_kernel<128, 128, 8, true>
+    (5, 256, 512, 14), (2, 128, 256, 28), (9, 128, 128, 4), (3, 128, 256, 8), (1, 256, 128, 56), (21, 128, 128, 6), (2, 128, 384, 12),
+]
+
+
+@pytest.mark.parametrize("splitk", [0, 1, 5])
+@pytest.mark.parametrize("case", S2W_CASES)
+def test_conv_wgrad_stride2_window_kernel(case, splitk):
+    """Weight gradient of the 3x3 / stride-2 convolutions (conv1 of layer3.0 / layer4.0's geometry) on the stride-2 window tiles
+    (round 5; VDQN_WGRAD_S2WIN=1 — off by default, it measured slower than the generic kernel): one staged window of the kernel row's input rows serves its three taps at a stride of two window rows per pixel.
+    Against torch — images of 2 x 2 to 28 x 28 output pixels (windows that span many images, left-column and top-row borders in
+    almost every fragment), co != ci, pixel ranges split 1 / 5 ways — and in deterministic mode twice, bit for bit."""
+    from video_dqn_amd import ops, _lib
+    n, ci, co, h = case
+    dtype = torch.bfloat16
+    ho = h // 2
+    x = q(rnd(91, "x", (n, ci, h, h)), dtype)
+    gy = q(rnd(92, "gy", (n, co, ho, ho)), dtype)
+    ref = F.grad.conv2d_weight(x, (co, ci, 3, 3), gy, 2, 1)
+    kw = dict(co=co, r=3, s=3, stride=2, pad=1, splitk=splitk, want_dbias=False)
+    lib = _lib.load()
+    gen = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), **kw)  # the generic kernel (what ships: the window form measured slower)
+    lib.vdqn_debug_set_wgrad_s2win(1)
+    try:
+        dw = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), **kw)
+        d1 = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), deterministic=True, poison_workspace=True, **kw)
+        d2 = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), deterministic=True, poison_workspace=True, **kw)
+        torch.cuda.synchronize()
+    finally:
+        lib.vdqn_debug_set_wgrad_s2win(-1)
+    assert relerr(dw.cpu()[:co].permute(0, 3, 1, 2), ref) < TOL_F32OUT[dtype]
+    assert torch.equal(d1, d2) and relerr(d1, dw) < 1e-5 and relerr(gen, dw) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(3, 64, 100, 9, 3, 1, 1), (2, 128, 15, 6, 1, 1, 0), (2, 128, 130, 8, 3, 2, 1)])
 def test_conv_wgrad_deterministic_with_ragged_co(case, dtype):

@@ -431,7 +431,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 constexpr int kWgZeroBytes = 16 * 256 + 256;  // wgrad_win: zero block (covers the +16-row immediate of high-half reads for 128- and 256-byte rows)
 constexpr int kWgCodeBytes = 3200;            // border-code table: images up to 56 x 56
 
-template <int BCO, int BCI, int NW>
+// S2 (round 5; eight waves): the 3x3 / STRIDE-2 / pad-1 layers over even-sized images.  Output pixel p = (q, x) (q = img * ho + y over the
+// stacked images) reads input pixel (2 q + kr - 1, 2 x + ks - 1).  The input rows a kernel row kr touches — every second row of the
+// stacked input — laid end to end form a sequence U = q * 2 wo + column in which tap ks of pixel p sits at U = 2 p + ks - 1: linear
+// in p with stride 2.  So the window of a K-step is the 2 KP + 2 consecutive elements of that sequence from 2 kb - 1 on (staged with
+// one division per DMA piece and lane: sequence element -> memory pixel), tap ks of tile pixel r reads window row 2 r + ks, and the
+// only borders are the top image row for kr = 0 and the left column for ks = 0.  The generic kernel restaged gy AND x for every
+// tap (stamps: 945-1067 of ~2,000 cycles per K tile in the DMA issue, profiles/r05y_stamp_wgrad_generic.txt).
+template <int BCO, int BCI, int NW, bool S2 = false>
 __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams p) {
   typedef bf16raw T;
   constexpr int E16 = 8;
@@ -445,11 +452,14 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   // group of four MFMAs waited lgkmcnt(0) for its own fragment pair, and five registers spilled into the K loop.)
   constexpr bool WSPLIT = (BCO == 64 && BCI == 64);
   static_assert(NW == 4 || (NW == 8 && BCO == 128 && BCI == 128), "8 waves: the 128 x 128 tile");
+  static_assert(!S2 || NW == 8, "stride-2 windows: the eight-wave tile");
   constexpr bool PIPE = WSPLIT || NW == 8;         // software-pipelined fragment stream (see compute)
-  constexpr int KSUB = PIPE ? 4 : 2;
+  constexpr int KSUB = PIPE ? (S2 ? 2 : 4) : 2;    // (stride 2: the window is twice as long per pixel — 64 pixels per K-step keep the tile in LDS)
   constexpr int KP = 32 * KSUB;
   constexpr int NLG = (KP * CPRG) / NT;
-  constexpr int WR = KP + 8;                       // window rows (KP + 2 needed)
+  constexpr int WR = S2 ? 2 * KP + 8 : KP + 8;     // window rows (KP + 2 / 2 KP + 2 needed)
+  constexpr int HI = (S2 ? 32 : 16) * RBX;         // LDS distance of a transposing read's high half (16 tile pixels further on)
+  constexpr int ZBYTES = S2 ? 32 * RBX + 256 : kWgZeroBytes;
   constexpr int NLX = (WR * CPRX + NT - 1) / NT;   // 16-byte slots per thread for the window (the last pass is partial)
   constexpr int WCOLS = WSPLIT ? 2 : NW / 2;       // wave grid: 2 output-channel halves (1 for WSPLIT) x WCOLS input-channel parts
   constexpr int NFA = WSPLIT ? 4 : BCO / 32;       // 16-wide fragments per wave: output channels
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   unsigned char* sA = smem;                         // [2][KP * RBG]   gy tiles
   unsigned char* sX = smem + 2 * KP * RBG;          // [2][WR * RBX]   x windows
   unsigned char* sZ = sX + 2 * WR * RBX;            // [kWgZeroBytes]  zeros at +0 and at +16 rows (every LDS bank once each; a multiple of 256 from smem)
-  unsigned char* sCode = sZ + kWgZeroBytes;         // [kWgCodeBytes]  PIPE: border code of every pixel position of an image
+  unsigned char* sCode = sZ + ZBYTES;               // [kWgCodeBytes]  PIPE: border code of every pixel position of an image
   static_assert((2 * KP * RBG) % 256 == 0 && (WR * RBX) % 256 == 0, "window buffers and the zero block sit at 256-byte boundaries");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   const int nk = (kend - kbeg + KP - 1) / KP;
   // zeros: [0, 256) for the low-half reads of border lanes and [16 RBX, 16 RBX + 256) for their high-half reads, which carry the
   // same +16-row immediate as the reads of the window (so one select serves an address pair)
-  for (int i = tid; i < 32; i += NT) reinterpret_cast<uint4*>(sZ + (i >> 4) * (16 * RBX))[i & 15] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 32; i += NT) reinterpret_cast<uint4*>(sZ + (i >> 4) * HI)[i & 15] = make_uint4(0, 0, 0, 0);
   const int howo = (int)p.d_howo.div;
   if constexpr (PIPE) {
     // border code of image position rem = oh * W + ow: 1 top row, 2 bottom row, 4 left column, 8 right column.  One table per
@@ -514,7 +524,11 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   // slot q = tid + 256 i of a staged tile is row q / CPR + (256 / CPR) i with the SAME source chunk for every i (the swizzle keys
   // repeat every 8 rows), so one per-lane offset per operand serves all pieces and the piece's row block is a scalar
   const uint32_t g_lane = (uint32_t)(tid / CPRG) * ldg_b + (uint32_t)((co0 + ((tid % CPRG) ^ wg_swz<T, BCO>(tid / CPRG)) * E16) * 2);
-  const uint32_t x_lane = (uint32_t)(tid / CPRX) * pix_b + (uint32_t)((ci0 + ((tid % CPRX) ^ wg_swz<T, BCI>(tid / CPRX)) * E16) * 2);
+  // (stride 2: window rows 2 j and 2 j + 1 share a swizzle key, so that the rows 2 r + ks a tap reads carry eight different keys)
+  const int x_key = S2 ? wg_swz<T, BCI>((tid / CPRX) >> 1) : wg_swz<T, BCI>(tid / CPRX);
+  const uint32_t x_chunk = (uint32_t)((ci0 + ((tid % CPRX) ^ x_key) * E16) * 2);
+  const uint32_t x_lane = (uint32_t)(tid / CPRX) * pix_b + x_chunk;
+  static_assert(!S2 || (NT / CPRX) % 16 == 0, "stride 2: the halved row index repeats its key over the pieces of one thread too");
   static_assert((NT / CPRG) % 8 == 0 && (NT / CPRX) % 8 == 0, "swizzle keys repeat over the pieces of one thread");
   const int x_shift = (kr - 1) * p.wo - 1;  // window row j = pixel kb + j + x_shift
 
@@ -527,7 +541,16 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     } else {
       const int ix = i - NLG;
       if (ix == NLX - 1 && wave_u >= X_TAIL_WAVES) return;
-      const uint32_t vx = x_lane + (uint32_t)(kb + x_shift + (NT / CPRX) * ix) * pix_b;  // may wrap below zero: out of range, zero-filled
+      uint32_t vx;
+      if constexpr (S2) {
+        // window row j = element U = 2 kb - 1 + j of the kernel row's input-row sequence -> memory pixel U + (U / 2 wo + kr - 1) 2 wo
+        const int U = 2 * kb - 1 + tid / CPRX + (NT / CPRX) * ix;
+        const int qrow = U >= 0 ? (int)fastdiv((uint32_t)U >> 1, p.d_wo) : 0;
+        const int mem = U + (qrow + kr - 1) * 2 * p.wo;
+        vx = (U >= 0 && mem >= 0) ? x_chunk + (uint32_t)mem * pix_b : kOobW;  // (past the tensor: beyond the descriptor's range, zero-filled)
+      } else {
+        vx = x_lane + (uint32_t)(kb + x_shift + (NT / CPRX) * ix) * pix_b;  // may wrap below zero: out of range, zero-filled
+      }
       const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RBG + buf * (WR * RBX) + ix * (NT * 16));
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vx), "s"(lx), "s"(rs_x) : "memory");
     }
@@ -604,7 +627,9 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   bool zb[NSUBW][3][2];    // zb[i][ks][hh]: tap ks of kernel row kr leaves the image for that pixel (lane masks in scalar registers)
   const uint32_t lds_smem = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const uint32_t z_base = lds_smem + (uint32_t)(sZ - smem);
-  const uint32_t vmask = kr == 0 ? 1u : (kr == 2 ? 2u : 0u);  // border code bits that put the whole kernel row outside
+  // border code bits that put the whole kernel row outside (stride 2 over an even-sized image: only the top row for kr = 0 —
+  // input row 2 y + 1 <= 2 ho - 1 always exists)
+  const uint32_t vmask = kr == 0 ? 1u : ((kr == 2 && !S2) ? 2u : 0u);
   const uint32_t kp_mod = (uint32_t)(KP % howo);
   auto masks_from_rem = [&](int i) {
     uint32_t c[2];
@@ -614,7 +639,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     for (int hh = 0; hh < 2; ++hh) {
       zb[i][0][hh] = (c[hh] & (vmask | 4u)) != 0u;  // kernel row outside, or left column with tap 0
       zb[i][1][hh] = (c[hh] & vmask) != 0u;
-      zb[i][2][hh] = (c[hh] & (vmask | 8u)) != 0u;  // ... or right column with tap 2
+      zb[i][2][hh] = (c[hh] & (vmask | (S2 ? 0u : 8u))) != 0u;  // ... or right column with tap 2 (stride 2: column 2 wo - 1 exists)
     }
   };
   auto advance_rem = [&](int i) {  // the same pixels of the next K tile: KP positions further on, modulo the image
@@ -635,8 +660,8 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     for (int i = 0; i < NSUBW; ++i) {
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const int jr = (sub0 + i) * 32 + row + ks;
-        const int szX = wg_swz<T, BCI>(jr);
+        const int jr = S2 ? 2 * ((sub0 + i) * 32 + row) + ks : (sub0 + i) * 32 + row + ks;
+        const int szX = S2 ? wg_swz<T, BCI>(jr >> 1) : wg_swz<T, BCI>(jr);
 #pragma unroll
         for (int j = 0; j < NFB; ++j) {
           const int cb = wc * (16 * NFB) + j * 16;
@@ -686,7 +711,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
         const uint32_t xaddr = off + xbuf;
         const uint32_t zaddr = z_base | ((off - lds_smem) & 255u);  // the lane's own bank position inside the zero block (z_base is a multiple of 256)
         const uint32_t a0 = zb[sb][ks][0] ? zaddr : xaddr, a1 = zb[sb][ks][1] ? zaddr : xaddr;
-        const s16x4 lo = lds_tr(a0, 0), hi = lds_tr(a1, 16 * RBX);
+        const s16x4 lo = lds_tr(a0, 0), hi = lds_tr(a1, HI);
         return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       };
 #pragma unroll
@@ -1274,16 +1299,18 @@ int launch_stem_wgrad(const WgradParams& p, hipStream_t stream) {
   return VDQN_OK;
 }
 
-template <int BCO, int BCI, int NW = 4>
+template <int BCO, int BCI, int NW = 4, bool S2 = false>
 int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
-  constexpr int KP = 32 * (((BCO == 64 && BCI == 64) || NW == 8) ? 4 : 2);
-  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * (KP + 8)) * BCI * 2 + kWgZeroBytes + kWgCodeBytes;  // gy tiles, x windows, zeros, border codes
+  constexpr int KP = 32 * (S2 ? 2 : (((BCO == 64 && BCI == 64) || NW == 8) ? 4 : 2));
+  constexpr int WR = S2 ? 2 * KP + 8 : KP + 8;
+  constexpr int ZB = S2 ? 32 * BCI * 2 + 256 : kWgZeroBytes;
+  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * WR) * BCI * 2 + ZB + kWgCodeBytes;  // gy tiles, x windows, zeros, border codes
   const size_t smem_epi = (BCO == 64 && BCI == 64) ? (size_t)2 * 64 * 64 * 4 : (size_t)BCO * BCI * 4;
   const size_t smem = smem_stage > smem_epi ? smem_stage : smem_epi;
-  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI, NW>), (size_t)smem);
-  vdqn_prof_begin(NW == 8 ? "wgrad_win<bf16,128>" : (BCO == 128 ? "wgrad_win<bf16,128x64>" : "wgrad_win<bf16,64>"), 2.0 * p.M * p.co * p.taps * p.ci,
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI, NW, S2>), (size_t)smem);
+  vdqn_prof_begin(S2 ? "wgrad_s2win<bf16,128>" : (NW == 8 ? "wgrad_win<bf16,128>" : (BCO == 128 ? "wgrad_win<bf16,128x64>" : "wgrad_win<bf16,64>")), 2.0 * p.M * p.co * p.taps * p.ci,
                   2.0 * ((double)p.M * p.ldg + (double)p.n_img * p.hi * p.wi * p.ci) + 4.0 * p.co * p.taps * p.ci, stream);
-  hipLaunchKernelGGL((wgrad_win_kernel<BCO, BCI, NW>), dim3(tiles * splitk), dim3(64 * NW), smem, stream, p);
+  hipLaunchKernelGGL((wgrad_win_kernel<BCO, BCI, NW, S2>), dim3(tiles * splitk), dim3(64 * NW), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
@@ -1291,11 +1318,13 @@ int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t st
 
 // Which kernel a call runs on and how its pixel range is split (shared by the launch and by the workspace-size query).
 struct WgradPlan {
-  int variant;      // 0 stem kernel, 1 window 64x64, 2 window 128x64, 3 generic, 4 window 128x128 (eight waves)
+  int variant;      // 0 stem kernel, 1 window 64x64, 2 window 128x64, 3 generic, 4 window 128x128 (eight waves), 5 stride-2 window 128x128 (eight waves)
   int bt, ci_tiles, tiles, splitk, kchunk;
   int copies;       // partial copies of dw the deterministic mode stores (active splits, or blocks of the stem kernel)
   long long copy_elems;  // floats per copy
 };
+
+int g_wgrad_s2win_override = -1;  // tests: vdqn_debug_set_wgrad_s2win
 
 int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
   VDQN_CHECK(a != nullptr, "vdqn_conv2d_wgrad: null args");
@@ -1355,7 +1384,24 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
   static const int use_win128 = [] { const char* e = getenv("VDQN_WGRAD_WIN128"); return e ? atoi(e) : 0; }();
   const bool win_geom = a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && a->pix_stride == a->ci && a->wo >= 2 &&
                         a->hi == a->ho && a->wi == a->wo && a->ho * a->wo <= kWgCodeBytes;  // (border-code table of one image in LDS)
-  if (use_win && use_win128 && use_win < 3 && win_geom && co_pad % 128 == 0 && a->ci % 128 == 0) {
+  // VDQN_WGRAD_S2WIN=1 (default 0): the 3x3 / stride-2 layers with 128+ channels on both sides (layer3.0, layer4.0 conv1) on the stride-2
+  // window tiles (wgrad_win_kernel<128, 128, 8, true>) instead of the generic kernel.  Built on the generic kernel's stamps (half of a
+  // K tile in the DMA issue) and MEASURED SLOWER: 0.146 vs 0.120 ms per update for the two launches (0.154 with 128 blocks;
+  // profiles/r06e_ab_wgrad_s2win_vs_generic.txt): at one 109 KB workgroup per CU nothing covers the tile's barriers, and the
+  // launches stay dominated by what they share with the generic kernel — 33-50 MB of f32 atomics for a 1.2-4.7 MB gradient.
+  static const int use_s2win_env = [] { const char* e = getenv("VDQN_WGRAD_S2WIN"); return e ? atoi(e) : 0; }();
+  const int use_s2win = g_wgrad_s2win_override >= 0 ? g_wgrad_s2win_override : use_s2win_env;
+  const bool s2_geom = a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 2 && a->pad == 1 && a->pix_stride == a->ci && a->wo >= 2 &&
+                       a->hi == 2 * a->ho && a->wi == 2 * a->wo && a->ho * a->wo <= kWgCodeBytes && co_pad % 128 == 0 && a->ci % 128 == 0 && M64 < (1 << 22);
+  if (use_s2win && s2_geom) {
+    pl->variant = 5;
+    pl->ci_tiles = a->ci / 128;
+    pl->tiles = (co_pad / 128) * 3 * pl->ci_tiles;
+    static const int target_s2 = [] { const char* e = getenv("VDQN_WGRAD_S2WIN_BLOCKS"); return e ? atoi(e) : 256; }();  // one workgroup per CU
+    splitk = a->splitk > 0 ? a->splitk : target_s2 / pl->tiles;
+    if (splitk > max_split) splitk = max_split;
+    if (splitk < 1) splitk = 1;
+  } else if (use_win && use_win128 && use_win < 3 && win_geom && co_pad % 128 == 0 && a->ci % 128 == 0) {
     pl->variant = 4;
     pl->ci_tiles = a->ci / 128;
     pl->tiles = (co_pad / 128) * 3 * pl->ci_tiles;
@@ -1384,6 +1430,8 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
 }
 
 }  // namespace
+
+extern "C" void vdqn_debug_set_wgrad_s2win(int v) { g_wgrad_s2win_override = v; }  // test hook (not part of include/vdqn.h): -1 = VDQN_WGRAD_S2WIN
 
 extern "C" int64_t vdqn_conv2d_wgrad_workspace_bytes(const vdqn_wgrad_args* a) {
   WgradPlan pl;
@@ -1431,6 +1479,7 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   }
   int rc;
   if (pl.variant == 0) rc = launch_stem_wgrad(p, st);
+  else if (pl.variant == 5) rc = launch_wgrad_win<128, 128, 8, true>(p, pl.tiles, pl.splitk, st);
   else if (pl.variant == 4) rc = launch_wgrad_win<128, 128, 8>(p, pl.tiles, pl.splitk, st);
   else if (pl.variant == 2) rc = launch_wgrad_win<128, 64>(p, pl.tiles, pl.splitk, st);
   else if (pl.variant == 1) rc = launch_wgrad_win<64, 64>(p, pl.tiles, pl.splitk, st);
