@@ -737,6 +737,7 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     {"VDQN_S2WIN_PERSIST": "0"},      # stride-2 plane-window kernel: one workgroup per tile (no tile walk)
     {"VDQN_S2WIN_PERSIST": "-1", "VDQN_FUSE_DS": "1"},  # ... and round 4's kernel for it
     {"VDQN_S2DGRAD_WIN": "0"},        # stride-2 data gradients on the generic class-tiled kernel instead of the plane-window kernel
+    {"VDQN_WIN9_MIXED": "1"},         # whole rounds of a window-kernel launch on 256-row tiles, the rest on 128-row tiles (off: slower)
     {"VDQN_WGRAD_S2WIN": "1"},        # stride-2 weight gradients on the stride-2 window tiles (off by default: slower)
     {"VDQN_WIN9_SPLITK": "1"},        # split-K remainder launches of the nine-tap window kernel (scratch in the workspaces; off by default)
     {"VDQN_WIN9_BALANCED": "2"},      # balanced row walk of the nine-tap window kernel (two launches per convolution)

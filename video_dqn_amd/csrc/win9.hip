@@ -117,8 +117,9 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     if (lt >= x_count) return;
     // (a launch of whole rounds in front of a split-K remainder launch clears that launch's arrival counters)
     if (p.sk_cnt && blockIdx.x == 0 && tid < 256) reinterpret_cast<uint4*>(p.sk_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
-    tile_n = (int)((x_first + lt) % (uint32_t)p.tiles_n);
-    tile_m = (int)((x_first + lt) / (uint32_t)p.tiles_n);
+    // (static walk: bal_rows = index of the launch's first tile — a launch may cover a tail of the tile sequence, see the launcher)
+    tile_n = (int)(((uint32_t)bal_rows + x_first + lt) % (uint32_t)p.tiles_n);
+    tile_m = (int)(((uint32_t)bal_rows + x_first + lt) / (uint32_t)p.tiles_n);
     n0 = tile_n * BN;
     m0 = tile_m * BM;
   }
@@ -518,8 +519,8 @@ __global__ __launch_bounds__(2 * BM, 2) void win9u_kernel(const IgemmParams p, c
     // (balanced walk: the next 128 rows of the workgroup's range, same column tile, same weights)
     const uint32_t lt_nx = lt + x_blocks;
     const bool has_nx = BAL ? m0 + BM < m_end : lt_nx < x_count;
-    const int tn_nx = (BAL || !has_nx) ? tile_n : (int)((x_first + lt_nx) % (uint32_t)p.tiles_n);
-    const int tm_nx = (BAL || !has_nx) ? tile_m : (int)((x_first + lt_nx) / (uint32_t)p.tiles_n);
+    const int tn_nx = (BAL || !has_nx) ? tile_n : (int)(((uint32_t)bal_rows + x_first + lt_nx) % (uint32_t)p.tiles_n);
+    const int tm_nx = (BAL || !has_nx) ? tile_m : (int)(((uint32_t)bal_rows + x_first + lt_nx) / (uint32_t)p.tiles_n);
     const int m0_nx = BAL ? (has_nx ? m0 + BM : m0) : tm_nx * BM;
     const int q0_t = BAL ? 0 : m0_nx - W - 1 + lrow;
     const uint32_t b_t = BAL ? b_off0 : (uint32_t)(tn_nx * BN + lrow) * (uint32_t)(p.ktot * 2) + (uint32_t)(lchunk_b * 16);
@@ -634,11 +635,14 @@ static int g_win9_balanced_override = -1;
 extern "C" void vdqn_debug_set_win9_balanced(int v) { g_win9_balanced_override = v; }  // test hook (not part of include/vdqn.h)
 
 // entry used by vdqn_conv2d (igemm.hip): returns VDQN_OK or an error code
+// tile_first / tile_count: the part of the launch's tile sequence (row block major, column tile fastest, in tiles of BM rows) this call
+// covers; tile_count < 0 = all of it
 template <int MODE, int BM>
-static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps) {
+static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps, int tile_first = 0, int tile_count = -1) {
   using G = Win9Geom<BM>;
   const int wrows = (BM + 2 * p.wo + 2 + 1 + 7) & ~7;  // <= G::WinRows for W <= 28
-  const unsigned tiles = (unsigned)(((p.M + BM - 1) / BM) * p.tiles_n);
+  const bool part = tile_count >= 0;
+  const unsigned tiles = part ? (unsigned)tile_count : (unsigned)(((p.M + BM - 1) / BM) * p.tiles_n);
   // VDQN_WIN9_PERSIST=1: at most as many workgroups as the chip holds at once, each walking its tiles with the next tile's first
   // two K-steps staged under the current tile's last steps and epilogue; 0: one workgroup per tile
   // (default: for launches of more than two rounds of resident workgroups — layer2 +5-7 %, layer3 at 512 frames +4 %; a launch of
@@ -660,7 +664,7 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
   static const int persist256 = [] { const char* e = getenv("VDQN_WIN9_PERSIST256"); return e ? atoi(e) : 1; }();
   unsigned grid = ((BM == 128 || persist256) && ((persist == 1 && tiles > 2 * resident) || (persist >= 2 && tiles > resident) || (BM == 256 && persist256 && tiles > resident))) ? resident : tiles;
   const bool lean_ok = !p.no_lean && p.co % 128 == 0 && p.vec_ok && p.out && !p.out_f32 && !p.mask && p.bias && (((uintptr_t)p.bias) & 15) == 0 && (long long)p.M * p.ldo * 2 < 0x7fffffffLL;
-  if (BM == 128 && MODE == 0 && balanced && lean_ok && !p.colsum_part && !p.wt_b && (tiles > resident || balanced >= 2) && p.tiles_n > 0 &&
+  if (BM == 128 && MODE == 0 && balanced && !part && lean_ok && !p.colsum_part && !p.wt_b && (tiles > resident || balanced >= 2) && p.tiles_n > 0 &&
       resident % (8u * (unsigned)p.tiles_n) == 0 && resident / (unsigned)p.tiles_n >= 8u) {
     const unsigned per_col = resident / (unsigned)p.tiles_n;       // workgroups (= row ranges) per column tile
     bal_rows = (int)((((long long)p.M + per_col - 1) / per_col + 15) / 16 * 16);
@@ -693,7 +697,7 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
     const int splitk = g_win9_splitk_override >= 0 ? g_win9_splitk_override : splitk_env();
     const unsigned whole = tiles / resident * resident, rem = tiles - whole;
     const int cpk = p.ci / 64;
-    if (splitk && p.sk_cnt && p.sk_slab && !p.wt_b && whole > 0 && rem > 0 && resident % 8u == 0 && resident / 8u <= 64u) {
+    if (splitk && !part && p.sk_cnt && p.sk_slab && !p.wt_b && whole > 0 && rem > 0 && resident % 8u == 0 && resident / 8u <= 64u) {
       const unsigned run = (rem * (unsigned)cpk + resident - 1) / resident;  // chunks of the longest run
       if (splitk >= 2 || 9 * run + 6 < 9u * (unsigned)cpk + 3) {
         const unsigned grid1 = ((persist == 1 && whole > 2 * resident) || (persist >= 2 && whole > resident)) ? resident : whole;
@@ -711,7 +715,7 @@ static void launch_win9u(const IgemmParams& p, hipStream_t stream, void* stamps)
   q.sk_cnt = nullptr;  // (no remainder launch behind this one: nothing to clear)
   vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&win9u_kernel<MODE, BM>), (size_t)G::Smem);
   hipLaunchKernelGGL((win9u_kernel<MODE, BM>), dim3(grid), dim3(G::NT), G::Smem, stream, q, wrows, make_fastdiv((uint32_t)p.wo),
-                     make_fastdiv((uint32_t)p.howo), tiles, stamps, 0);
+                     make_fastdiv((uint32_t)p.howo), tiles, stamps, tile_first);
 }
 
 int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
@@ -728,10 +732,21 @@ int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
   bool big = bm256 == 2 || (bm256 == 1 && (long long)p.tiles_m * p.tiles_n > 2ll * vdqn_num_cus());
   // (the data gradient's 256-row tiles got the lean epilogue with this rule: on the shared igemm_epilogue they measured 0.617 vs
   // 0.612 ms in the update although the bare kernel is 3-5 % faster, profiles/r06a_ab_bm256_auto_vs_128.txt)
+  // MIXED tiling (VDQN_WIN9_MIXED=1; default 0): where the fractional part is small, the launch's WHOLE rounds on 256-row tiles (the
+  // faster K-step) and only the rows behind them on 128-row tiles, whose partial round is the cheap one — two launches over disjoint
+  // rows, every output element computed by the same K order as before (bit-identical).  MEASURED SLOWER: layer3 at 512 frames 116.1
+  // vs 105.8 us, at 384 frames 89.7 vs 79.2, layer4 at 384 frames 99.7 vs 92.7; in the update the forward launches 1.637 vs 1.606 ms
+  // (profiles/r06i_*): the second launch starts only when the first has drained and pays a launch gap of its own, which costs more
+  // than the 6 % the 256-row rounds save.
+  static const int mixed_env = [] { const char* e = getenv("VDQN_WIN9_MIXED"); return e ? atoi(e) : 0; }();
+  int mixed_tiles128 = 0;  // > 0: 128-row tiles [0, mixed_tiles128) run as 256-row tiles, the rest as they are
   if (bm256 == 3 && p.ci >= 256 && !p.wt_b) {
-    const double r = (double)p.tiles_m * p.tiles_n / (2.0 * vdqn_num_cus());  // rounds of the 128-row tiles (p.tiles_m counts those)
+    const long long tiles128 = (long long)p.tiles_m * p.tiles_n, res128 = 2ll * vdqn_num_cus();
+    const double r = (double)tiles128 / (double)res128;  // rounds of the 128-row tiles (p.tiles_m counts those)
     const double frac = r - (double)(long long)r;
     big = r >= 0.7 && frac >= 0.45;
+    const long long whole = tiles128 / res128 * res128;
+    if (!big && mixed_env && whole > 0 && whole < tiles128 && whole % (2ll * p.tiles_n) == 0) mixed_tiles128 = (int)whole;
   }
   void* stamps = nullptr;
 #ifdef VDQN_STAMP
@@ -739,7 +754,16 @@ int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
 #endif
   vdqn_prof_begin(mode == 0 ? "igemm_win<bf16,128,fwd>" : "igemm_win<bf16,128,dgrad>", 2.0 * p.M * p.co * p.ktot,
                   2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
-  if (mode == 0) {
+  if (mixed_tiles128 > 0) {
+    const int n128 = p.tiles_m * p.tiles_n - mixed_tiles128;
+    if (mode == 0) {
+      launch_win9u<0, 256>(p, stream, stamps, 0, mixed_tiles128 / 2);
+      launch_win9u<0, 128>(p, stream, stamps, mixed_tiles128, n128);
+    } else {
+      launch_win9u<1, 256>(p, stream, stamps, 0, mixed_tiles128 / 2);
+      launch_win9u<1, 128>(p, stream, stamps, mixed_tiles128, n128);
+    }
+  } else if (mode == 0) {
     if (big) launch_win9u<0, 256>(p, stream, stamps); else launch_win9u<0, 128>(p, stream, stamps);
   } else {
     if (big) launch_win9u<1, 256>(p, stream, stamps); else launch_win9u<1, 128>(p, stream, stamps);
