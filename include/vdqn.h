@@ -38,6 +38,10 @@ extern "C" {
 const char* vdqn_last_error(void);
 /* ABI version; bumped on any signature change */
 int vdqn_abi_version(void);
+/* sizeof() of the argument structs as THIS library was compiled (which: 0 vdqn_conv_args, 1 vdqn_wgrad_args, 2 vdqn_td_args,
+ * 3 vdqn_net_config, 4 vdqn_param_info, 5 vdqn_prof_entry, 6 vdqn_step_args; -1 for any other value): a foreign-function binding
+ * (ctypes / cgo / JNI) compares them with its own struct definitions at load time instead of finding a drifted field at run time */
+int32_t vdqn_abi_struct_size(int32_t which);
 
 /* Launch profiler (off by default).  While enabled, every kernel launch of the library is bracketed by HIP
  * events on its launch stream; collect() synchronises those events and returns one entry per kernel symbol:

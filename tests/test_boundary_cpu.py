@@ -23,6 +23,25 @@ def test_c_abi_exports_every_declared_symbol():
     assert _lib.load().vdqn_abi_version() == _lib.ABI_VERSION
 
 
+def test_binding_structs_match_the_library():
+    """Every argument struct of the ctypes binding has the size the library was compiled with (vdqn_abi_struct_size, checked by
+    _lib.load() too): a field added on one side only fails at load time.  The C layout is derived from include/vdqn.h itself:
+    the number of fields of each typedef'd struct in the header equals the binding's."""
+    from video_dqn_amd import _lib
+    lib = _lib.load()
+    structs = (("vdqn_conv_args", _lib.ConvArgs), ("vdqn_wgrad_args", _lib.WgradArgs), ("vdqn_td_args", _lib.TdArgs),
+               ("vdqn_net_config", _lib.NetConfig), ("vdqn_param_info", _lib.ParamInfo), ("vdqn_prof_entry", _lib.ProfEntry),
+               ("vdqn_step_args", _lib.StepArgs))
+    hdr = open(os.path.join(ROOT, "include", "vdqn.h")).read()
+    for which, (cname, st) in enumerate(structs):
+        assert lib.vdqn_abi_struct_size(which) == ctypes.sizeof(st), cname
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        n_fields = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
+        assert n_fields == len(st._fields_), (cname, n_fields, len(st._fields_))
+    assert lib.vdqn_abi_struct_size(len(structs)) == -1
+
+
 def test_compute_fails_loudly_without_gpu():
     from video_dqn_amd import _lib
     from video_dqn_amd.engine import NetEngine, TDStepper

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", f"libvdqn{'_' + os.environ['VDQN_LIB'] if os.environ.get('VDQN_LIB') else ''}.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -80,6 +80,7 @@ _SIGS = {
     "vdqn_profile_enable": (C.c_int, [C.c_int]),
     "vdqn_profile_collect": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "vdqn_conv2d": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
+    "vdqn_abi_struct_size": (c_i32, [c_i32]),
     "vdqn_conv2d_colsum_rows": (c_i32, [C.POINTER(ConvArgs)]),
     "vdqn_conv2d_splitk_workspace_bytes": (c_i64, []),
     "vdqn_conv2d_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
@@ -162,6 +163,11 @@ def load():
         fn.argtypes = args
     if lib.vdqn_abi_version() != ABI_VERSION:
         raise VdqnError(f"libvdqn ABI {lib.vdqn_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    # the argument structs of this binding against the library's own sizeof(): a drifted field fails here, not inside a kernel
+    for which, st in enumerate((ConvArgs, WgradArgs, TdArgs, NetConfig, ParamInfo, ProfEntry, StepArgs)):
+        if lib.vdqn_abi_struct_size(which) != C.sizeof(st):
+            raise VdqnError(f"libvdqn: sizeof({st.__name__}) is {lib.vdqn_abi_struct_size(which)} in the library, "
+                            f"{C.sizeof(st)} in this binding: include/vdqn.h and video_dqn_amd/_lib.py have drifted apart")
     _lib = lib
     return lib
 

@@ -29,7 +29,19 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 12; }
+extern "C" int vdqn_abi_version(void) { return 13; }
+extern "C" int32_t vdqn_abi_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return (int32_t)sizeof(vdqn_conv_args);
+    case 1: return (int32_t)sizeof(vdqn_wgrad_args);
+    case 2: return (int32_t)sizeof(vdqn_td_args);
+    case 3: return (int32_t)sizeof(vdqn_net_config);
+    case 4: return (int32_t)sizeof(vdqn_param_info);
+    case 5: return (int32_t)sizeof(vdqn_prof_entry);
+    case 6: return (int32_t)sizeof(vdqn_step_args);
+    default: return -1;
+  }
+}
 
 namespace {
 
