@@ -121,3 +121,25 @@ def test_rank_sharded_store_holds_a_quarter_and_draws_the_same_batches(tmp_path)
             for x, y in zip(a[:2] + a[3:], b[:2] + b[3:]):
                 assert x.shape == y.shape and torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0))
             assert st.bytes() == full.bytes() // world == (n_frames // world) * FRAME_BYTES
+
+
+def test_host_gather_copies_every_record_once():
+    """vdqn_host_gather (csrc/hostio.hip; the per-sample fetch + collate of dataloaders/q_learning_real.py:55-73 for decoded-frame
+    shards): n records from n addresses into one contiguous buffer, on 1 .. 9 threads, with n below, equal to and far above the thread
+    count, n = 0, and an error (not a crash) for a null destination."""
+    import ctypes as C
+    import numpy as np
+    from video_dqn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, size=(37, 1000), dtype=np.uint8)
+    for n in (0, 1, 3, 8, 37):
+        for threads in (0, 1, 2, 4, 9):
+            order = rng.permutation(37)[:n]
+            ptrs = (C.c_void_p * max(n, 1))(*[src[i].ctypes.data for i in order])
+            dst = np.full((max(n, 1), 1000), 7, dtype=np.uint8)
+            rc = lib.vdqn_host_gather(C.c_void_p(dst.ctypes.data), ptrs, n, 1000, threads)
+            assert rc == 0
+            assert np.array_equal(dst[:n], src[order]) and (n > 0 or (dst == 7).all())
+    assert lib.vdqn_host_gather(None, ptrs, 1, 1000, 1) != 0
+    assert b"vdqn_host_gather" in lib.vdqn_last_error()
