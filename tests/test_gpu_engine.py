@@ -567,6 +567,7 @@ def test_side_stream_overlap_matches_serial():
 
 
 @pytest.mark.parametrize("dtype,B,F", [("bf16", 128, 1), ("bf16", 8, 1), ("f32", 4, 1), ("bf16", 4, 4)])
+@pytest.mark.variants
 def test_grouped_forward_is_bit_identical_to_two_passes(dtype, B, F):
     """The online pass over [s; s'] and the target pass over s' as ONE chain of grouped launches (vdqn_step_args.acts_target == NULL,
     vdqn_conv_args.wt_b: tiles from row 2B*H*W on take the target network's weights) against the two separate passes
@@ -727,39 +728,39 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
 
 
 @pytest.mark.parametrize("env", [
-    {"VDQN_SPLIT_ONLINE": "1"},       # online forward as two half-batch passes on two streams
-    {"VDQN_FUSE_POOL_BWD": "0"},      # max-pool backward + stem weight gradient as two launches
-    {"VDQN_WIN9_BM256": "2"},         # 256-row tiles of the nine-tap window kernel everywhere
-    {"VDQN_WIN9_BM256": "0", "VDQN_WIN9_PERSIST256": "0"},  # ... nowhere (rounds 1-4), and their round-4 form: one workgroup per tile
+    pytest.param({"VDQN_SPLIT_ONLINE": "1"}, marks=pytest.mark.variants),       # online forward as two half-batch passes on two streams
+    pytest.param({"VDQN_FUSE_POOL_BWD": "0"}, marks=pytest.mark.variants),      # max-pool backward + stem weight gradient as two launches
+    pytest.param({"VDQN_WIN9_BM256": "2"}, marks=pytest.mark.variants),         # 256-row tiles of the nine-tap window kernel everywhere
+    pytest.param({"VDQN_WIN9_BM256": "0", "VDQN_WIN9_PERSIST256": "0"}, marks=pytest.mark.variants),  # ... nowhere (rounds 1-4), and their round-4 form: one workgroup per tile
     {"VDQN_FUSE_DS": "1"},            # round 4's default: the 1x1 downsample as its own forward launch (fused in the data gradient only)
-    {"VDQN_FUSE_DS": "7"},            # fused in the forward pass on the generic kernel too (f32 engines)
+    pytest.param({"VDQN_FUSE_DS": "7"}, marks=pytest.mark.variants),            # fused in the forward pass on the generic kernel too (f32 engines)
     {"VDQN_LEAN_EPILOGUE": "0"},      # the window kernels on the shared igemm_epilogue (round 4) instead of the lean ones
-    {"VDQN_S2WIN_PERSIST": "0"},      # stride-2 plane-window kernel: one workgroup per tile (no tile walk)
-    {"VDQN_S2WIN_PERSIST": "-1", "VDQN_FUSE_DS": "1"},  # ... and round 4's kernel for it
+    pytest.param({"VDQN_S2WIN_PERSIST": "0"}, marks=pytest.mark.variants),      # stride-2 plane-window kernel: one workgroup per tile (no tile walk)
+    pytest.param({"VDQN_S2WIN_PERSIST": "-1", "VDQN_FUSE_DS": "1"}, marks=pytest.mark.variants),  # ... and round 4's kernel for it
     {"VDQN_S2DGRAD_WIN": "0"},        # stride-2 data gradients on the generic class-tiled kernel instead of the plane-window kernel
-    {"VDQN_WIN9_MIXED": "1"},         # whole rounds of a window-kernel launch on 256-row tiles, the rest on 128-row tiles (off: slower)
-    {"VDQN_WGRAD_S2WIN": "1"},        # stride-2 weight gradients on the stride-2 window tiles (off by default: slower)
-    {"VDQN_WIN9_SPLITK": "1"},        # split-K remainder launches of the nine-tap window kernel (scratch in the workspaces; off by default)
-    {"VDQN_WIN9_BALANCED": "2"},      # balanced row walk of the nine-tap window kernel (two launches per convolution)
-    {"VDQN_GROUPED_FWD": "1"},        # online and target forward as one chain of grouped launches
-    {"VDQN_GROUPED_FWD": "1", "VDQN_GROUPED_LAUNCH": "0"},  # grouped forward, every layer through the internal two-launch fall-back
-    {"VDQN_WIN9_MFMA32": "1"},        # nine-tap window kernel on 32x32x16 MFMAs (win9m.hip)
-    {"VDQN_WIN9_MFMA32": "0"},        # ... on 16x16x32 MFMAs (win9.hip)
-    {"VDQN_WGRAD_WINDOW": "1"},       # round 2's choice: 64x64 window weight-gradient tiles up to 256 channels, generic 128x128 tiles for layer4
-    {"VDQN_WGRAD_WIN128": "1"},       # eight-wave 128x128 window weight-gradient tiles for the 128+ channel layers
-    {"VDQN_WGRAD_TWO_STAGE": "1"},    # split-K partials as plain stores + ordered reduce kernels instead of f32 atomics
+    pytest.param({"VDQN_WIN9_MIXED": "1"}, marks=pytest.mark.variants),         # whole rounds of a window-kernel launch on 256-row tiles, the rest on 128-row tiles (off: slower)
+    pytest.param({"VDQN_WGRAD_S2WIN": "1"}, marks=pytest.mark.variants),        # stride-2 weight gradients on the stride-2 window tiles (off by default: slower)
+    pytest.param({"VDQN_WIN9_SPLITK": "1"}, marks=pytest.mark.variants),        # split-K remainder launches of the nine-tap window kernel (scratch in the workspaces; off by default)
+    pytest.param({"VDQN_WIN9_BALANCED": "2"}, marks=pytest.mark.variants),      # balanced row walk of the nine-tap window kernel (two launches per convolution)
+    pytest.param({"VDQN_GROUPED_FWD": "1"}, marks=pytest.mark.variants),        # online and target forward as one chain of grouped launches
+    pytest.param({"VDQN_GROUPED_FWD": "1", "VDQN_GROUPED_LAUNCH": "0"}, marks=pytest.mark.variants),  # grouped forward, every layer through the internal two-launch fall-back
+    pytest.param({"VDQN_WIN9_MFMA32": "1"}, marks=pytest.mark.variants),        # nine-tap window kernel on 32x32x16 MFMAs (win9m.hip)
+    pytest.param({"VDQN_WIN9_MFMA32": "0"}, marks=pytest.mark.variants),        # ... on 16x16x32 MFMAs (win9.hip)
+    pytest.param({"VDQN_WGRAD_WINDOW": "1"}, marks=pytest.mark.variants),       # round 2's choice: 64x64 window weight-gradient tiles up to 256 channels, generic 128x128 tiles for layer4
+    pytest.param({"VDQN_WGRAD_WIN128": "1"}, marks=pytest.mark.variants),       # eight-wave 128x128 window weight-gradient tiles for the 128+ channel layers
+    pytest.param({"VDQN_WGRAD_TWO_STAGE": "1"}, marks=pytest.mark.variants),    # split-K partials as plain stores + ordered reduce kernels instead of f32 atomics
     {"VDQN_WGRAD_STREAMS": "1"},      # all weight gradients on ONE side stream (default: alternating between the two)
-    {"VDQN_S2WIN": "0"},              # stride-2 3x3 forward convolutions on the generic kernel (no plane-window kernel)
-    {"VDQN_STEM_NOIDX": "0"},         # the stem writes the max-pool arg-max bytes of the no-grad frames too
+    pytest.param({"VDQN_S2WIN": "0"}, marks=pytest.mark.variants),              # stride-2 3x3 forward convolutions on the generic kernel (no plane-window kernel)
+    pytest.param({"VDQN_STEM_NOIDX": "0"}, marks=pytest.mark.variants),         # the stem writes the max-pool arg-max bytes of the no-grad frames too
     {"VDQN_EARLY_ADAM": "0"},         # TDStepper.step: one Adam launch behind the whole backward pass
-    {"VDQN_PACK_AFTER_FIRST": "1"},   # the s' frames packed first and the target pass right behind them, the s frames on the caller's stream
-    {"VDQN_FOLD_SPLIT": "1"},         # weight fold of stage 2's layers first, the rest on the side stream beside the stem
-    {"VDQN_STEM_WGRAD_MAIN": "0"},    # conv1's weight gradient on the side stream behind block 0's instead of beside them
+    pytest.param({"VDQN_PACK_AFTER_FIRST": "1"}, marks=pytest.mark.variants),   # the s' frames packed first and the target pass right behind them, the s frames on the caller's stream
+    pytest.param({"VDQN_FOLD_SPLIT": "1"}, marks=pytest.mark.variants),         # weight fold of stage 2's layers first, the rest on the side stream beside the stem
+    pytest.param({"VDQN_STEM_WGRAD_MAIN": "0"}, marks=pytest.mark.variants),    # conv1's weight gradient on the side stream behind block 0's instead of beside them
     {"VDQN_SKINNY": "0"},             # the Q-head's layers on the generic tiled kernel instead of the skinny GEMM kernels
-    {"VDQN_SKINNY_CONV_CFG": "9"},    # features.8 on the skinny kernel that reads its input from global memory (default: images in LDS)
-    {"VDQN_SIDE_PRIORITY": "normal"}, # the side streams at the caller's stream priority (default: below it)
-    {"VDQN_EARLY_FOLD": "1", "VDQN_PACK_TWO_STREAMS": "1"},  # stage 0 / 1 weights folded behind their early Adam; the two input packs on two streams
-], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+    pytest.param({"VDQN_SKINNY_CONV_CFG": "9"}, marks=pytest.mark.variants),    # features.8 on the skinny kernel that reads its input from global memory (default: images in LDS)
+    pytest.param({"VDQN_SIDE_PRIORITY": "normal"}, marks=pytest.mark.variants), # the side streams at the caller's stream priority (default: below it)
+    pytest.param({"VDQN_EARLY_FOLD": "1", "VDQN_PACK_TWO_STREAMS": "1"}, marks=pytest.mark.variants),  # stage 0 / 1 weights folded behind their early Adam; the two input packs on two streams
+], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) if isinstance(e, dict) else None)
 def test_non_default_kernel_selections(env):
     """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and
     determinism tests green: re-run them in a child process with the switch set."""

@@ -202,6 +202,7 @@ S2W_CASES = [  # n, ci, co, h (even): 3x3 / stride 2 / pad 1 with 128+ channels 
 
 @pytest.mark.parametrize("splitk", [0, 1, 5])
 @pytest.mark.parametrize("case", S2W_CASES)
+@pytest.mark.variants
 def test_conv_wgrad_stride2_window_kernel(case, splitk):
     """Weight gradient of the 3x3 / stride-2 convolutions (conv1 of layer3.0 / layer4.0's geometry) on the stride-2 window tiles
     (round 5; VDQN_WGRAD_S2WIN=1 — off by default, it measured slower than the generic kernel): one staged window of the kernel row's input rows serves its three taps at a stride of two window rows per pixel.
@@ -643,6 +644,7 @@ def test_nine_tap_window_kernel_nonsquare(geom):
     assert relerr(part.sum(0).cpu(), got.float().cpu().sum((0, 1, 2))) < 1e-4
 
 
+@pytest.mark.variants
 def test_nine_tap_kernel_256_row_tiles():
     """win9u_kernel<MODE, 256>: 256-row tiles on eight waves, one workgroup per CU, persistent above one round since round 5 (the
     launcher picks them by the launch's round count: VDQN_WIN9_BM256=3; 2 = always).  The operator tests that reach the kernel —
@@ -659,6 +661,7 @@ def test_nine_tap_kernel_256_row_tiles():
 
 
 @pytest.mark.parametrize("mfma32", ["0", "1"])
+@pytest.mark.variants
 def test_nine_tap_kernels_both_mfma_shapes(mfma32):
     """The nine-tap window kernel exists on 16x16x32 MFMAs (win9.hip) and on 32x32x16 MFMAs (win9m.hip: other fragment layout,
     other LDS swizzles, its own epilogue); VDQN_WIN9_MFMA32 (read once per process) selects one.  The operator tests that reach
@@ -675,6 +678,7 @@ def test_nine_tap_kernels_both_mfma_shapes(mfma32):
 
 
 @pytest.mark.parametrize("win128", ["0", "1"])
+@pytest.mark.variants
 def test_weight_gradient_kernels_both_tilings(win128):
     """The 3x3 / stride-1 weight gradients of the 128+ channel layers run on 64 x 64 window / generic 128 x 128 tiles (default) or on
     128 x 128 window tiles (eight waves, VDQN_WGRAD_WIN128=1): the weight-gradient operator tests under each setting."""
@@ -743,6 +747,7 @@ BAL_CASES = [  # n, c (ci = co), h, pretend-CUs: column tiles 1 / 2 / 4; ranges 
 
 
 @pytest.mark.parametrize("case", BAL_CASES)
+@pytest.mark.variants
 def test_nine_tap_window_kernel_balanced_walk(case):
     """win9u_kernel's balanced walk (round 5, forward; an off-by-default switch — it measured slower than the static walk): the rows of
     a launch are split EVENLY over the resident workgroups of each column tile, every workgroup walks its range in 128-row tiles
@@ -842,6 +847,7 @@ SK_CASES = [  # n, channels, h, pretend-CUs (resident workgroups = 2 x CUs, a mu
 
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("case", SK_CASES)
+@pytest.mark.variants
 def test_nine_tap_window_kernel_split_k_remainder(case, mode):
     """win9u_kernel<.., 3> (round 5): the tiles behind a launch's last WHOLE round of resident workgroups are split along K — each
     workgroup of an XCD takes an equal run of the remainder's channel chunks, writes its f32 partial tile to the caller's scratch and

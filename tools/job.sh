@@ -2,7 +2,8 @@
 # The GPU-box jobs of a round as ONE parametrised script (run through tools/gpu_job.sh, which freezes the tree first):
 #     tools/gpu_job.sh <timeout_s> 'bash tools/job.sh <TAG> <recipe> [<recipe> ...]'
 # Every recipe writes under gpurun_out/<TAG>/; what is to be judged is then copied into profiles/ by hand.
-#   suite          the whole GPU test suite (pytest -m gpu), log + return code
+#   suite          the GPU test suite as the driver runs it (plain pytest -m gpu, 1150 s limit, --durations) + smoke(), logs + return codes
+#   variants       the switch-variant tests (VDQN_TEST_VARIANTS=1, -m 'gpu and variants')
 #   tests:<expr>   pytest -m gpu -k "<expr>" (underscores for spaces: tests:vs_oracle_or_emulating)
 #   bench          three default bench.py runs in a row (the first with the CPU baseline)
 #   profile        rocprofv3 kernel stats (serial + overlap) and the event-profiled bench line: tools/profile_round.sh
@@ -23,7 +24,12 @@ cd "$R"
 for recipe in "$@"; do
   name=${recipe%%:*}; arg=${recipe#*:}; [ "$arg" = "$recipe" ] && arg=""
   case $name in
-    suite)   timeout 2400 python -m pytest tests -m gpu -q --maxfail=8 > "$O/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$O/pytest_gpu.log"; tail -4 "$O/pytest_gpu.log" | cut -c1-300 ;;
+    suite)   # what the driver runs: plain -m gpu (variants deselected), under the driver's own 1200 s limit, then smoke()
+             t0=$(date +%s); timeout 1150 python -m pytest tests -m gpu -q --maxfail=8 --durations=60 --durations-min=1.5 > "$O/pytest_gpu.log" 2>&1; echo "pytest rc=$? wall=$(( $(date +%s) - t0 ))s" >> "$O/pytest_gpu.log"
+             timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1; echo "smoke rc=$?" >> "$O/smoke.log"
+             tail -4 "$O/pytest_gpu.log" | cut -c1-300; tail -2 "$O/smoke.log" | cut -c1-200 ;;
+    variants) # the A/B switch variants the plain suite deselects (tests/conftest.py: @pytest.mark.variants)
+             t0=$(date +%s); VDQN_TEST_VARIANTS=1 timeout 2400 python -m pytest tests -m "gpu and variants" -q --maxfail=8 > "$O/pytest_variants.log" 2>&1; echo "pytest rc=$? wall=$(( $(date +%s) - t0 ))s" >> "$O/pytest_variants.log"; tail -3 "$O/pytest_variants.log" | cut -c1-300 ;;
     tests)   timeout 2400 python -m pytest tests -m gpu -q -k "${arg//_or_/ or }" > "$O/pytest_${arg:0:40}.log" 2>&1; echo "pytest rc=$?" >> "$O/pytest_${arg:0:40}.log"; tail -3 "$O/pytest_${arg:0:40}.log" | cut -c1-300 ;;
     bench)   for i in 1 2 3; do timeout 300 python bench.py $( [ $i -gt 1 ] && echo --no-cpu-baseline ) > "$O/bench_$i.json" 2>> "$O/err.log"; done
              python - "$O" <<'PY'
