@@ -282,7 +282,7 @@ def main():
         nxt = None
         if args.pack_ahead or os.environ.get("VDQN_BENCH_PACK_AHEAD") == "1":
             nb_, na_ = pool[pool_i["i"] % n_pool][:2]
-            nxt = (nb_, na_, 0)
+            nxt = (nb_, na_, 0, True)  # (pool tensors are never rewritten: an announcement that aliases this step's frames is a replay)
         return stp.step(b_, a_, 0, act_, rew_, term_, finish_allreduce=(comm.finish if comm else None), next_frames=nxt)
 
     # device ramp (untimed, before the W warm-up steps): a box that sat idle takes longer than 20 updates (0.13 s) to reach the

@@ -99,25 +99,8 @@ typedef struct vdqn_conv_args {
   const float* bias2;
   void* out2;
   int32_t co2, ldo2, relu2, ci2;
-  /* Optional grouped forward (mode 0, no sibling / mask / column sums): TWO weight sets over one batch — images [0, split_img)
-   * are computed with wt / bias, images [split_img, n_img) with wt_b / bias_b (same shapes).  One TD update runs the online
-   * network on [s; s'] and the target network on s' (train_q_network.py:131,140,142): with the three image ranges in one tensor
-   * every layer is one launch instead of two.  Each output element is bit-identical to the two separate calls; kernels without a
-   * grouped form (or a split that is not a multiple of their tile height) run the two ranges as two launches internally.
-   * All NULL / 0 = plain call. */
-  const void* wt_b;
-  const float* bias_b;
-  int32_t split_img;
-  /* Optional scratch for the split-K remainder of the bf16 nine-tap window kernel (3x3 / stride 1 / 128+ channels, mode 0 / 1):
-   * with it, the tiles behind a launch's last WHOLE round of resident workgroups are split along K over all workgroups and their
-   * f32 partial tiles summed here in a fixed order (csrc/win9.hip) — results are reproducible for a given call shape, but a split
-   * tile's f32 sum is associated differently from the unsplit kernel's.  vdqn_conv2d_splitk_workspace_bytes() bytes serve any
-   * call; the buffer needs no initialisation; calls that may run CONCURRENTLY need separate buffers.  NULL / too small = unsplit. */
-  void* splitk_ws;
-  int64_t splitk_ws_bytes;
 } vdqn_conv_args;
 int vdqn_conv2d(const vdqn_conv_args* a, void* stream);
-int64_t vdqn_conv2d_splitk_workspace_bytes(void);
 /* rows of `out` covered by one entry of colsum_part for this call (what sizes that buffer): 128, or the row tile of the skinny
  * GEMM kernels that take the Q-head's bf16 linear layers (archs/HabitatDQNMultiAction.py:31; csrc/skinny.hip) */
 int32_t vdqn_conv2d_colsum_rows(const vdqn_conv_args* a);
@@ -346,10 +329,6 @@ int vdqn_net_pack_weights(vdqn_net* net, const float* params, const float* bnsta
                           void* stream);
 /* with_dgrad is a flag word: bit 0 = also pack the data-gradient operands, bit 1 = do NOT fold BatchNorm (the
  * convolutions then produce the raw pre-BatchNorm output; used by the train-mode BatchNorm path of 'basic'). */
-/* The same for the layers of ONE backward stage (0: head + layer4, 1: layer3, 2: layer2, layer1, stem): lets the caller refresh a
- * stage's packed weights as soon as that stage's range of `params` has had its optimiser update (vdqn_step_args.prefolded_stages). */
-int vdqn_net_pack_weights_stage(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad,
-                                int32_t stage, void* stream);
 
 /* Forward of `n_samples` samples (n_samples * F frames).  frames: see vdqn_pack_input (src_kind).
  * q_out: f32 [n_samples][num_classes*action_dim] (HabitatDQNMultiAction.forward, archs/...:44-54). */
@@ -399,11 +378,8 @@ typedef struct vdqn_step_args {
   float gamma;
   float inv_count;            /* 1 / (num_classes * global_batch) */
   int32_t clip_rect, linear, use_valid, train_on_ground_truth, value_learning;
-  void* acts_online;          /* vdqn_net_acts_bytes(2B); vdqn_net_acts_bytes(3B) when acts_target is NULL (grouped forward) */
-  void* acts_target;          /* vdqn_net_acts_bytes(B); NULL (TD branch, extra_capacity only) = GROUPED forward: the target network's
-                                 pass over s' shares the online workspace (samples 2B .. 3B-1 of every activation tensor) and every
-                                 layer behind the stem is ONE launch over [s | s' | s'] with two weight sets (vdqn_conv_args.wt_b):
-                                 bit-identical Q-values, a third fewer launches */
+  void* acts_online;          /* vdqn_net_acts_bytes(2B) (B on the ground-truth branch) */
+  void* acts_target;          /* vdqn_net_acts_bytes(B); NULL on the ground-truth branch */
   void* bwd;                  /* vdqn_net_bwd_bytes(B)   */
   float* grads;               /* flat f32 [trainable_numel] */
   float* loss;                /* f32 scalar (device) */
@@ -416,11 +392,7 @@ typedef struct vdqn_step_args {
                                  arrive packed (or that pack the NEXT minibatch during this update: the loader of
                                  train_q_network.py:213 has it a step ahead — measured slower on one GPU).
                                  NULL: the update packs them itself. */
-  int32_t prefolded_stages;   /* bit s set: `packed_online` ALREADY holds the packed weights of backward stage s's layers for the current
-                                 `params` (the caller ran vdqn_net_pack_weights_stage after that stage's optimiser update of the
-                                 PREVIOUS update, under its remaining backward pass); vdqn_net_td_forward then folds only the other
-                                 stages.  0: it folds everything, as torch does nothing of the kind (set_train, archs/...:37-40). */
-  int32_t acts_samples;       /* 0: `acts_online` is laid out as vdqn_net_td_forward leaves it (2B samples, 3B grouped, B on the
+  int32_t acts_samples;       /* 0: `acts_online` is laid out as vdqn_net_td_forward leaves it (2B samples, B on the
                                  ground-truth branch).  > 0: `acts_online` is the workspace of ONE vdqn_net_forward call over that
                                  many samples (== batch) — the backward of a single model call, vdqn_net_backward_begin below. */
 } vdqn_step_args;
@@ -431,11 +403,6 @@ int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream);
  * for stage 2 makes `stream` wait for the side stream, so vdqn_adam on `stream` sees every gradient.  A consumer of one stage's
  * gradients (the data-parallel all-reduce) orders itself behind vdqn_net_grad_stream. */
 int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream);
-/* A second internal stream (below the caller's stream in priority).  In the default schedule the engine runs every other weight
- * gradient on it (two weight-gradient streams, VDQN_WGRAD_STREAMS=2) and joins it at the end of each backward stage; it is also for work of the NEXT update that a
- * loop wants to run under the current one (its frames packed ahead, vdqn_step_args.packed_frames; a stage's weights folded ahead,
- * vdqn_net_pack_weights_stage).  The caller orders it (hipStreamWaitEvent both ways); NULL when the overlap is off. */
-void* vdqn_net_aux_stream(vdqn_net* net);
 /* Backward of ONE earlier vdqn_net_forward(net, packed, frames, .., B, acts, ..) call from a caller-supplied dL/dQ: what
  * torch.autograd runs for `before_values = model(before)` when the reference's own loop calls loss.backward()
  * (train_q_network.py:131,226) on the HIP-backed module (video_dqn_amd/model.py).  `a` carries params, bnstats, packed_online

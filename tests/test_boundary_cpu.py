@@ -259,3 +259,53 @@ def test_shard_indices_disjoint_and_equal():
     assert all(len(s) == 24 for s in shards)
     flat = [i for s in shards for i in s]
     assert len(set(flat)) == len(flat)
+
+
+@pytest.mark.refonly
+@pytest.mark.skipif(not os.path.isdir("/root/reference/archs"), reason="needs /root/reference (build container only)")
+@pytest.mark.parametrize("extra_capacity,panorama,n_keys,n_ids", [(True, False, 250, 70), (False, True, 244, 64)])
+def test_checkpoint_loads_into_the_reference_class(tmp_path, extra_capacity, panorama, n_keys, n_ids):
+    """SURVEY 8c G6 as written: a checkpoint in the build's format (trainer.save_checkpoint — what run_train writes every
+    CHECKPOINT_INTERVAL, train_q_network.py:241-247) -> the REFERENCE's own class, imported from /root/reference exactly as
+    tests/golden/make_golden.py does (torchvision is not installed here: `models.resnet18` is the published topology restated in
+    oracle/ref_cpu.py), through the reference's own loading lines: `model.load_state_dict(snapshot['model_state_dict'])`
+    (train_q_network.py:50-57, strict) and `optimizer.load_state_dict(snapshot['optimizer_state_dict'])` (:197); the reference model
+    then returns the tensors the build saved, and its Adam steps from the loaded state."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    RefClass = mg.import_reference_model()
+    from video_dqn_amd import synth
+    from video_dqn_amd.model import HabitatDQNMultiAction
+    from video_dqn_amd.trainer import optimizer_state_dict, save_checkpoint
+    m = HabitatDQNMultiAction(3, 5, extra_capacity=extra_capacity, panorama=panorama, device="cpu")
+    if extra_capacity:
+        m.load_state_dict(synth.make_state_dict(5), strict=True)
+
+    class FakeStepper:  # the Adam-state part of TDStepper without a GPU
+        pass
+    st = FakeStepper()
+    st.net, st.lr, st.betas, st.eps, st.adam_step = m.engine, 1e-4, (0.9, 0.999), 1e-8, 3
+    nt = m.engine.trainable_numel
+    st.exp_avg = torch.from_numpy(synth.uniform(1, "m", (nt,), -1e-3, 1e-3))
+    st.exp_avg_sq = torch.from_numpy(synth.uniform(1, "v", (nt,), 0, 1e-6))
+    path = tmp_path / "sample3.torch"
+    save_checkpoint(path, 3, m, st)
+    snapshot = torch.load(path, map_location="cpu")
+    assert len(snapshot["model_state_dict"]) == n_keys
+    ref = RefClass(3, 5, extra_capacity=extra_capacity, panorama=panorama)
+    assert type(ref).__module__ == "archs.HabitatDQNMultiAction"
+    ref.load_state_dict(snapshot["model_state_dict"])  # train_q_network.py:56 (strict is the default)
+    saved = m.state_dict()
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, saved[k]), k
+    optimizer = torch.optim.Adam(ref.parameters(), lr=0.5)  # :124 builds it over model.parameters(); the loaded group carries the lr
+    optimizer.load_state_dict(snapshot["optimizer_state_dict"])  # :197
+    assert optimizer.param_groups[0]["lr"] == 1e-4 and len(optimizer.param_groups[0]["params"]) == n_ids
+    frozen = {id(p) for p in (ref.resnet.fc.weight, ref.resnet.fc.bias)}
+    assert all(id(p) not in optimizer.state for p in ref.parameters() if id(p) in frozen)
+    for p in ref.parameters():
+        p.grad = None if id(p) in frozen else torch.zeros_like(p)
+    optimizer.step()
+    assert all(int(s["step"]) == 4 for s in optimizer.state.values())

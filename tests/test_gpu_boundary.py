@@ -191,3 +191,65 @@ def test_run_train_on_feather_jpeg_dataset_and_shards(tmp_path):
     model, stepper, running = run_train(cfg, log=lambda *a: logs.append(" ".join(str(x) for x in a)))
     assert any("resident in HBM" in l for l in logs) and np.isfinite(running)
     assert os.path.exists(folder / "models" / "sample3.torch")
+
+
+def test_host_frame_stream_device_branch(tmp_path):
+    """The streaming input path's DEVICE branch (replaces dataloaders/q_learning_real.py:55-73 under torch's
+    DataLoader, train_q_network.py:98,114): pinned staging slots reused behind an event, host-to-device copies on a prefetch
+    stream, record_stream towards the consumer (shards.py HostFrameStream._produce / batches).  Against DeviceFrameStore.batches
+    bit for bit — frames, labels, order — over 5 x depth minibatches and two epoch boundaries, with and without the
+    PREVIOUS_IMAGES gather, while the COMPUTE stream is kept busy so that every batch is read late: the producer runs ahead of
+    the consumer by the queue's depth, re-fills pinned slots and gets recycled device blocks from the allocator — a slot reused
+    before its copy finished, or a device buffer recycled before the consumer read it, shows as a wrong frame here."""
+    from test_shards_cpu import _synthetic_shards
+    from video_dqn_amd.shards import DeviceFrameStore, HostFrameStream
+    root = str(tmp_path / "shards")
+    _synthetic_shards(root)
+    depth, B = 2, 4
+    for kw in (dict(inverse_actions=True), dict(inverse_actions=True, previous_images=True)):
+        store = DeviceFrameStore(root, "cuda", **kw)
+        ref = store.batches(B, 11)
+        with HostFrameStream(root, "cuda", B, 11, threads=3, depth=depth, **kw) as stream:
+            got = stream.batches()
+            held = []
+            for k in range(5 * depth + 8):  # 37 // 4 = 9 batches per epoch: 18 batches cross two epoch boundaries
+                b = next(got)
+                torch.cuda._sleep(20_000_000)  # ~10 ms of compute-stream work queued in front of this batch's first reader
+                held.append(tuple(t.clone() if torch.is_tensor(t) else t for t in b))  # the late read, on the compute stream
+                del b
+            torch.cuda.synchronize()
+            for h in held:
+                a = next(ref)
+                assert a[2] == h[2] == 0
+                for x, y in zip(a[:2] + a[3:], h[:2] + h[3:]):
+                    assert x.dtype == y.dtype and x.shape == y.shape and y.is_cuda
+                    assert torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0))
+            thread = stream._thread
+        assert stream._thread is None and not thread.is_alive() and stream._slots == []  # close() joined the producer
+
+
+def test_run_train_streaming_equals_resident(tmp_path):
+    """run_train on decoded-frame shards with DEVICE_RESIDENT_DATA 'off' + SHARD_INPUT 'stream' (HostFrameStream) ends with the
+    parameters of the HBM-resident run: same minibatch sequence, same updates (deterministic sums: bit for bit)."""
+    from test_shards_cpu import _make_dataset
+    from video_dqn_amd.config import ExperimentConfig
+    from video_dqn_amd.shards import build_shards
+    from video_dqn_amd.trainer import run_train
+    feather = _make_dataset(tmp_path, n=9)
+    shards = str(tmp_path / "shards")
+    build_shards(feather, shards, shard_frames=4, log=lambda *a: None)
+    finals = []
+    for tag, extra in (("resident", "DEVICE_RESIDENT_DATA: 'on'\n"), ("stream", "DEVICE_RESIDENT_DATA: 'off'\nSHARD_INPUT: 'stream'\nHOST_GATHER_THREADS: 2\n")):
+        folder = tmp_path / f"exp_{tag}"
+        folder.mkdir()
+        (folder / "config.yml").write_text(
+            f"DATASET: '{shards}'\nPANORAMA: False\nLOSS_CLIP: 'rect'\nARCHITECTURE: 'extra_capacity'\nUSE_INVERSE_ACTIONS: True\n"
+            "LEARNING_RATE: 0.0001\nCHECKPOINT_INTERVAL: 5\nNUM_STEPS: 5\nSEED: 4\nBATCH_SIZE: 4\nNUM_WORKERS: 0\nCOMPUTE_DTYPE: 'f32'\n"
+            "DETERMINISTIC: True\n" + extra)
+        logs = []
+        cfg = ExperimentConfig(str(folder), device="cuda", tensorboard=False)
+        model, stepper, running = run_train(cfg, log=lambda *a: logs.append(" ".join(str(x) for x in a)))
+        assert any(("resident in HBM" if tag == "resident" else "streamed from memory-mapped shards") in l for l in logs), logs
+        assert np.isfinite(running) and os.path.exists(folder / "models" / "sample5.torch")
+        finals.append((model.engine.params.cpu().clone(), running))
+    assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]

@@ -389,9 +389,10 @@ def test_frames_packed_one_update_ahead_is_the_same_update(dtype):
 
 @pytest.mark.parametrize("dtype", ["bf16"])
 def test_frames_announced_ahead_may_alias_this_calls_tensors(dtype):
-    """`next_frames` that ARE this call's tensors.  A loop that replays one resident minibatch (bench.py --pack-ahead
-    --pool 1) gets a valid pack; a loop that refills fixed staging tensors in place advances their `_version`, so the pack announced
-    on the old content is discarded and the call packs its own frames.  Both bit-equal to the loop without announcements."""
+    """ADVICE rounds 4-5: `next_frames` that ARE this call's tensors.  A loop that replays one resident minibatch (bench.py --pack-ahead
+    --pool 1) announces them with the explicit promise (fourth element True) and gets a valid pack; a loop that refills fixed staging
+    tensors announces without it — the aliased announcement is ignored and the call packs its own frames, whatever wrote the tensors
+    (here once through copy_, once through `.data`, which does not advance `_version`).  All bit-equal to the loop without announcements."""
     from video_dqn_amd.engine import TDStepper
     B = 4
     batches = []
@@ -407,13 +408,16 @@ def test_frames_announced_ahead_may_alias_this_calls_tensors(dtype):
         for i in range(6):
             b = batches[0] if mode.startswith("replay") else batches[i % 3]
             if mode.startswith("refill"):
-                sb.copy_(b[0]); sa.copy_(b[1])
+                if mode.startswith("refill_data"):
+                    sb.data.copy_(b[0]); sa.data.copy_(b[1])
+                else:
+                    sb.copy_(b[0]); sa.copy_(b[1])
                 b = (sb, sa) + b[2:]
-            nxt = b[:3] if mode.endswith("announced") else None
+            nxt = (b[:3] + ((True,) if mode.startswith("replay") else ())) if mode.endswith("announced") else None
             losses.append(stp.step(*b, next_frames=nxt).clone())
         torch.cuda.synchronize()
         return net.params.clone(), torch.cat(losses)
-    for kind in ("replay", "refill"):
+    for kind in ("replay", "refill", "refill_data"):
         p0, l0 = run(kind)
         p1, l1 = run(kind + "_announced")
         assert torch.equal(p0, p1) and torch.equal(l0, l1), kind
@@ -566,43 +570,6 @@ def test_side_stream_overlap_matches_serial():
     net.lib.vdqn_net_set_overlap(net.handle, 1)
 
 
-@pytest.mark.parametrize("dtype,B,F", [("bf16", 128, 1), ("bf16", 8, 1), ("f32", 4, 1), ("bf16", 4, 4)])
-@pytest.mark.variants
-def test_grouped_forward_is_bit_identical_to_two_passes(dtype, B, F):
-    """The online pass over [s; s'] and the target pass over s' as ONE chain of grouped launches (vdqn_step_args.acts_target == NULL,
-    vdqn_conv_args.wt_b: tiles from row 2B*H*W on take the target network's weights) against the two separate passes
-    (train_q_network.py:131,140,142 — three model calls): Q(s), the online Q(s'), the TARGET Q(s') and every saved activation
-    of the online range must be the same bits, hence loss and (deterministic mode) gradients too.  B = 128 puts every layer on
-    its grouped kernel (split rows a multiple of 256); B = 8 / 4 mix grouped kernels with the internal two-launch fall-back
-    (14 x 14 and 7 x 7 maps: 2B*H*W is not a multiple of the tile height); f32 runs the kernels that have no grouped form."""
-    from video_dqn_amd.engine import NetEngine, TDStepper
-    res = {}
-    for grouped in (False, True):
-        net = NetEngine(3, 5, F, True, dtype, 2 * B, deterministic=True)
-        net.load_tensors(synth.make_state_dict(7, num_frames=F))
-        stp = TDStepper(net, B, lr=1e-4, gamma=0.99, clip_rect=True, grouped_forward=grouped)
-        tnet = NetEngine(3, 5, F, True, dtype, 2 * B)
-        tnet.load_tensors(synth.make_state_dict(8, num_frames=F))  # a target network that differs from the online one
-        tnet.pack_weights(stp.packed_target)
-        assert stp.grouped == grouped and (stp.acts_target is None) == grouped
-        (tup, raw) = synth.make_batch(900 + B, B, F, structured=True, reward_p=0.3)
-        stp.forward_backward(torch.from_numpy(raw[0]).to(DEV), torch.from_numpy(raw[1]).to(DEV), 0, tup[2].to(DEV), tup[3].float().to(DEV), tup[4].float().to(DEV))
-        torch.cuda.synchronize()
-        n = stp.layout_samples
-        q_all = _act_f32(net, stp.acts_online, n, "qf", (n, 64)).clone()
-        q_tgt = q_all[2 * B:3 * B] if grouped else _act_f32(net, stp.acts_target, B, "qf", (B, 64)).clone()
-        acts = {name: _act(net, stp.acts_online, n, name, (n * F, 56 >> (int(name[1]) // 2), 56 >> (int(name[1]) // 2), 64 << (int(name[1]) // 2)))[:2 * B * F].clone()
-                for name in ("o0", "h2", "o3", "o5", "h7", "o7")}
-        res[grouped] = (q_all[:2 * B], q_tgt, stp.loss.clone(), stp.grads.clone(), acts)
-    a, b = res[False], res[True]
-    assert torch.equal(a[0], b[0]), "online Q differs"
-    assert torch.equal(a[1], b[1]), "target Q differs"
-    assert (a[1] != a[0][B:]).any()  # the target range really used the other weight set
-    for name in a[4]:
-        assert torch.equal(a[4][name], b[4][name]), name
-    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
-
-
 def _act_f32(net, buf, n_samples, name, shape):
     off = net.lib.vdqn_net_act_offset(net.handle, n_samples, name.encode())
     assert off >= 0, name
@@ -728,7 +695,6 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
 
 
 @pytest.mark.parametrize("env", [
-    pytest.param({"VDQN_SPLIT_ONLINE": "1"}, marks=pytest.mark.variants),       # online forward as two half-batch passes on two streams
     pytest.param({"VDQN_FUSE_POOL_BWD": "0"}, marks=pytest.mark.variants),      # max-pool backward + stem weight gradient as two launches
     pytest.param({"VDQN_WIN9_BM256": "2"}, marks=pytest.mark.variants),         # 256-row tiles of the nine-tap window kernel everywhere
     pytest.param({"VDQN_WIN9_BM256": "0", "VDQN_WIN9_PERSIST256": "0"}, marks=pytest.mark.variants),  # ... nowhere (rounds 1-4), and their round-4 form: one workgroup per tile
@@ -738,28 +704,16 @@ def test_deterministic_wgrad_operator_matches_atomic_mode():
     pytest.param({"VDQN_S2WIN_PERSIST": "0"}, marks=pytest.mark.variants),      # stride-2 plane-window kernel: one workgroup per tile (no tile walk)
     pytest.param({"VDQN_S2WIN_PERSIST": "-1", "VDQN_FUSE_DS": "1"}, marks=pytest.mark.variants),  # ... and round 4's kernel for it
     {"VDQN_S2DGRAD_WIN": "0"},        # stride-2 data gradients on the generic class-tiled kernel instead of the plane-window kernel
-    pytest.param({"VDQN_WIN9_MIXED": "1"}, marks=pytest.mark.variants),         # whole rounds of a window-kernel launch on 256-row tiles, the rest on 128-row tiles (off: slower)
-    pytest.param({"VDQN_WGRAD_S2WIN": "1"}, marks=pytest.mark.variants),        # stride-2 weight gradients on the stride-2 window tiles (off by default: slower)
-    pytest.param({"VDQN_WIN9_SPLITK": "1"}, marks=pytest.mark.variants),        # split-K remainder launches of the nine-tap window kernel (scratch in the workspaces; off by default)
-    pytest.param({"VDQN_WIN9_BALANCED": "2"}, marks=pytest.mark.variants),      # balanced row walk of the nine-tap window kernel (two launches per convolution)
-    pytest.param({"VDQN_GROUPED_FWD": "1"}, marks=pytest.mark.variants),        # online and target forward as one chain of grouped launches
-    pytest.param({"VDQN_GROUPED_FWD": "1", "VDQN_GROUPED_LAUNCH": "0"}, marks=pytest.mark.variants),  # grouped forward, every layer through the internal two-launch fall-back
-    pytest.param({"VDQN_WIN9_MFMA32": "1"}, marks=pytest.mark.variants),        # nine-tap window kernel on 32x32x16 MFMAs (win9m.hip)
-    pytest.param({"VDQN_WIN9_MFMA32": "0"}, marks=pytest.mark.variants),        # ... on 16x16x32 MFMAs (win9.hip)
-    pytest.param({"VDQN_WGRAD_WINDOW": "1"}, marks=pytest.mark.variants),       # round 2's choice: 64x64 window weight-gradient tiles up to 256 channels, generic 128x128 tiles for layer4
-    pytest.param({"VDQN_WGRAD_WIN128": "1"}, marks=pytest.mark.variants),       # eight-wave 128x128 window weight-gradient tiles for the 128+ channel layers
     pytest.param({"VDQN_WGRAD_TWO_STAGE": "1"}, marks=pytest.mark.variants),    # split-K partials as plain stores + ordered reduce kernels instead of f32 atomics
+    pytest.param({"VDQN_WGRAD_WINDOW": "0"}, marks=pytest.mark.variants),       # the 3x3 / stride-1 weight gradients on the generic kernel (no window tiles)
     {"VDQN_WGRAD_STREAMS": "1"},      # all weight gradients on ONE side stream (default: alternating between the two)
     pytest.param({"VDQN_S2WIN": "0"}, marks=pytest.mark.variants),              # stride-2 3x3 forward convolutions on the generic kernel (no plane-window kernel)
     pytest.param({"VDQN_STEM_NOIDX": "0"}, marks=pytest.mark.variants),         # the stem writes the max-pool arg-max bytes of the no-grad frames too
     {"VDQN_EARLY_ADAM": "0"},         # TDStepper.step: one Adam launch behind the whole backward pass
-    pytest.param({"VDQN_PACK_AFTER_FIRST": "1"}, marks=pytest.mark.variants),   # the s' frames packed first and the target pass right behind them, the s frames on the caller's stream
-    pytest.param({"VDQN_FOLD_SPLIT": "1"}, marks=pytest.mark.variants),         # weight fold of stage 2's layers first, the rest on the side stream beside the stem
     pytest.param({"VDQN_STEM_WGRAD_MAIN": "0"}, marks=pytest.mark.variants),    # conv1's weight gradient on the side stream behind block 0's instead of beside them
     {"VDQN_SKINNY": "0"},             # the Q-head's layers on the generic tiled kernel instead of the skinny GEMM kernels
     pytest.param({"VDQN_SKINNY_CONV_CFG": "9"}, marks=pytest.mark.variants),    # features.8 on the skinny kernel that reads its input from global memory (default: images in LDS)
     pytest.param({"VDQN_SIDE_PRIORITY": "normal"}, marks=pytest.mark.variants), # the side streams at the caller's stream priority (default: below it)
-    pytest.param({"VDQN_EARLY_FOLD": "1", "VDQN_PACK_TWO_STREAMS": "1"}, marks=pytest.mark.variants),  # stage 0 / 1 weights folded behind their early Adam; the two input packs on two streams
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) if isinstance(e, dict) else None)
 def test_non_default_kernel_selections(env):
     """The switches that select a non-default kernel or stream arrangement (read once per process) keep the engine's parity and

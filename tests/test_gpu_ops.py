@@ -195,41 +195,6 @@ def test_conv_wgrad(case, dtype, splitk):
     assert relerr(db.cpu()[:co], gy.sum((0, 2, 3))) < TOL_F32OUT[dtype]
 
 
-S2W_CASES = [  # n, ci, co, h (even): 3x3 / stride 2 / pad 1 with 128+ channels on both sides -> wgrad_win_kernel<128, 128, 8, true>
-    (5, 256, 512, 14), (2, 128, 256, 28), (9, 128, 128, 4), (3, 128, 256, 8), (1, 256, 128, 56), (21, 128, 128, 6), (2, 128, 384, 12),
-]
-
-
-@pytest.mark.parametrize("splitk", [0, 1, 5])
-@pytest.mark.parametrize("case", S2W_CASES)
-@pytest.mark.variants
-def test_conv_wgrad_stride2_window_kernel(case, splitk):
-    """Weight gradient of the 3x3 / stride-2 convolutions (conv1 of layer3.0 / layer4.0's geometry) on the stride-2 window tiles
-    (round 5; VDQN_WGRAD_S2WIN=1 — off by default, it measured slower than the generic kernel): one staged window of the kernel row's input rows serves its three taps at a stride of two window rows per pixel.
-    Against torch — images of 2 x 2 to 28 x 28 output pixels (windows that span many images, left-column and top-row borders in
-    almost every fragment), co != ci, pixel ranges split 1 / 5 ways — and in deterministic mode twice, bit for bit."""
-    from video_dqn_amd import ops, _lib
-    n, ci, co, h = case
-    dtype = torch.bfloat16
-    ho = h // 2
-    x = q(rnd(91, "x", (n, ci, h, h)), dtype)
-    gy = q(rnd(92, "gy", (n, co, ho, ho)), dtype)
-    ref = F.grad.conv2d_weight(x, (co, ci, 3, 3), gy, 2, 1)
-    kw = dict(co=co, r=3, s=3, stride=2, pad=1, splitk=splitk, want_dbias=False)
-    lib = _lib.load()
-    gen = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), **kw)  # the generic kernel (what ships: the window form measured slower)
-    lib.vdqn_debug_set_wgrad_s2win(1)
-    try:
-        dw = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), **kw)
-        d1 = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), deterministic=True, poison_workspace=True, **kw)
-        d2 = ops.conv2d_wgrad(nhwc(gy, dtype), nhwc(x, dtype), deterministic=True, poison_workspace=True, **kw)
-        torch.cuda.synchronize()
-    finally:
-        lib.vdqn_debug_set_wgrad_s2win(-1)
-    assert relerr(dw.cpu()[:co].permute(0, 3, 1, 2), ref) < TOL_F32OUT[dtype]
-    assert torch.equal(d1, d2) and relerr(d1, dw) < 1e-5 and relerr(gen, dw) < 1e-4
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(3, 64, 100, 9, 3, 1, 1), (2, 128, 15, 6, 1, 1, 0), (2, 128, 130, 8, 3, 2, 1)])
 def test_conv_wgrad_deterministic_with_ragged_co(case, dtype):
@@ -659,39 +624,6 @@ def test_nine_tap_kernel_256_row_tiles():
                        env=dict(os.environ, VDQN_WIN9_BM256="2"), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
 
-
-@pytest.mark.parametrize("mfma32", ["0", "1"])
-@pytest.mark.variants
-def test_nine_tap_kernels_both_mfma_shapes(mfma32):
-    """The nine-tap window kernel exists on 16x16x32 MFMAs (win9.hip) and on 32x32x16 MFMAs (win9m.hip: other fragment layout,
-    other LDS swizzles, its own epilogue); VDQN_WIN9_MFMA32 (read once per process) selects one.  The operator tests that reach
-    it — layer2-4 geometries, edge geometries, persistent multi-tile launches, non-square images, forward with residual + ReLU
-    and f32 output, data gradient with mask and column sums — run in a child process under each setting."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "(nine_tap and not both_mfma and not 256_row) or (test_conv_forward and bfloat16) or (test_conv_dgrad and bfloat16)"],
-                       env=dict(os.environ, VDQN_WIN9_MFMA32=mfma32), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]
-
-
-@pytest.mark.parametrize("win128", ["0", "1"])
-@pytest.mark.variants
-def test_weight_gradient_kernels_both_tilings(win128):
-    """The 3x3 / stride-1 weight gradients of the 128+ channel layers run on 64 x 64 window / generic 128 x 128 tiles (default) or on
-    128 x 128 window tiles (eight waves, VDQN_WGRAD_WIN128=1): the weight-gradient operator tests under each setting."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), os.path.join(root, "tests", "test_gpu_engine.py"),
-                        "-m", "gpu", "-q", "-x", "-k", "(test_conv_wgrad and not both_tilings) or deterministic_wgrad_operator"],
-                       env=dict(os.environ, VDQN_WGRAD_WIN128=win128), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]
-
-
 S2P_CASES = [  # n, ci, planes, h, pretend-CUs: layer2.0 / 3.0 / 4.0 chunk counts (1 / 2 / 4), tile walks of 2 - 13 tiles per workgroup
     (21, 64, 128, 28, 4), (9, 64, 128, 56, 5), (40, 128, 256, 20, 4), (17, 128, 256, 28, 7), (90, 256, 512, 14, 4), (33, 256, 512, 12, 9),
     (3, 64, 128, 8, 4), (2, 128, 256, 6, 4), (2, 256, 512, 4, 4),
@@ -737,46 +669,6 @@ def test_stride2_persistent_kernel_with_fused_downsample(case, sib):
         torch.cuda.synchronize()
         assert torch.equal(one_out2, sep2)
         assert relerr(one_out2.float().cpu().permute(0, 3, 1, 2), F.conv2d(x, w2, b2, 2, 0)) < TOL[dtype]
-
-
-BAL_CASES = [  # n, c (ci = co), h, pretend-CUs: column tiles 1 / 2 / 4; ranges of 1 - 6 tiles whose last tile holds 16, <= 16, 17 - 64, > 64 rows
-    (37, 128, 28, 4), (16, 128, 28, 4), (9, 128, 20, 12), (61, 256, 14, 8), (40, 256, 14, 16), (90, 512, 7, 16),
-    (2, 128, 28, 4), (4, 128, 28, 8), (8, 256, 14, 8),   # ranges of 208 rows: the last tile holds 80 (second wave row: one fragment)
-    (21, 512, 7, 16), (8, 128, 12, 4), (29, 128, 6, 4),  # ranges of 144 rows: the last tile holds 16 (first wave row: one fragment, second: none)
-]
-
-
-@pytest.mark.parametrize("case", BAL_CASES)
-@pytest.mark.variants
-def test_nine_tap_window_kernel_balanced_walk(case):
-    """win9u_kernel's balanced walk (round 5, forward; an off-by-default switch — it measured slower than the static walk): the rows of
-    a launch are split EVENLY over the resident workgroups of each column tile, every workgroup walks its range in 128-row tiles
-    (first launch) and a second launch computes every range's partial last tile, in which a wave computes all four, one or none of
-    its 16-row fragments.  With the device pretended to have 4 - 32 CUs small tensors take that walk; the output
-    must be BIT-IDENTICAL to the one-workgroup-per-tile launch of the same kernel (same K order per element) and match torch."""
-    from video_dqn_amd import ops, _lib
-    n, c, h, cus = case
-    dtype = torch.bfloat16
-    x = q(rnd(61, "x", (n, c, h, h)), dtype)
-    w = q(rnd(62, "w", (c, c, 3, 3), -0.05, 0.05), dtype)
-    b = rnd(63, "b", (c,))
-    res = q(rnd(64, "res", (n, c, h, h)), dtype)
-    kw = dict(ho=h, wo=h, co=c, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
-    lib = _lib.load()
-    one = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), **kw)  # the real CU count: at most one round of tiles -> one tile per workgroup
-    torch.cuda.synchronize()
-    lib.vdqn_debug_set_num_cus(cus)
-    lib.vdqn_debug_set_win9_balanced(1)  # (off by default since it measured slower: DESIGN.md section 6d)
-    lib.vdqn_debug_set_win9_bm256(0)     # (the walk exists for 128-row tiles)
-    try:
-        bal = ops.conv2d(nhwc(x, dtype), krsc(w, dtype), **kw)
-        torch.cuda.synchronize()
-    finally:
-        lib.vdqn_debug_set_num_cus(0)
-        lib.vdqn_debug_set_win9_balanced(-1)
-        lib.vdqn_debug_set_win9_bm256(-1)
-    assert torch.equal(bal, one)
-    assert relerr(one.float().cpu().permute(0, 3, 1, 2), F.relu(F.conv2d(x, w, b, 1, 1) + res)) < TOL[dtype]
 
 
 S2D_CASES = [  # n, ci (of the forward conv = columns of the gradient), planes (gy channels), h, pretend-CUs
@@ -832,74 +724,3 @@ def test_stride2_data_gradient_plane_window_kernel(case, sib):
     assert relerr(one.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
     assert relerr(part.sum(0).cpu(), one.float().cpu().sum((0, 1, 2))) < 1e-4
 
-
-SK_CASES = [  # n, channels, h, pretend-CUs (resident workgroups = 2 x CUs, a multiple of 8)
-    (6, 256, 14, 8),     # 20 tiles on 16 slots: 4 remainder tiles, one per XCD, two workgroups x 2 chunks each
-    (7, 256, 14, 12),    # 22 tiles on 24 slots ... no whole round: unsplit; kept as the "nothing to split" case
-    (16, 256, 14, 12),   # 50 tiles on 24 slots: 2 remainder tiles of 4 chunks over 3 workgroups per XCD: runs of 1, 1, 2 (odd runs)
-    (5, 128, 28, 8),     # layer2: 2 chunks per tile, 31 tiles on 16 slots: 15 remainder tiles, runs of 1-2 chunks, whole and half tiles
-    (40, 512, 7, 8),     # layer4: 8 chunks per tile, 64 tiles (4 column tiles) on 16 slots: no remainder -> unsplit
-    (43, 512, 7, 8),     # 68 tiles: 4 remainder tiles x 8 chunks over 2 workgroups per XCD: 4 chunks each
-    (45, 512, 7, 20),    # 72 tiles on 40 slots: 32 remainder tiles over 5 workgroups per XCD: runs that cross tiles, up to 3 parts per tile
-    (24, 128, 28, 20),   # 147 tiles on 40 slots: 27 remainder tiles of 2 chunks
-]
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("case", SK_CASES)
-@pytest.mark.variants
-def test_nine_tap_window_kernel_split_k_remainder(case, mode):
-    """win9u_kernel<.., 3> (round 5): the tiles behind a launch's last WHOLE round of resident workgroups are split along K — each
-    workgroup of an XCD takes an equal run of the remainder's channel chunks, writes its f32 partial tile to the caller's scratch and
-    the last arriver of a tile adds the parts in part order and runs the epilogue.  Against the unsplit kernel (same bf16 outputs up
-    to the re-association of one f32 sum: a few last-bit differences at most), against torch, twice in a row bit-identically, and from a
-    scratch buffer full of garbage (the first launch clears the arrival counters).  Forward (bias + residual + ReLU) and data
-    gradient (mask + residual + column sums)."""
-    from video_dqn_amd import ops, _lib
-    if os.environ.get("VDQN_WIN9_MFMA32") == "1":
-        pytest.skip("the 32x32x16 variant of the window kernel (win9m.hip) has no split-K remainder")
-    # (the launcher's own choice of 256-row tiles — which have no split-K remainder either — is switched off for this test's calls)
-    n, c, h, cus = case
-    dtype = torch.bfloat16
-    lib = _lib.load()
-    x = q(rnd(81, "x", (n, c, h, h)), dtype)
-    w = q(rnd(82, "w", (c, c, 3, 3), -0.05, 0.05), dtype)
-    res = q(rnd(84, "res", (n, c, h, h)), dtype)
-    if mode == 0:
-        b = rnd(83, "b", (c,))
-        kw = dict(ho=h, wo=h, co=c, r=3, s=3, stride=1, pad=1, bias=b.to(DEV), resid=nhwc(res, dtype), relu=True)
-        wt = krsc(w, dtype)
-        ref = F.relu(F.conv2d(x, w, b, 1, 1) + res)
-    else:
-        xact = q(rnd(85, "xa", (n, c, h, h)), dtype)
-        kw = dict(ho=h, wo=h, co=c, r=3, s=3, stride=1, pad=1, mode=1, mask=nhwc(xact, dtype), resid=nhwc(res, dtype), want_colsum=True)
-        wt = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(DEV)  # [ci][3][3][co]
-        ref = (F.grad.conv2d_input((n, c, h, h), w, x, 1, 1) + res) * (xact > 0)
-    ws = torch.empty(ops.splitk_workspace_bytes(), dtype=torch.uint8, device=DEV)
-    lib.vdqn_debug_set_num_cus(cus)
-    lib.vdqn_debug_set_win9_splitk(2)  # split whenever there is a whole round and a remainder (the launcher's default also asks that it pays)
-    lib.vdqn_debug_set_win9_bm256(0)   # (128-row tiles: the 256-row form has no split-K remainder)
-    try:
-        plain = ops.conv2d(nhwc(x, dtype), wt, **kw)
-        torch.cuda.synchronize()
-        ws.fill_(0xA5)
-        a = ops.conv2d(nhwc(x, dtype), wt, splitk_ws=ws[:ops.splitk_workspace_bytes()], **kw)
-        torch.cuda.synchronize()
-        counters = ws[:4096].clone()
-        b2 = ops.conv2d(nhwc(x, dtype), wt, splitk_ws=ws[:ops.splitk_workspace_bytes()], **kw)
-        torch.cuda.synchronize()
-    finally:
-        lib.vdqn_debug_set_num_cus(0)
-        lib.vdqn_debug_set_win9_splitk(-1)
-        lib.vdqn_debug_set_win9_bm256(-1)
-    if mode == 1:
-        (plain, part_p), (a, part_a), (b2, part_b) = plain, a, b2
-        assert torch.equal(part_a, part_b)
-        assert relerr(part_a.sum(0).cpu(), a.float().cpu().sum((0, 1, 2))) < 1e-4
-    assert torch.equal(a, b2)
-    tiles = ((n * h * h + 127) // 128) * (c // 128)
-    if tiles > 2 * cus and tiles % (2 * cus) != 0:
-        assert (counters.view(torch.int32) == 0).all()  # every split tile was finished by its last arriver, which cleared its counter
-    d = (a.float() - plain.float()).abs()
-    assert (d > 0).float().mean().item() < 0.02 and relerr(a.float().cpu(), plain.float().cpu()) < 5e-3  # (one bf16 step of the largest outputs)
-    assert relerr(a.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]

@@ -22,19 +22,17 @@ LAYERS = [  # name, ci, co, hi, k, stride, pad
 def main(n_fwd=512, n_bwd=256, reps=20, dtype=torch.bfloat16):
     dev = "cuda"
     rows = []
-    # SPLITK=1: hand every call the scratch of the window kernel's split-K remainder (include/vdqn.h: vdqn_conv_args.splitk_ws)
-    ws = torch.empty(ops.splitk_workspace_bytes(), dtype=torch.uint8, device=dev) if os.environ.get("SPLITK") == "1" else None
     for name, ci, co, hi, k, stride, pad in LAYERS:
         ho = (hi + 2 * pad - k) // stride + 1
         for mode, n in ((0, n_fwd), (1, n_bwd)):
             if mode == 0:
                 x = torch.randn((n, hi, hi, ci), device=dev).to(dtype)
                 w = (torch.randn((co, k, k, ci), device=dev) * 0.05).to(dtype)
-                kw = dict(ho=ho, wo=ho, co=co, r=k, s=k, stride=stride, pad=pad, relu=True, bias=torch.zeros(co, device=dev), splitk_ws=ws)
+                kw = dict(ho=ho, wo=ho, co=co, r=k, s=k, stride=stride, pad=pad, relu=True, bias=torch.zeros(co, device=dev))
             else:  # data gradient: gy [n, ho, ho, co] -> gx [n, hi, hi, ci]
                 x = torch.randn((n, ho, ho, co), device=dev).to(dtype)
                 w = (torch.randn((ci, k, k, co), device=dev) * 0.05).to(dtype)
-                kw = dict(ho=hi, wo=hi, co=ci, r=k, s=k, stride=stride, pad=pad, mode=1, splitk_ws=ws)
+                kw = dict(ho=hi, wo=hi, co=ci, r=k, s=k, stride=stride, pad=pad, mode=1)
             for _ in range(3):
                 ops.conv2d(x, w, **kw)
             torch.cuda.synchronize()

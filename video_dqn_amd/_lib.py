@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", f"libvdqn{'_' + os.environ['VDQN_LIB'] if os.environ.get('VDQN_LIB') else ''}.so")
 
 VDQN_F32, VDQN_BF16 = 0, 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -26,8 +26,7 @@ class ConvArgs(C.Structure):
                 ("mode", c_i32), ("relu", c_i32), ("dtype", c_i32),
                 ("in2", c_vp), ("wt2", c_vp), ("bias2", c_vp), ("out2", c_vp),
                 ("co2", c_i32), ("ldo2", c_i32), ("relu2", c_i32), ("ci2", c_i32),
-                ("wt_b", c_vp), ("bias_b", c_vp), ("split_img", c_i32),
-                ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64)]
+]
 
 
 class WgradArgs(C.Structure):
@@ -69,7 +68,7 @@ class StepArgs(C.Structure):
                 ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("train_on_ground_truth", c_i32),
                 ("value_learning", c_i32),
                 ("acts_online", c_vp), ("acts_target", c_vp), ("bwd", c_vp), ("grads", c_vp), ("loss", c_vp),
-                ("q_before", c_vp), ("loss_kind", c_i32), ("packed_frames", c_vp), ("prefolded_stages", c_i32), ("acts_samples", c_i32)]
+                ("q_before", c_vp), ("loss_kind", c_i32), ("packed_frames", c_vp), ("acts_samples", c_i32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, c_vp, c_vp, c_i64, c_vp)  # vdqn_allreduce_fn(user, buf, count, stream)
@@ -82,7 +81,6 @@ _SIGS = {
     "vdqn_conv2d": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
     "vdqn_abi_struct_size": (c_i32, [c_i32]),
     "vdqn_conv2d_colsum_rows": (c_i32, [C.POINTER(ConvArgs)]),
-    "vdqn_conv2d_splitk_workspace_bytes": (c_i64, []),
     "vdqn_conv2d_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
     "vdqn_conv2d_wgrad_workspace_bytes": (c_i64, [C.POINTER(WgradArgs)]),
     "vdqn_pack_input": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp]),
@@ -105,7 +103,6 @@ _SIGS = {
     "vdqn_stem_wgrad_pool_workspace_bytes": (c_i64, [c_i32]),
     "vdqn_net_set_overlap": (C.c_int, [c_vp, C.c_int]),
     "vdqn_net_grad_stream": (c_vp, [c_vp]),
-    "vdqn_net_aux_stream": (c_vp, [c_vp]),
     "vdqn_net_set_bn_sync": (C.c_int, [c_vp, c_vp, c_vp, c_i32]),
     "vdqn_net_num_params": (C.c_int, [c_vp]),
     "vdqn_net_param_info": (C.c_int, [c_vp, C.c_int, C.POINTER(ParamInfo)]),
@@ -119,7 +116,6 @@ _SIGS = {
     "vdqn_net_act_offset": (c_i64, [c_vp, c_i32, C.c_char_p]),
     "vdqn_net_bwd_offset": (c_i64, [c_vp, c_i32, C.c_char_p]),
     "vdqn_net_pack_weights": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
-    "vdqn_net_pack_weights_stage": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vdqn_net_forward": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vdqn_net_trunk_forward": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "vdqn_softmax_rows": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

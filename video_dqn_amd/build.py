@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 _VARIANT = os.environ.get("VDQN_LIB_OUT", "")
 OBJ_DIR = os.path.join(LIB_DIR, "obj", _VARIANT or "main")
 LIB_PATH = os.path.join(LIB_DIR, f"libvdqn{'_' + _VARIANT if _VARIANT else ''}.so")
-SOURCES = ["igemm.hip", "win9.hip", "win9m.hip", "win9s.hip", "win9d.hip", "skinny.hip", "stem.hip", "wgrad.hip", "pointwise.hip", "bn_train.hip", "engine.hip", "profile.hip", "comm.hip", "hostio.hip"]
+SOURCES = ["igemm.hip", "win9.hip", "win9s.hip", "win9d.hip", "skinny.hip", "stem.hip", "wgrad.hip", "pointwise.hip", "bn_train.hip", "engine.hip", "profile.hip", "comm.hip", "hostio.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm_common.h"), os.path.join(os.path.dirname(HERE), "include", "vdqn.h")]
 CFLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 

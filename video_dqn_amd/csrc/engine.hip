@@ -29,7 +29,7 @@ void vdqn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vdqn_last_error(void) { return g_err; }
-extern "C" int vdqn_abi_version(void) { return 13; }
+extern "C" int vdqn_abi_version(void) { return 14; }
 extern "C" int32_t vdqn_abi_struct_size(int32_t which) {
   switch (which) {
     case 0: return (int32_t)sizeof(vdqn_conv_args);
@@ -93,7 +93,6 @@ struct ActLayout {
   // ARCHITECTURE='basic' only: pooled features, raw (pre-BatchNorm) conv outputs, per-layer BatchNorm work areas
   int64_t avg, r_c1, r_h[8], r_o[8], r_ds[8], bnw[kMaxLayers], bnw_begin, bnw_bytes, bn_sync;
   int64_t bn_det = -1, bn_det_bytes = 0;  // deterministic mode ('basic'): per-block partial sums of the train-mode BatchNorm kernels
-  int64_t sk = -1, sk_bytes = 0;          // scratch of the window kernel's split-K remainder (vdqn_conv_args.splitk_ws): one per pass
   int64_t total;
 };
 struct BwdLayout {
@@ -102,7 +101,6 @@ struct BwdLayout {
   int64_t p_l1, p_l0, p_f8, p_o[8], p_h[8], p_pool;  // per-128-row-tile column sums written by the dgrad epilogues
   int64_t g_avg, g_or[8], g_dsr[8];  // 'basic' only: gradient of the pooled features / of the raw conv2, downsample outputs
   int64_t det_ws, det_ws_bytes;      // deterministic mode: the weight-gradient kernels' partial copies (one layer at a time)
-  int64_t sk = -1, sk_bytes = 0;     // scratch of the window kernel's split-K remainder (data-gradient chain)
   int64_t total;
 };
 
@@ -728,11 +726,6 @@ void build_layers(vdqn_net* net) {
   }
 }
 
-// The split-K remainder of the nine-tap window kernel (win9.hip) changes how the f32 sum of a split tile is associated, by call
-// shape: the deterministic mode — whose contract includes "one 2B pass == two B passes == a grouped pass, bit for bit" — keeps the
-// unsplit kernel; f32 engines never reach that kernel.
-bool net_splitk(const vdqn_net* net);
-
 ActLayout act_layout(const vdqn_net* net, int n_samples) {
   const int64_t F = net->cfg.num_frames, n = (int64_t)n_samples * F, e = net->esz;
   ActLayout L;
@@ -790,40 +783,12 @@ ActLayout act_layout(const vdqn_net* net, int n_samples) {
       L.bn_det = take(L.bn_det_bytes);
     }
   }
-  if (net_splitk(net)) {
-    L.sk_bytes = vdqn_conv2d_splitk_workspace_bytes();
-    L.sk = take(L.sk_bytes);
-  }
   L.total = off;
   return L;
 }
 
 vdqn_wgrad_args wgrad_shape_args(const vdqn_net* net, const Layer& L, int n_units);
 int64_t wgrad_max_imgs(const vdqn_net* net, const Layer& L);
-
-// the same layout seen from sample `first`: every tensor's offset advanced by `first` samples (extra_capacity tensors only) —
-// lets one half of a batch run through forward_impl on its own stream
-ActLayout shift_layout(const vdqn_net* net, ActLayout A, int first) {
-  const int64_t F = net->cfg.num_frames, e = net->esz, s = first;
-  A.sk = -1;  // (the half that runs beside the unshifted one must not share its split-K scratch)
-  A.sk_bytes = 0;
-  A.t_in += s * F * 115 * 115 * 16 * e;
-  A.pool += s * F * 56 * 56 * 64 * e;
-  A.idx += s * F * 56 * 56 * 64;
-  for (int b = 0; b < 8; ++b) {
-    const int64_t planes = 64 << (b / 2), sp = 56 >> (b / 2);
-    const int64_t per = F * sp * sp * planes * e;
-    A.h[b] += s * per;
-    A.o[b] += s * per;
-    if (A.ds[b] >= 0) A.ds[b] += s * per;
-  }
-  A.f8 += s * F * 25 * 64 * e;
-  A.l0 += s * 512 * e;
-  A.l1 += s * 256 * e;
-  A.q += s * 64 * e;
-  A.qf += s * 64 * 4;
-  return A;
-}
 
 bool wgrad_two_stage();
 
@@ -887,10 +852,6 @@ BwdLayout bwd_layout(const vdqn_net* net, int n_samples) {
       if (b % 2 == 0 && b > 0) L.g_dsr[b] = take(n * sp * sp * planes * e);
     }
   }
-  if (net_splitk(net)) {
-    L.sk_bytes = vdqn_conv2d_splitk_workspace_bytes();
-    L.sk = take(L.sk_bytes);
-  }
   L.total = off;
   return L;
 }
@@ -950,37 +911,15 @@ int fuse_ds_mask() {
   return m;
 }
 bool fuse_ds() { return (fuse_ds_mask() & 1) != 0; }
-bool net_splitk(const vdqn_net* net) {
-  static const bool on = [] { const char* e = getenv("VDQN_WIN9_SPLITK"); return e && e[0] != '0'; }();  // (off by default: measured slower)
-  return on && net->cfg.dtype == VDQN_BF16 && !net->cfg.deterministic;
-}
 bool fuse_ds_fwd(int dtype) { return (fuse_ds_mask() & 2) != 0 && (dtype == VDQN_BF16 || (fuse_ds_mask() & 4) != 0); }
 
-// scratch of the pass being enqueued (forward_impl / the backward stages set it around their launches; the host enqueues one pass
-// at a time, and two passes that may RUN concurrently — online and target forward, forward halves on two streams — never share one)
-thread_local void* g_sk_ws = nullptr;
-thread_local int64_t g_sk_bytes = 0;
-struct SkScope {
-  void* prev_ws;
-  int64_t prev_bytes;
-  SkScope(void* ws, int64_t bytes) : prev_ws(g_sk_ws), prev_bytes(g_sk_bytes) { g_sk_ws = ws; g_sk_bytes = ws ? bytes : 0; }
-  ~SkScope() { g_sk_ws = prev_ws; g_sk_bytes = prev_bytes; }
-};
-
-// packed_b / split_units: grouped forward — units [split_units, n_units) run with the second network's packed weights
 int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, const void* in, void* out, int n_units, const void* resid,
-             int relu, float* out_f32, hipStream_t st, const Layer* sib = nullptr, void* sib_out = nullptr, const unsigned char* packed_b = nullptr,
-             int split_units = 0) {
+             int relu, float* out_f32, hipStream_t st, const Layer* sib = nullptr, void* sib_out = nullptr) {
   vdqn_conv_args a;
   memset(&a, 0, sizeof(a));
   a.in = in;
   a.wt = packed + L.wf_off;
   a.bias = reinterpret_cast<const float*>(packed + L.bias_off);
-  if (packed_b) {
-    a.wt_b = packed_b + L.wf_off;
-    a.bias_b = reinterpret_cast<const float*>(packed_b + L.bias_off);
-    a.split_img = split_units;
-  }
   a.resid = resid;
   a.mask = nullptr;
   a.out = out;
@@ -991,7 +930,6 @@ int run_conv(const vdqn_net* net, const Layer& L, const unsigned char* packed, c
   a.stride = L.kind == K_CONV1_S2D ? 1 : L.stride;
   a.pad = L.kind == K_CONV1_S2D ? 0 : L.pad;
   a.mode = 0; a.relu = relu; a.dtype = net->cfg.dtype;
-  a.splitk_ws = g_sk_ws; a.splitk_ws_bytes = g_sk_bytes;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
   if (sib) {  // the block's 1x1 / stride-2 downsample (BatchNorm folded, no ReLU): second output of the same launch
     a.wt2 = packed + sib->wf_off;
@@ -1021,7 +959,6 @@ int run_dgrad(const vdqn_net* net, const Layer& L, const unsigned char* packed, 
   a.ho = L.hi; a.wo = L.wi; a.co = L.k_ci; a.ldo = L.k_ci;
   a.r = L.k_r; a.s = L.k_s; a.stride = L.stride; a.pad = L.pad;
   a.mode = 1; a.relu = 0; a.dtype = net->cfg.dtype;
-  a.splitk_ws = g_sk_ws; a.splitk_ws_bytes = g_sk_bytes;
   g_prof_alg_flops = 2.0 * n_units * L.ho * L.wo * (double)L.co * L.ci * L.r * L.s;
   if (sib) {  // + the data gradient of the block's 1x1 / stride-2 downsample, accumulated in the same tiles
     a.in2 = sib_gy;
@@ -1079,56 +1016,38 @@ int run_wgrad(const vdqn_net* net, const Layer& L, unsigned char* bwd, const voi
   } while (0)
 
 // forward over n_samples samples whose packed input already sits at `t_in`
-// packed_b != nullptr: GROUPED pass — samples [0, split_samples) with `packed`, samples [split_samples, n_samples) with `packed_b`
-// (the online network on [s; s'] and the target network on s' of one TD update as ONE chain of launches; t_in_b = packed frames of
-// the second range).  The stem runs once per range (its weights live in registers), every later layer is one vdqn_conv2d call.
 int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t_in, int n_samples, unsigned char* acts, const ActLayout& A,
-                 hipStream_t st, bool trunk_only = false, const unsigned char* packed_b = nullptr, int split_samples = 0, const void* t_in_b = nullptr,
-                 int grad_samples = -1, hipEvent_t late_weights = nullptr) {
-  // late_weights: the packed weights of the layers outside backward stage 2 (layer3, layer4, head) are being written on another
-  // stream; `st` waits for that event in front of the first such layer (vdqn_net_td_forward folds them beside the stem)
+                 hipStream_t st, bool trunk_only = false, int grad_samples = -1) {
   const int n = n_samples * net->cfg.num_frames;
   const int dt = net->cfg.dtype;
-  const SkScope sk_scope_(A.sk >= 0 ? acts + A.sk : nullptr, A.sk_bytes);
-  const int n_a = packed_b ? split_samples * net->cfg.num_frames : n;  // frames of the first range
   // grad_samples >= 0: only the first grad_samples samples will see a backward pass — the stem skips the arg-max bytes of the
   // max-pool for the rest (the s' rows and the target pass of a TD update: 2/3 of its frames; VDQN_STEM_NOIDX=0 writes them all)
   static const bool stem_noidx = [] { const char* e = getenv("VDQN_STEM_NOIDX"); return !(e && e[0] == '0'); }();
-  const int n_idx = (grad_samples >= 0 && stem_noidx) ? (grad_samples * net->cfg.num_frames < n_a ? grad_samples * net->cfg.num_frames : n_a) : n_a;
+  const int n_idx = (grad_samples >= 0 && stem_noidx) ? (grad_samples * net->cfg.num_frames < n ? grad_samples * net->cfg.num_frames : n) : n;
   if (A.c1 >= 0) {  // 'basic' eval path keeps the separate kernels (its train path needs the raw conv output anyway)
     RC(run_conv(net, net->layers[net->l_conv1], packed, t_in, acts + A.c1, n, nullptr, 1, nullptr, st));
     RC(vdqn_maxpool_fwd(acts + A.c1, acts + A.pool, acts + A.idx, n, 112, 112, 64, dt, st));
   } else {
     const Layer& L1 = net->layers[net->l_conv1];
-    const int64_t frame_pool = (int64_t)56 * 56 * 64;
-    prof_layer(L1, n_a);
-    RC(vdqn_stem_conv_pool_n(t_in, packed + L1.wf_off, reinterpret_cast<const float*>(packed + L1.bias_off), acts + A.pool, acts + A.idx, n_a, n_idx, dt, st));
-    if (packed_b) {
-      prof_layer(L1, n - n_a);
-      RC(vdqn_stem_conv_pool(t_in_b, packed_b + L1.wf_off, reinterpret_cast<const float*>(packed_b + L1.bias_off),
-                             acts + A.pool + n_a * frame_pool * net->esz, (grad_samples >= 0 && stem_noidx) ? nullptr : acts + A.idx + n_a * frame_pool, n - n_a, dt, st));
-    }
+    prof_layer(L1, n);
+    RC(vdqn_stem_conv_pool_n(t_in, packed + L1.wf_off, reinterpret_cast<const float*>(packed + L1.bias_off), acts + A.pool, acts + A.idx, n, n_idx, dt, st));
   }
   const unsigned char* x = acts + A.pool;
   for (int b = 0; b < 8; ++b) {
     const Layer& c1 = net->layers[net->l_b_conv1[b]];
     const Layer& c2 = net->layers[net->l_b_conv2[b]];
     const void* identity = x;
-    if (late_weights && net->l_b_conv1[b] < net->layer_stage_first[2]) {
-      (void)hipStreamWaitEvent(st, late_weights, 0);
-      late_weights = nullptr;
-    }
-    if (net->l_b_ds[b] >= 0 && fuse_ds_fwd(dt) && !packed_b) {  // stride-2 block: conv1 and the downsample read the same pixels — one launch
+    if (net->l_b_ds[b] >= 0 && fuse_ds_fwd(dt)) {  // stride-2 block: conv1 and the downsample read the same pixels — one launch
       RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st, &net->layers[net->l_b_ds[b]], acts + A.ds[b]));
       identity = acts + A.ds[b];
     } else {
-      RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st, nullptr, nullptr, packed_b, n_a));
+      RC(run_conv(net, c1, packed, x, acts + A.h[b], n, nullptr, 1, nullptr, st));
       if (net->l_b_ds[b] >= 0) {
-        RC(run_conv(net, net->layers[net->l_b_ds[b]], packed, x, acts + A.ds[b], n, nullptr, 0, nullptr, st, nullptr, nullptr, packed_b, n_a));
+        RC(run_conv(net, net->layers[net->l_b_ds[b]], packed, x, acts + A.ds[b], n, nullptr, 0, nullptr, st));
         identity = acts + A.ds[b];
       }
     }
-    RC(run_conv(net, c2, packed, acts + A.h[b], acts + A.o[b], n, identity, 1, nullptr, st, nullptr, nullptr, packed_b, n_a));
+    RC(run_conv(net, c2, packed, acts + A.h[b], acts + A.o[b], n, identity, 1, nullptr, st));
     x = acts + A.o[b];
   }
   if (trunk_only) return VDQN_OK;  // the 512 x 7 x 7 features are in o7
@@ -1137,11 +1056,10 @@ int forward_impl(const vdqn_net* net, const unsigned char* packed, const void* t
     RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.avg, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
     return VDQN_OK;
   }
-  RC(run_conv(net, net->layers[net->l_f8], packed, x, acts + A.f8, n, nullptr, 1, nullptr, st, nullptr, nullptr, packed_b, n_a));
-  RC(run_conv(net, net->layers[net->l_top0], packed, acts + A.f8, acts + A.l0, n_samples, nullptr, 1, nullptr, st, nullptr, nullptr, packed_b, split_samples));
-  RC(run_conv(net, net->layers[net->l_top2], packed, acts + A.l0, acts + A.l1, n_samples, nullptr, 1, nullptr, st, nullptr, nullptr, packed_b, split_samples));
-  RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.l1, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st, nullptr, nullptr,
-              packed_b, split_samples));
+  RC(run_conv(net, net->layers[net->l_f8], packed, x, acts + A.f8, n, nullptr, 1, nullptr, st));
+  RC(run_conv(net, net->layers[net->l_top0], packed, acts + A.f8, acts + A.l0, n_samples, nullptr, 1, nullptr, st));
+  RC(run_conv(net, net->layers[net->l_top2], packed, acts + A.l0, acts + A.l1, n_samples, nullptr, 1, nullptr, st));
+  RC(run_conv(net, net->layers[net->l_top4], packed, acts + A.l1, acts + A.q, n_samples, nullptr, 0, reinterpret_cast<float*>(acts + A.qf), st));
   return VDQN_OK;
 }
 
@@ -1353,13 +1271,6 @@ extern "C" int vdqn_net_pack_weights(vdqn_net* net, const float* params, const f
   return pack_weights_layers(net, params, bnstats, packed, with_dgrad, 0, (int)net->layers.size(), (hipStream_t)stream);
 }
 
-extern "C" int vdqn_net_pack_weights_stage(vdqn_net* net, const float* params, const float* bnstats, void* packed, int32_t with_dgrad, int32_t stage,
-                                           void* stream) {
-  VDQN_CHECK(net && params && bnstats && packed, "vdqn_net_pack_weights_stage: null arg");
-  VDQN_CHECK(stage >= 0 && stage < 3, "vdqn_net_pack_weights_stage: stage %d", stage);
-  return pack_weights_layers(net, params, bnstats, packed, with_dgrad, net->layer_stage_first[stage], net->layer_stage_count[stage], (hipStream_t)stream);
-}
-
 extern "C" int vdqn_net_forward(vdqn_net* net, const void* packed, const void* frames, int32_t src_kind, int32_t n_samples, void* acts,
                                 float* q_out, void* stream) {
   VDQN_CHECK(net && packed && frames && acts && q_out, "vdqn_net_forward: null arg");
@@ -1403,15 +1314,11 @@ extern "C" int vdqn_net_forward_train(vdqn_net* net, const float* params, float*
   return VDQN_OK;
 }
 
-// Grouped TD update (vdqn_step_args.acts_target == NULL): online and target forward share one 3B-sample workspace.
-static bool step_grouped(const vdqn_net* net, const vdqn_step_args* a) {
-  return !a->train_on_ground_truth && a->acts_target == nullptr && !net->basic();
-}
 // samples the `acts_online` workspace of this update is laid out for
 static int step_layout_samples(const vdqn_net* net, const vdqn_step_args* a) {
   if (a->acts_samples > 0) return a->acts_samples;  // the workspace of one vdqn_net_forward call (vdqn_net_backward_begin)
   if (a->train_on_ground_truth) return a->batch;
-  return step_grouped(net, a) ? 3 * a->batch : 2 * a->batch;
+  return 2 * a->batch;
 }
 
 extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void* stream) {
@@ -1421,10 +1328,7 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   const bool gtb = a->train_on_ground_truth != 0;
   VDQN_CHECK(B >= 1 && 2 * B <= net->cfg.max_batch, "vdqn_net_td_forward: batch %d needs max_batch >= %d", B, 2 * B);
   VDQN_CHECK(gtb ? (a->gt != nullptr) : (a->after && a->packed_target && a->rew && a->term), "vdqn_net_td_forward: missing inputs for this loss branch");
-  // acts_target == NULL (TD branch, extra_capacity): GROUPED forward — `acts_online` holds 3B samples [s | s' | s' again for the
-  // target network] and every layer behind the stem is ONE launch over all three ranges (vdqn_conv_args.wt_b)
-  const bool grouped = step_grouped(net, a);
-  VDQN_CHECK(gtb || grouped || a->acts_target, "vdqn_net_td_forward: acts_target is NULL (only the grouped extra_capacity TD update runs without it)");
+  VDQN_CHECK(gtb || a->acts_target, "vdqn_net_td_forward: acts_target is NULL");
   hipStream_t st = (hipStream_t)stream;
   const int F = net->cfg.num_frames, dt = net->cfg.dtype;
   const int ns_online = step_layout_samples(net, a);
@@ -1440,89 +1344,23 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   hipStream_t tst = fork_side(net, st);  // == st when the overlap is off
   // the packed frames of this update: the engine's own buffer, or the caller's (vdqn_step_args.packed_frames: packed ahead of time)
   const unsigned char* tin = a->packed_frames ? (const unsigned char*)a->packed_frames : ao + A.t_in;
-  const bool prepacked = a->packed_frames != nullptr;
-  // VDQN_PACK_AFTER_FIRST=1 (off by default): the s' frames are packed FIRST, on the side stream, and the target pass follows them at
-  // once, so that its stem (matrix work) runs beside the caller's stream packing the s frames and folding the weights (HBM work)
-  // instead of behind both packs.  Measured on alternating runs: 5.88 vs 5.75-5.77 ms per update — slower
-  // (profiles/r03s_ab_pack_after_first.txt); the default keeps both packs on the side stream and the fold beside them.
-  static const bool after_first_on = [] { const char* e = getenv("VDQN_PACK_AFTER_FIRST"); return e && e[0] == '1'; }();
-  const bool after_first = after_first_on && tst != st && !gtb && !grouped && a->packed_frames == nullptr;
-  hipEvent_t e_after = nullptr;
-  if (prepacked) {
-    // nothing to pack
-  } else if (after_first) {
-    RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
-    e_after = next_event(net);
-    (void)hipEventRecord(e_after, tst);
-    RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, st));
-  } else {
-    // VDQN_PACK_TWO_STREAMS=1 (off by default): the two packs side by side on two streams instead of one behind the other.  Each alone
-    // reaches ~3 TB/s and little else runs at the start of an update, yet measured on alternating runs it is 1 % SLOWER (5.775 against
-    // 5.712 ms per update, profiles/r04g_ab_early_fold_two_stream_packs.txt).
-    static const bool two = [] { const char* e = getenv("VDQN_PACK_TWO_STREAMS"); return e && e[0] == '1'; }();
-    hipStream_t pst = (two && tst != st && !gtb) ? fork_side2(net, st) : tst;
-    RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, pst));
+  // (tried and measured slower, experiments/: the s' frames packed first with the target pass right behind them; the two packs
+  // on two streams; a split weight fold with layer3+ beside the stem; stage folds behind their early Adam; online and target
+  // forward as one chain of grouped launches; the online pass as two half-batch passes on two streams)
+  if (!a->packed_frames) {
+    RC(vdqn_pack_input(a->before, a->src_kind, ao + A.t_in, B * F, dt, tst));
     if (!gtb) RC(vdqn_pack_input(a->after, a->src_kind, ao + A.t_in + (int64_t)B * F * frame_bytes, B * F, dt, tst));
-    if (pst != tst) {  // the side stream (target pass, and the join below) continues behind both packs
-      hipEvent_t e = next_event(net);
-      (void)hipEventRecord(e, pst);
-      (void)hipStreamWaitEvent(tst, e, 0);
-    }
   }
-  // VDQN_FOLD_SPLIT=1 (off by default): only stage 2's layers (stem, layer1, layer2: 0.7 M of the 12.4 M parameters) are folded in
-  // front of the online pass; the rest (layer3, layer4, head) on the side stream beside the stem and layer1, and the caller's stream
-  // waits for it in front of layer3.  Measured on alternating runs it is 0.03 ms per update SLOWER than the one fold in front of
-  // everything (5.785 vs 5.757 ms, profiles/r03q_ab_fold_split.txt): the side stream's target pass starts that much later.
-  static const bool fold_split_on = [] { const char* e = getenv("VDQN_FOLD_SPLIT"); return e && e[0] == '1'; }();
-  const bool fold_split = fold_split_on && tst != st && !net->basic() && net->layer_stage_first[2] > 0;
-  hipEvent_t late_weights = nullptr;
-  if (fold_split) {
-    RC(pack_weights_layers(net, a->params, a->bnstats, a->packed_online, 1, net->layer_stage_first[2], net->layer_stage_count[2], st));
-  } else if (a->prefolded_stages & 7) {  // the caller folded some stages behind their optimiser update: only the others here
-    for (int s = 0; s < 3; ++s)
-      if (!((a->prefolded_stages >> s) & 1))
-        RC(pack_weights_layers(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, net->layer_stage_first[s], net->layer_stage_count[s], st));
-  } else {
-    RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
-  }
-  if (after_first) (void)hipStreamWaitEvent(st, e_after, 0);  // the s' half of the packed input
-  else if (tst != st) join_side(net, st);                      // packed input ready for the online pass
-  if (fold_split) {
-    RC(pack_weights_layers(net, a->params, a->bnstats, a->packed_online, 1, 0, net->layer_stage_first[2], tst));
-    late_weights = next_event(net);
-    (void)hipEventRecord(late_weights, tst);
-  }
-  if (grouped) {
-    // [s; s'] with the online weights and s' with the target's, one chain of launches on the caller's stream (the side stream
-    // carries nothing during the forward); the target range's stem reads the packed s' frames of the online range
-    RC(forward_impl(net, (const unsigned char*)a->packed_online, tin, 3 * B, ao, A, st, false, (const unsigned char*)a->packed_target, 2 * B,
-                    tin + (int64_t)B * F * frame_bytes, B, late_weights));
-  } else if (!gtb) {
+  RC(vdqn_net_pack_weights(net, a->params, a->bnstats, a->packed_online, net->basic() ? 3 : 1, st));
+  if (tst != st) join_side(net, st);  // packed input ready for the online pass
+  if (!gtb) {
     const ActLayout T = act_layout(net, B);
-    RC(forward_impl(net, (const unsigned char*)a->packed_target, tin + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst, false,
-                    nullptr, 0, nullptr, 0));
+    RC(forward_impl(net, (const unsigned char*)a->packed_target, tin + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst));
   }
-  if (grouped) {
-    // (done above)
-  } else if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
+  if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
     RC(forward_train_impl(net, (const unsigned char*)a->packed_online, a->params, a->bnstats, tin, ns_online, gtb ? 1 : 2, ao, A, st));
-  else {
-    // VDQN_SPLIT_ONLINE=1: the online pass over [before; after] as two independent half-batch passes on two streams (BatchNorm in
-    // eval mode: samples are independent, each half is bit-identical to its part of the 2B pass); with the target pass that
-    // makes three concurrent kernel chains walking the same layers, whose tiles fill each other's tail rounds.  Measured on
-    // alternating runs (profiles/r02n_split_online_ab.txt) it is 6.04-6.06 ms per update in some processes and 6.27-6.33 in others
-    // (the two equal chains either interleave or fall into step), against a steady 6.10-6.15 for the single 2B pass: off by default.
-    static const bool split = [] { const char* e = getenv("VDQN_SPLIT_ONLINE"); return e && e[0] == '1'; }();
-    hipStream_t s2 = (split && !gtb) ? fork_side2(net, st) : st;
-    if (s2 != st) {
-      const ActLayout A2 = shift_layout(net, A, B);
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, tin + (A2.t_in - A.t_in), B, ao, A2, s2, false, nullptr, 0, nullptr, 0, late_weights));
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, tin, B, ao, A, st, false, nullptr, 0, nullptr, -1, late_weights));
-      join_side2(net, st);
-    } else {
-      RC(forward_impl(net, (const unsigned char*)a->packed_online, tin, ns_online, ao, A, st, false, nullptr, 0, nullptr, B, late_weights));
-    }
-  }
+  else
+    RC(forward_impl(net, (const unsigned char*)a->packed_online, tin, ns_online, ao, A, st, false, B));
   if (tst != st) join_side(net, st);
 
   hipError_t e = hipMemsetAsync(bw + W.zero_begin, 0, (size_t)W.zero_bytes, st);
@@ -1538,7 +1376,7 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     memset(&t, 0, sizeof(t));
     t.q_before = qf_online;
     t.q_after_online = qf_online + (size_t)B * 64;
-    t.q_after_target = grouped ? qf_online + (size_t)2 * B * 64 : reinterpret_cast<const float*>(at + T.qf);
+    t.q_after_target = reinterpret_cast<const float*>(at + T.qf);
     t.act = a->act; t.rew = a->rew; t.term = a->term; t.valid = a->valid;
     t.loss = a->loss;
     t.dq = bw + W.dq;
@@ -1678,11 +1516,6 @@ extern "C" void* vdqn_net_grad_stream(vdqn_net* net) {
   return (void*)net->side;
 }
 
-extern "C" void* vdqn_net_aux_stream(vdqn_net* net) {
-  if (!net || !side_ready(net)) return nullptr;
-  return (void*)net->side2;
-}
-
 extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, int32_t stage, void* stream) {
   VDQN_CHECK(net && a && a->grads, "vdqn_net_backward_stage: null arg");
   VDQN_CHECK(stage >= 0 && stage < 3, "vdqn_net_backward_stage: stage %d", stage);
@@ -1694,7 +1527,6 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
   const unsigned char* pk = (const unsigned char*)a->packed_online;
   unsigned char* ao = (unsigned char*)a->acts_online;
   unsigned char* bw = (unsigned char*)a->bwd;
-  const SkScope sk_scope_(W.sk >= 0 ? bw + W.sk : nullptr, W.sk_bytes);
   bool split_conv1 = false;  // stage 2, extra_capacity: conv1's weight gradient is unfolded separately (see below)
   int pr_l1 = 128, pr_l0 = 128, pr_f8 = 128;  // row granularity of the head's column-sum partials (stage 0)
 

@@ -28,11 +28,21 @@ extern "C" int vdqn_host_gather(void* dst, const void* const* src, int64_t n, in
   std::vector<std::thread> pool;
   pool.reserve((size_t)t - 1);
   const int64_t per = (n + t - 1) / t;
+  // A thread that cannot be created (EAGAIN under a pid limit, 8 ranks x 16 threads) must not unwind through this extern "C"
+  // function with joinable threads alive (std::terminate): the records from the failed one on are copied by this thread instead.
+  int64_t inline_from = n;
   for (int k = 1; k < t; ++k) {
     const int64_t lo = k * per, hi = lo + per < n ? lo + per : n;
-    if (lo < hi) pool.emplace_back(run, lo, hi);
+    if (lo >= hi) break;
+    try {
+      pool.emplace_back(run, lo, hi);
+    } catch (...) {
+      inline_from = lo;
+      break;
+    }
   }
   run(0, per < n ? per : n);
+  if (inline_from < n) run(inline_from, n);
   for (auto& th : pool) th.join();
   return VDQN_OK;
 }

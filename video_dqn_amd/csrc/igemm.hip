@@ -32,8 +32,6 @@ int vdqn_launch_win9s(const void* igemm_params, hipStream_t stream);            
 int vdqn_win9s_supports(int cpk, int has_sib);
 int vdqn_launch_win9d(const void* igemm_params, hipStream_t stream);                                                              // win9d.hip
 int vdqn_win9d_supports(int ci, int co, int has_sib, int ci2);                                                                    // win9d.hip                                                                                    // win9s.hip
-int vdqn_launch_win9m(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9m.hip
-extern "C" int64_t vdqn_conv2d_splitk_workspace_bytes(void);                                                                       // win9.hip
 int vdqn_launch_win9u(const void* igemm_params, int mode, hipStream_t stream);                                                    // win9.hip
 
 #include "igemm_common.h"
@@ -126,9 +124,7 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
   long long a_rem = p.in_bytes - a_base_off;
   if (a_rem > 0x7fffffffLL) a_rem = 0x7fffffffLL;
   const unsigned long long a_ptr = (unsigned long long)((const unsigned char*)p.in + a_base_off);
-  // grouped forward: the tiles from row m_split on use the second weight set (same size, so the descriptor range is the same)
-  const bool grp_b = MODE == 0 && m0 >= p.m_split;
-  const unsigned long long b_ptr = (unsigned long long)(sib ? p.wt2 : (grp_b ? p.wt_b : p.wt));
+  const unsigned long long b_ptr = (unsigned long long)(sib ? p.wt2 : p.wt);
   const i32x4 rs_a = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_ptr), __builtin_amdgcn_readfirstlane((int)((a_ptr >> 32) & 0xffff)),
                       __builtin_amdgcn_readfirstlane((int)a_rem), 0x00020000};
   const i32x4 rs_b = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_ptr), __builtin_amdgcn_readfirstlane((int)((b_ptr >> 32) & 0xffff)),
@@ -572,7 +568,7 @@ __global__ __launch_bounds__(BM * WN, 2) void igemm_kernel(const IgemmParams p) 
       return;
     }
   }
-  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw, grp_b ? p.bias_b : p.bias);
+  igemm_epilogue<T, BM, BN, MODE, WN>(p, acc, smem, m0, n0, tile_m, rows_total, pix_per_img, row_w, cls_ph, cls_pw, p.bias);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1128,7 +1124,7 @@ constexpr int kC64Smem = 2 * kC64WinBytes + 256 + 512 + 256 + (9 - kC64RegTaps) 
 // middle of the K loop for the epilogue) otherwise stay reserved in every instance, and with all 256 VGPRs taken the compiler
 // serialises the second half of the K loop into read / wait / two MFMAs
 template <int MODE, bool HAS_RES, bool HAS_MSK>
-__global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, const int n_tiles, const FastDiv d_wo, const FastDiv d_howo, const int grp_a_blocks) {
+__global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, const int n_tiles, const FastDiv d_wo, const FastDiv d_howo) {
   using T = bf16raw;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sZ = smem + 2 * kC64WinBytes;
@@ -1143,17 +1139,12 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
   const int wr = wave >> 1, wc = wave & 1;
   const int i16 = lane & 15, g = lane >> 4;
   const int W = p.wo, H = p.ho;
-  // grouped forward (IgemmParams::m_split): the weights live in registers for the life of a workgroup, so the GRID is split — the
-  // first grp_a_blocks workgroups walk the tiles below row m_split with the first weight set, the others the tiles from m_split on
-  // with wt_b / bias_b (both counts are multiples of 8: the XCD-contiguous tile order holds inside each range).  Not grouped:
-  // grp_a_blocks = gridDim.x and one range.
-  const bool grp_b = (int)blockIdx.x >= grp_a_blocks;
-  const int g_first = grp_b ? p.m_split / 128 : 0;                                   // first tile of this workgroup's range
-  const int g_tiles = grp_b ? n_tiles - g_first : (grp_a_blocks < (int)gridDim.x ? p.m_split / 128 : n_tiles);
-  const int g_blocks = grp_b ? (int)gridDim.x - grp_a_blocks : grp_a_blocks;
-  const int g_bid = grp_b ? (int)blockIdx.x - grp_a_blocks : (int)blockIdx.x;
-  const unsigned char* w_src = reinterpret_cast<const unsigned char*>(grp_b ? p.wt_b : p.wt);
-  const float* bias_src = grp_b ? p.bias_b : p.bias;
+  constexpr int g_first = 0;
+  const int g_tiles = n_tiles;
+  const int g_blocks = (int)gridDim.x;
+  const int g_bid = (int)blockIdx.x;
+  const unsigned char* w_src = reinterpret_cast<const unsigned char*>(p.wt);
+  const float* bias_src = p.bias;
   if (tid < 16) reinterpret_cast<uint4*>(sZ)[tid] = make_uint4(0, 0, 0, 0);
   if (tid >= 64 && tid < 128) sBias[tid - 64] = bias_src ? bias_src[tid - 64] : 0.f;
   // output / residual / mask / column-sum buffers as buffer resources: rows past M get an out-of-range offset, so every
@@ -1496,26 +1487,14 @@ int launch_conv64(const IgemmParams& p, hipStream_t stream) {
   const int n_cu = vdqn_num_cus();
   const int n_tiles = (p.M + 127) / 128;
   int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
-  int grp_a = grid;  // workgroups of the first weight set (all of them unless this is a grouped forward)
-  if (MODE == 0 && p.wt_b) {
-    // grouped forward: the workgroups are dealt to the two row ranges in proportion to their tile counts, in multiples of 8 (one
-    // per XCD) so that each range keeps the XCD-contiguous tile order
-    const int ta = p.m_split / 128, tb = n_tiles - ta;
-    grid = (grid + 7) & ~7;
-    if (grid < 16) grid = 16;
-    grp_a = (int)(((long long)grid * ta / n_tiles + 4) & ~7ll);
-    if (grp_a < 8) grp_a = 8;
-    if (grp_a > grid - 8) grp_a = grid - 8;
-    (void)tb;
-  }
   vdqn_prof_begin(MODE == 0 ? "conv64<bf16,fwd>" : "conv64<bf16,dgrad>", 2.0 * p.M * p.co * p.ktot,
                   2.0 * ((double)p.n_img * p.hi * p.wi * p.ci + (double)p.co * p.ktot + (double)p.M * p.co * (1 + (p.resid != nullptr) + (p.mask != nullptr))), stream);
 #ifdef VDQN_STAMP
   IgemmParams ps = p;
   ps.pool_out = g_stamp_buffer;  // (conv64 has no pooled output: the field carries the stamp buffer in diagnostic builds)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kC64Smem, stream, ps, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), grp_a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kC64Smem, stream, ps, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo));
 #else
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kC64Smem, stream, p, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo), grp_a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kC64Smem, stream, p, n_tiles, make_fastdiv((uint32_t)p.wo), make_fastdiv((uint32_t)p.howo));
 #endif
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
@@ -1572,10 +1551,8 @@ int launch_mode(const IgemmParams& p, int mode, hipStream_t st) {
 extern "C" void vdqn_debug_stamp_buffer(void* p) { g_stamp_buffer = p; }  // diagnostic builds only (not part of include/vdqn.h)
 #endif
 
-// One launch of the layer.  group_rows > 0: a grouped forward was asked for (a->wt_b); the kernel this call selects takes it in
-// ONE launch when group_rows is a multiple of its tile height — otherwise *grouped_done stays 0 and nothing is launched (the
-// caller then issues the two row ranges as two calls).
-static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, int* grouped_done) {
+extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
+  VDQN_CHECK(a != nullptr, "vdqn_conv2d: null args");
   VDQN_CHECK(a != nullptr, "vdqn_conv2d: null args");
   VDQN_CHECK(a->dtype == VDQN_F32 || a->dtype == VDQN_BF16, "vdqn_conv2d: bad dtype %d", a->dtype);
   const int esz = a->dtype == VDQN_BF16 ? 2 : 4;
@@ -1592,22 +1569,8 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
   p.pool_out = nullptr; p.pool_idx = nullptr;
   p.in2 = nullptr; p.wt2 = nullptr; p.bias2 = nullptr; p.out2 = nullptr;
   p.co2 = p.ldo2 = p.relu2 = p.ci2 = p.wt2_bytes = 0;
-  p.wt_b = nullptr; p.bias_b = nullptr; p.m_split = 0x7fffffff;
   static const int no_lean = [] { const char* e = getenv("VDQN_LEAN_EPILOGUE"); return (e && e[0] == '0') ? 1 : 0; }();
   p.no_lean = no_lean;
-  p.sk_cnt = nullptr; p.sk_slab = nullptr;
-  if (a->splitk_ws && a->splitk_ws_bytes >= vdqn_conv2d_splitk_workspace_bytes() && (((uintptr_t)a->splitk_ws) & 255) == 0) {
-    p.sk_cnt = reinterpret_cast<unsigned*>(a->splitk_ws);
-    p.sk_slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a->splitk_ws) + 4096);
-  }
-  // grouped forward, decided per kernel below: `grp(bm)` arms it if the split is a multiple of that kernel's tile height
-  auto grp = [&](int bm) {
-    if (group_rows <= 0) return true;       // not a grouped call
-    if (group_rows % bm != 0) return false;  // a tile would mix the two weight sets: the caller falls back to two launches
-    p.wt_b = a->wt_b; p.bias_b = a->bias_b; p.m_split = group_rows;
-    *grouped_done = 1;
-    return true;
-  };
   p.n_img = a->n_img; p.hi = a->hi; p.wi = a->wi; p.ci = a->ci; p.pix_stride = a->pix_stride;
   p.ho = a->ho; p.wo = a->wo; p.co = a->co; p.ldo = a->ldo; p.r = a->r; p.s = a->s; p.stride = a->stride; p.pad = a->pad;
   p.relu = a->relu;
@@ -1662,11 +1625,7 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
   hipStream_t st = (hipStream_t)stream;
   // the Q-head's skinny GEMMs (bf16 linear layers forward / data gradient, features.8 forward): small tiles, K split over the waves
   if (mode != 2) {
-    vdqn_conv_args one = *a;  // a grouped call is asked as one of its two ranges: they then run as two launches of the SAME kernel
-    one.wt_b = nullptr;       // (bit-identical to the two-pass update: test_grouped_forward_is_bit_identical_to_two_passes)
-    one.bias_b = nullptr;
-    const int sk = vdqn_skinny_kind(&one);
-    if (sk && group_rows > 0) return VDQN_OK;
+    const int sk = vdqn_skinny_kind(a);
     if (sk) return vdqn_launch_skinny(&p, sk, st);
   }
   // 64-column layers with many rows: 256-row tiles, 8 waves (more MFMA work per DMA round trip, half the weight traffic)
@@ -1677,7 +1636,6 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
   if (use_c64 && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && mode != 2 && a->ci == 64 && a->co == 64 &&
       a->pix_stride == 64 && a->hi == a->ho && a->wi == a->wo && a->wo >= 2 && a->wo <= 56 && p.in_bytes < 0x7fffffffLL && (long long)p.M * 128 < 0x7fffffffLL &&
       a->out && !a->out_f32 && p.vec_ok && (long long)p.M * a->ldo * 2 < 0x7fffffffLL && (mode == 1 || !a->colsum_part)) {
-    if (!grp(128)) return VDQN_OK;
     return mode == 0 ? launch_conv64<0>(p, st) : launch_conv64<1>(p, st);
   }
   static const int use_win = [] { const char* e = getenv("VDQN_IGEMM_WINDOW"); return e ? atoi(e) : 1; }();
@@ -1688,32 +1646,24 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
         // VDQN_WIN9_UNROLLED (default 1): the K loop unrolled over a chunk pair (win9.hip: half the instructions per K-step); 0: igemm_win9_kernel
         static const int unrolled = [] { const char* e = getenv("VDQN_WIN9_UNROLLED"); return e ? atoi(e) : 1; }();
         if (unrolled && a->ci % 128 == 0) {
-          if (!grp(256)) return VDQN_OK;  // (256: also right for the optional 256-row tiles)
-          // VDQN_WIN9_MFMA32: the same kernel on 32x32x16 MFMAs (win9m.hip; vector epilogue only)
-          static const int mfma32 = [] { const char* e = getenv("VDQN_WIN9_MFMA32"); return e ? atoi(e) : 0; }();
-          if (mfma32 && p.vec_ok && a->co % 128 == 0) return vdqn_launch_win9m(&p, mode, st);
           return vdqn_launch_win9u(&p, mode, st);
         }
-        if (group_rows > 0) return VDQN_OK;  // the remaining window kernels have no grouped form: two launches
         return mode == 0 ? launch_igemm_win9<bf16raw, 0>(p, st) : launch_igemm_win9<bf16raw, 1>(p, st);
       }
-      if (group_rows > 0) return VDQN_OK;
       if (bn == 128) return mode == 0 ? launch_igemm_win<bf16raw, 128, 0>(p, st) : launch_igemm_win<bf16raw, 128, 1>(p, st);
       return mode == 0 ? launch_igemm_win<bf16raw, 64, 0>(p, st) : launch_igemm_win<bf16raw, 64, 1>(p, st);
     }
-    if (group_rows > 0) return VDQN_OK;
     if (bn == 128) return mode == 0 ? launch_igemm_win<float, 128, 0>(p, st) : launch_igemm_win<float, 128, 1>(p, st);
     return mode == 0 ? launch_igemm_win<float, 64, 0>(p, st) : launch_igemm_win<float, 64, 1>(p, st);
   }
   // 3x3 / stride 2 / pad 1 forward over an even-sized input (conv1 of layer2.0 / layer3.0 / layer4.0), bf16, 128-column tiles: the
-  // plane-window kernel (win9s.hip; VDQN_S2WIN=0 keeps the generic kernel).  No grouped form.  A fused sibling 1x1 (the block's
+  // plane-window kernel (win9s.hip; VDQN_S2WIN=0 keeps the generic kernel).  A fused sibling 1x1 (the block's
   // downsample) rides in the same persistent launch for 1, 2 or 4 channel chunks (round 5).
   static const int use_s2win = [] { const char* e = getenv("VDQN_S2WIN"); return e ? atoi(e) : 1; }();
   if (use_s2win && mode == 0 && a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 2 && a->pad == 1 &&
       bn == 128 && a->co % 128 == 0 && a->hi == 2 * a->ho && a->wi == 2 * a->wo && a->wo >= 2 && a->wo <= 28 && a->pix_stride == a->ci && a->ci % 64 == 0 &&
       p.in_bytes < 0x7fffffffLL && !a->colsum_part && !a->mask && vdqn_win9s_supports(a->ci / 64, has_sib) &&
       (!has_sib || (a->co2 == a->co && p.vec_ok && !a->out_f32 && !a->resid))) {
-    if (group_rows > 0) return VDQN_OK;  // no grouped form: the caller runs the two row ranges as two launches of THIS kernel (same bits as two passes)
     return vdqn_launch_win9s(&p, st);
   }
   // data gradient of 3x3 / stride 2 / pad 1 over an even-sized image, bf16: the plane-window kernel (win9d.hip, round 5;
@@ -1727,46 +1677,11 @@ static int conv2d_impl(const vdqn_conv_args* a, void* stream, int group_rows, in
   }
   static const long long min256 = [] { const char* e = getenv("VDQN_BM256_MIN_ROWS"); return e ? atoll(e) : 256ll * 1024; }();
   if (bn == 64 && mode != 2 && p.M >= min256 && !has_sib) {
-    if (!grp(256)) return VDQN_OK;
     p.tiles_m = (p.M + 255) / 256;
     return a->dtype == VDQN_BF16 ? launch_mode<bf16raw, 256, 64>(p, mode, st) : launch_mode<float, 256, 64>(p, mode, st);
   }
-  if (!grp(128)) return VDQN_OK;
   if (a->dtype == VDQN_BF16) return bn == 128 ? launch_mode<bf16raw, 128, 128>(p, mode, st) : launch_mode<bf16raw, 128, 64>(p, mode, st);
   return bn == 128 ? launch_mode<float, 128, 128>(p, mode, st) : launch_mode<float, 128, 64>(p, mode, st);
-}
-
-extern "C" int vdqn_conv2d(const vdqn_conv_args* a, void* stream) {
-  VDQN_CHECK(a != nullptr, "vdqn_conv2d: null args");
-  if (!a->wt_b) return conv2d_impl(a, stream, 0, nullptr);
-  // grouped forward: images [0, split_img) with wt / bias, images [split_img, n_img) with wt_b / bias_b
-  VDQN_CHECK(a->mode == 0 && !a->wt2 && !a->in2 && !a->colsum_part && !a->mask, "vdqn_conv2d: wt_b (grouped forward) needs a plain forward call");
-  VDQN_CHECK(a->split_img > 0 && a->split_img < a->n_img, "vdqn_conv2d: split_img %d outside (0, n_img = %d)", a->split_img, a->n_img);
-  VDQN_CHECK((a->bias != nullptr) == (a->bias_b != nullptr) && (((uintptr_t)a->wt_b) & 15) == 0, "vdqn_conv2d: bias_b must be given iff bias is; wt_b 16-byte aligned");
-  const int64_t rows_a = (int64_t)a->split_img * a->ho * a->wo;
-  VDQN_CHECK(rows_a < (1ll << 31), "vdqn_conv2d: too many output pixels");
-  static const int one_launch = [] { const char* e = getenv("VDQN_GROUPED_LAUNCH"); return e ? atoi(e) : 1; }();
-  int done = 0;
-  if (one_launch) {
-    const int rc = conv2d_impl(a, stream, (int)rows_a, &done);
-    if (rc != VDQN_OK || done) return rc;
-  }
-  // this layer's kernel has no grouped form, or the split is not a multiple of its tile height: the two row ranges as two launches
-  const int esz = a->dtype == VDQN_BF16 ? 2 : 4;
-  vdqn_conv_args lo = *a, hi = *a;
-  lo.wt_b = nullptr; lo.bias_b = nullptr; lo.split_img = 0; lo.n_img = a->split_img;
-  hi.wt_b = nullptr; hi.bias_b = nullptr; hi.split_img = 0; hi.n_img = a->n_img - a->split_img;
-  hi.wt = a->wt_b; hi.bias = a->bias_b;
-  hi.in = (const unsigned char*)a->in + (int64_t)a->split_img * a->hi * a->wi * a->pix_stride * esz;
-  if (a->out) hi.out = (unsigned char*)a->out + rows_a * a->ldo * esz;
-  if (a->out_f32) hi.out_f32 = a->out_f32 + rows_a * a->ldo;
-  if (a->resid) hi.resid = (const unsigned char*)a->resid + rows_a * a->ldo * esz;
-  const double flops = g_prof_alg_flops;  // the engine's figure covers both ranges
-  if (flops > 0) g_prof_alg_flops = flops * a->split_img / a->n_img;
-  const int rc = conv2d_impl(&lo, stream, 0, nullptr);
-  if (rc != VDQN_OK) return rc;
-  if (flops > 0) g_prof_alg_flops = flops * (a->n_img - a->split_img) / a->n_img;
-  return conv2d_impl(&hi, stream, 0, nullptr);
 }
 
 extern "C" int vdqn_stem_conv_pool_n(const void* t_in, const void* wt, const float* bias, void* pool, void* idx, int32_t n_img, int32_t n_idx_img,

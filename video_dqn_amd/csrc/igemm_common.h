@@ -39,18 +39,7 @@ struct IgemmParams {
   const float* bias2;
   void* out2;
   int co2, ldo2, relu2, ci2, wt2_bytes, tiles_n1;
-  // grouped forward (two weight sets over one row range, e.g. the online and the target network of a TD update in ONE launch,
-  // train_q_network.py:131,140,142): output rows m >= m_split are computed with wt_b / bias_b.  m_split is a multiple of the
-  // kernel's tile height (the launcher falls back to two launches otherwise), so no tile mixes the sets and every output element
-  // is bit-identical to the two-launch result.  Not grouped: m_split = INT_MAX.
-  const void* wt_b;
-  const float* bias_b;
-  int m_split;
   int no_lean;  // VDQN_LEAN_EPILOGUE=0 (A/B switch): the window kernels keep igemm_epilogue where the lean one would serve
-  // split-K remainder of the nine-tap window kernel (vdqn_conv_args.splitk_ws; win9.hip): 4 KiB of per-tile arrival counters, then
-  // f32 partial tiles of 128 x 128
-  unsigned* sk_cnt;
-  float* sk_slab;
 };
 
 constexpr unsigned kOob = 0x80000000u;  // voffset beyond any descriptor range (num_records <= 0x7fffffff)
@@ -82,7 +71,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     const bool vec = p.vec_ok && (ncol + CPL <= p.co);
     float bv[CPL];
 #pragma unroll
-    for (int e = 0; e < CPL; ++e) bv[e] = (bias && ncol + e < p.co) ? bias[ncol + e] : 0.f;  // (grouped forward: the tile's own set)
+    for (int e = 0; e < CPL; ++e) bv[e] = (bias && ncol + e < p.co) ? bias[ncol + e] : 0.f;
     size_t o[4];
     bool okr[4];
 #pragma unroll

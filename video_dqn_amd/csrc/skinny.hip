@@ -316,9 +316,9 @@ bool vdqn_skinny_enabled() {
 
 // Does vdqn_conv2d hand this call to the skinny kernels?  bf16, a linear layer (1x1 over 1x1 "images": M = samples) or a valid
 // (pad 0) stride-1 r x s convolution with at most 64 output columns, forward or (linear only) data gradient, M small enough that the
-// generic kernel would be a handful of tiles; no sibling, no residual, not grouped.
+// generic kernel would be a handful of tiles; no sibling, no residual.
 int vdqn_skinny_kind(const vdqn_conv_args* a) {
-  if (!vdqn_skinny_enabled() || a->dtype != VDQN_BF16 || a->wt2 || a->in2 || a->wt_b || a->resid) return 0;
+  if (!vdqn_skinny_enabled() || a->dtype != VDQN_BF16 || a->wt2 || a->in2 || a->resid) return 0;
   if (a->ci % 32 != 0 || (a->pix_stride * 2) % 16 != 0 || a->ldo % 4 != 0 || a->co % 4 != 0) return 0;
   if ((((uintptr_t)a->out | (uintptr_t)a->mask) & 7) != 0 || (((uintptr_t)a->out_f32) & 15) != 0) return 0;
   const long long M = (long long)a->n_img * a->ho * a->wo;

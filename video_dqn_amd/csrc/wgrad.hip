@@ -422,55 +422,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // byte the block does three times the MFMAs of wgrad_kernel (which restages both operands for every tap).
 // Grid: (co tile, kernel row, ci tile) x split of the pixel range.
 // ---------------------------------------------------------------------------------------------------------
-// NW = 4 waves, two workgroups per CU (64 x 64 tiles, and 128 x 64 as a 2 x 2 wave grid); NW = 8 waves, ONE workgroup per CU:
-// 128 x 128 tiles for the 128+ channel layers — wave (co half, ci quarter) owns 64 x 32 x 3 taps = 96 accumulator VGPRs for all
-// four sub-steps, nothing is summed across waves, and per staged byte the tile does twice the MFMAs of two 64 x 64 tiles:
-// 66 KB per 128 pixels and CU for 6.3 MMAC instead of 66 KB for 3.1.  (The 64 x 64 tiles of two co-resident workgroups ask the
-// L2 -> LDS path for 43 B per cycle and CU at full MFMA rate, against the ~33 it delivers — MI355X_MICROARCH.md, gather into LDS —
-// which is why pipelining their fragment stream alone did not move them: profiles/r03b_ab_grouped_mfma32_wgradwin.txt.)
+// 64 x 64 tiles, four waves, two workgroups per CU.  (Eight-wave 128 x 128 tiles — stride 1 and a stride-2 window form — and
+// 128 x 64 tiles were built and measured slower: experiments/, DESIGN.md section 6d.  The 64 x 64 tiles of two co-resident
+// workgroups ask the L2 -> LDS path for 43 B per cycle and CU at full MFMA rate, against the ~33 it delivers —
+// MI355X_MICROARCH.md, gather into LDS.)
 constexpr int kWgZeroBytes = 16 * 256 + 256;  // wgrad_win: zero block (covers the +16-row immediate of high-half reads for 128- and 256-byte rows)
 constexpr int kWgCodeBytes = 3200;            // border-code table: images up to 56 x 56
 
-// S2 (round 5; eight waves): the 3x3 / STRIDE-2 / pad-1 layers over even-sized images.  Output pixel p = (q, x) (q = img * ho + y over the
-// stacked images) reads input pixel (2 q + kr - 1, 2 x + ks - 1).  The input rows a kernel row kr touches — every second row of the
-// stacked input — laid end to end form a sequence U = q * 2 wo + column in which tap ks of pixel p sits at U = 2 p + ks - 1: linear
-// in p with stride 2.  So the window of a K-step is the 2 KP + 2 consecutive elements of that sequence from 2 kb - 1 on (staged with
-// one division per DMA piece and lane: sequence element -> memory pixel), tap ks of tile pixel r reads window row 2 r + ks, and the
-// only borders are the top image row for kr = 0 and the left column for ks = 0.  The generic kernel restaged gy AND x for every
-// tap (stamps: 945-1067 of ~2,000 cycles per K tile in the DMA issue, profiles/r05y_stamp_wgrad_generic.txt).
-template <int BCO, int BCI, int NW, bool S2 = false>
-__global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradParams p) {
   typedef bf16raw T;
+  constexpr int BCO = 64, BCI = 64, NW = 4;
   constexpr int E16 = 8;
   constexpr int NT = 64 * NW;
   constexpr int RBG = BCO * 2, RBX = BCI * 2;      // bytes per staged gy / x row (one pixel)
   constexpr int CPRG = RBG / 16, CPRX = RBX / 16;
-  // WSPLIT (64 x 64 tiles): wave (wave & 1) owns ALL 64 output channels x one HALF of the input channels (three taps: 24
+  // wave (wave & 1) owns ALL 64 output channels x one HALF of the input channels (three taps: 24
   // accumulator tiles = 96 VGPRs) for TWO of the four 32-pixel sub-steps of a staged K-step (waves 0, 1: sub-steps 0, 1; waves
   // 2, 3: sub-steps 2, 3); the two partial tiles of a channel half are summed through LDS before the atomics.  (Round 2 gave
   // every wave the whole 64 x 64 x 3 tile = 192 accumulator VGPRs for one sub-step: no room for a second fragment set, every
   // group of four MFMAs waited lgkmcnt(0) for its own fragment pair, and five registers spilled into the K loop.)
-  constexpr bool WSPLIT = (BCO == 64 && BCI == 64);
-  static_assert(NW == 4 || (NW == 8 && BCO == 128 && BCI == 128), "8 waves: the 128 x 128 tile");
-  static_assert(!S2 || NW == 8, "stride-2 windows: the eight-wave tile");
-  constexpr bool PIPE = WSPLIT || NW == 8;         // software-pipelined fragment stream (see compute)
-  constexpr int KSUB = PIPE ? (S2 ? 2 : 4) : 2;    // (stride 2: the window is twice as long per pixel — 64 pixels per K-step keep the tile in LDS)
+  constexpr int KSUB = 4;                          // 32-pixel sub-steps of a staged K-step
   constexpr int KP = 32 * KSUB;
   constexpr int NLG = (KP * CPRG) / NT;
-  constexpr int WR = S2 ? 2 * KP + 8 : KP + 8;     // window rows (KP + 2 / 2 KP + 2 needed)
-  constexpr int HI = (S2 ? 32 : 16) * RBX;         // LDS distance of a transposing read's high half (16 tile pixels further on)
-  constexpr int ZBYTES = S2 ? 32 * RBX + 256 : kWgZeroBytes;
+  constexpr int WR = KP + 8;                       // window rows (KP + 2 needed)
+  constexpr int HI = 16 * RBX;                     // LDS distance of a transposing read's high half (16 tile pixels further on)
+  constexpr int ZBYTES = kWgZeroBytes;
   constexpr int NLX = (WR * CPRX + NT - 1) / NT;   // 16-byte slots per thread for the window (the last pass is partial)
-  constexpr int WCOLS = WSPLIT ? 2 : NW / 2;       // wave grid: 2 output-channel halves (1 for WSPLIT) x WCOLS input-channel parts
-  constexpr int NFA = WSPLIT ? 4 : BCO / 32;       // 16-wide fragments per wave: output channels
-  constexpr int NFB = BCI / (16 * WCOLS);          //                              input channels
-  constexpr int NSUBW = WSPLIT ? 2 : KSUB;         // sub-steps of a staged K-step this wave computes
+  constexpr int NFA = 4;                           // 16-wide fragments per wave: output channels
+  constexpr int NFB = 2;                           //                              input channels
+  constexpr int NSUBW = 2;                         // sub-steps of a staged K-step this wave computes
   static_assert((KP * CPRG) % NT == 0 && (WR * CPRX - NT * (NLX - 1)) % 64 == 0, "staging passes are whole waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;                         // [2][KP * RBG]   gy tiles
   unsigned char* sX = smem + 2 * KP * RBG;          // [2][WR * RBX]   x windows
   unsigned char* sZ = sX + 2 * WR * RBX;            // [kWgZeroBytes]  zeros at +0 and at +16 rows (every LDS bank once each; a multiple of 256 from smem)
-  unsigned char* sCode = sZ + ZBYTES;               // [kWgCodeBytes]  PIPE: border code of every pixel position of an image
+  unsigned char* sCode = sZ + ZBYTES;               // [kWgCodeBytes]  border code of every pixel position of an image
   static_assert((2 * KP * RBG) % 256 == 0 && (WR * RBX) % 256 == 0, "window buffers and the zero block sit at 256-byte boundaries");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -491,13 +477,11 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   // same +16-row immediate as the reads of the window (so one select serves an address pair)
   for (int i = tid; i < 32; i += NT) reinterpret_cast<uint4*>(sZ + (i >> 4) * HI)[i & 15] = make_uint4(0, 0, 0, 0);
   const int howo = (int)p.d_howo.div;
-  if constexpr (PIPE) {
-    // border code of image position rem = oh * W + ow: 1 top row, 2 bottom row, 4 left column, 8 right column.  One table per
-    // workgroup instead of two divisions per pixel and K tile in every lane.
-    for (int i = tid; i < howo; i += NT) {
-      const uint32_t oh = fastdiv((uint32_t)i, p.d_wo), ow = (uint32_t)i - oh * p.d_wo.div;
-      sCode[i] = (unsigned char)((oh == 0 ? 1u : 0u) | (oh == (uint32_t)p.ho - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)p.wo - 1 ? 8u : 0u));
-    }
+  // border code of image position rem = oh * W + ow: 1 top row, 2 bottom row, 4 left column, 8 right column.  One table per
+  // workgroup instead of two divisions per pixel and K tile in every lane.
+  for (int i = tid; i < howo; i += NT) {
+    const uint32_t oh = fastdiv((uint32_t)i, p.d_wo), ow = (uint32_t)i - oh * p.d_wo.div;
+    sCode[i] = (unsigned char)((oh == 0 ? 1u : 0u) | (oh == (uint32_t)p.ho - 1 ? 2u : 0u) | (ow == 0 ? 4u : 0u) | (ow == (uint32_t)p.wo - 1 ? 8u : 0u));
   }
 
   typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -506,7 +490,6 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
                       __builtin_amdgcn_readfirstlane(p.gy_bytes), 0x00020000};
   const i32x4 rs_x = {__builtin_amdgcn_readfirstlane((int)(unsigned)x_ptr), __builtin_amdgcn_readfirstlane((int)((x_ptr >> 32) & 0xffff)),
                       __builtin_amdgcn_readfirstlane(p.x_bytes), 0x00020000};
-  constexpr unsigned kOobW = 0x80000000u;
   // 16-byte slot q = tid + 256 i of a staged tile: row q / CPR, source chunk (q % CPR) ^ swizzle(row) — recomputed per
   // issue (shifts and xors) instead of held in registers: the three accumulator tiles need most of the VGPRs
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -524,11 +507,9 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   // slot q = tid + 256 i of a staged tile is row q / CPR + (256 / CPR) i with the SAME source chunk for every i (the swizzle keys
   // repeat every 8 rows), so one per-lane offset per operand serves all pieces and the piece's row block is a scalar
   const uint32_t g_lane = (uint32_t)(tid / CPRG) * ldg_b + (uint32_t)((co0 + ((tid % CPRG) ^ wg_swz<T, BCO>(tid / CPRG)) * E16) * 2);
-  // (stride 2: window rows 2 j and 2 j + 1 share a swizzle key, so that the rows 2 r + ks a tap reads carry eight different keys)
-  const int x_key = S2 ? wg_swz<T, BCI>((tid / CPRX) >> 1) : wg_swz<T, BCI>(tid / CPRX);
+  const int x_key = wg_swz<T, BCI>(tid / CPRX);
   const uint32_t x_chunk = (uint32_t)((ci0 + ((tid % CPRX) ^ x_key) * E16) * 2);
   const uint32_t x_lane = (uint32_t)(tid / CPRX) * pix_b + x_chunk;
-  static_assert(!S2 || (NT / CPRX) % 16 == 0, "stride 2: the halved row index repeats its key over the pieces of one thread too");
   static_assert((NT / CPRG) % 8 == 0 && (NT / CPRX) % 8 == 0, "swizzle keys repeat over the pieces of one thread");
   const int x_shift = (kr - 1) * p.wo - 1;  // window row j = pixel kb + j + x_shift
 
@@ -541,16 +522,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     } else {
       const int ix = i - NLG;
       if (ix == NLX - 1 && wave_u >= X_TAIL_WAVES) return;
-      uint32_t vx;
-      if constexpr (S2) {
-        // window row j = element U = 2 kb - 1 + j of the kernel row's input-row sequence -> memory pixel U + (U / 2 wo + kr - 1) 2 wo
-        const int U = 2 * kb - 1 + tid / CPRX + (NT / CPRX) * ix;
-        const int qrow = U >= 0 ? (int)fastdiv((uint32_t)U >> 1, p.d_wo) : 0;
-        const int mem = U + (qrow + kr - 1) * 2 * p.wo;
-        vx = (U >= 0 && mem >= 0) ? x_chunk + (uint32_t)mem * pix_b : kOobW;  // (past the tensor: beyond the descriptor's range, zero-filled)
-      } else {
-        vx = x_lane + (uint32_t)(kb + x_shift + (NT / CPRX) * ix) * pix_b;  // may wrap below zero: out of range, zero-filled
-      }
+      const uint32_t vx = x_lane + (uint32_t)(kb + x_shift + (NT / CPRX) * ix) * pix_b;  // may wrap below zero: out of range, zero-filled
       const uint32_t lx = lds_wave + (uint32_t)(2 * KP * RBG + buf * (WR * RBX) + ix * (NT * 16));
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(vx), "s"(lx), "s"(rs_x) : "memory");
     }
@@ -568,51 +540,14 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
 #pragma unroll
       for (int j = 0; j < NFB; ++j) acc[k3][f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = WSPLIT ? 0 : wave / WCOLS, wc = WSPLIT ? (wave & 1) : wave % WCOLS;
+  const int wc = wave & 1;
   const int grp = lane >> 4, i16 = lane & 15;
   const int q4 = i16 >> 2, pp = i16 & 3;
   const int row = 4 * grp + q4;            // pixel row (of 32) this lane addresses in a transposing read; + 16 for the high half
   const int sub8 = (pp & 1) << 3;
   const int szA = wg_swz<T, BCO>(row);
 
-  typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
-  // border flags of the two output pixels this lane addresses in sub-step `sub` (rows `row` and `row + 16`): bit hh = the tap ks
-  // of kernel row kr leaves the image for pixel hh -> that lane reads zeros
-  auto border = [&](int kb, int sub, uint32_t (&zmask)[3]) {
-    zmask[0] = zmask[1] = zmask[2] = 0u;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const uint32_t pm = (uint32_t)(kb + sub * 32 + row + 16 * hh);
-      const uint32_t rem = pm - fastdiv(pm, p.d_howo) * p.d_howo.div;
-      const uint32_t oh = fastdiv(rem, p.d_wo);
-      const uint32_t ow = rem - oh * p.d_wo.div;
-      // (bitwise, not short-circuit: the compiler otherwise branches per lane inside the K loop)
-      const uint32_t e_v = ((uint32_t)(kr == 0) & (uint32_t)(oh == 0)) | ((uint32_t)(kr == 2) & (uint32_t)(oh == (uint32_t)p.ho - 1));  // whole kernel row outside
-      zmask[0] |= (e_v | (uint32_t)(ow == 0)) << hh;
-      zmask[1] |= e_v << hh;
-      zmask[2] |= (e_v | (uint32_t)(ow == (uint32_t)p.wo - 1)) << hh;
-    }
-  };
-  // x fragment (input channels cb .. cb + 15) of tap ks for sub-step `sub`: two transposing reads, a border lane reads the zeros
-  // at its OWN position modulo 256 bytes (the lane groups of the read then still hit distinct banks)
-  auto load_x = [&](const unsigned char* xw, int sub, int ks, int cb, uint32_t zm) -> s16x8 {
-    const int jr = sub * 32 + row + ks;  // window row of the low half; high half: + 16 (same swizzle key for both)
-    const int szX = wg_swz<T, BCI>(jr);
-    const int off = jr * RBX + ((((cb >> 3) + (pp >> 1)) ^ szX) << 4) + sub8;
-    const unsigned char* p0 = (zm & 1u) ? sZ + (off & 255) : xw + off;
-    const unsigned char* p1 = (zm & 2u) ? sZ + ((off + 16 * RBX) & 255) : xw + off + 16 * RBX;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)p1);
-    return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  };
-  auto load_g = [&](const unsigned char* a, int cb) -> s16x8 {
-    const int off = row * RBG + ((((cb >> 3) + (pp >> 1)) ^ szA) << 4) + sub8;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a + off));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a + off + 16 * RBG));
-    return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  };
-
-  // ---- PIPE path: everything a fragment read needs is a per-lane constant of the workgroup, computed here once ----
+  // ---- everything a fragment read needs is a per-lane constant of the workgroup, computed here once ----
   // The K loop of round 2 issued ~4.8 vector instructions per MFMA (SQ_INSTS_VALU / SQ_INSTS_MFMA = 6 over the whole kernel): LDS
   // addresses rebuilt for every read, two divisions per pixel for the border test, selects — at 4 issue cycles each beside 8 per
   // MFMA that is 1300 issue cycles per wave and K tile for 768 cycles of matrix work, with two waves per SIMD: the loop was bound
@@ -621,15 +556,14 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   // sub-step i, tap ks, channel fragment j; go[f] = offset of gy fragment f inside a sub-step's 32 gy rows; the buffer index is a
   // compile-time constant (the K loop is unrolled by two), so buffer / sub-step / high-half offsets are ds_read immediates; a
   // border lane's read pair is redirected by ONE select pair to the zero block at its own bank position (off & 255).
-  const int sub0 = WSPLIT ? (wave >> 1) * 2 : 0;  // first sub-step of this wave
+  const int sub0 = (wave >> 1) * 2;  // first sub-step of this wave
   uint32_t xo[NSUBW][3][NFB], go[NFA];
   uint32_t rem[NSUBW][2];  // position inside its image (oh * W + ow) of the wave's pixels (sub-step i, half hh) of the CURRENT K tile
   bool zb[NSUBW][3][2];    // zb[i][ks][hh]: tap ks of kernel row kr leaves the image for that pixel (lane masks in scalar registers)
   const uint32_t lds_smem = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const uint32_t z_base = lds_smem + (uint32_t)(sZ - smem);
-  // border code bits that put the whole kernel row outside (stride 2 over an even-sized image: only the top row for kr = 0 —
-  // input row 2 y + 1 <= 2 ho - 1 always exists)
-  const uint32_t vmask = kr == 0 ? 1u : ((kr == 2 && !S2) ? 2u : 0u);
+  // border code bits that put the whole kernel row outside
+  const uint32_t vmask = kr == 0 ? 1u : (kr == 2 ? 2u : 0u);
   const uint32_t kp_mod = (uint32_t)(KP % howo);
   auto masks_from_rem = [&](int i) {
     uint32_t c[2];
@@ -639,7 +573,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     for (int hh = 0; hh < 2; ++hh) {
       zb[i][0][hh] = (c[hh] & (vmask | 4u)) != 0u;  // kernel row outside, or left column with tap 0
       zb[i][1][hh] = (c[hh] & vmask) != 0u;
-      zb[i][2][hh] = (c[hh] & (vmask | (S2 ? 0u : 8u))) != 0u;  // ... or right column with tap 2 (stride 2: column 2 wo - 1 exists)
+      zb[i][2][hh] = (c[hh] & (vmask | 8u)) != 0u;  // ... or right column with tap 2
     }
   };
   auto advance_rem = [&](int i) {  // the same pixels of the next K tile: KP positions further on, modulo the image
@@ -650,34 +584,32 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
       rem[i][hh] = r;
     }
   };
-  if constexpr (PIPE) {
 #pragma unroll
-    for (int f = 0; f < NFA; ++f) {
-      const int cb = wr * (BCO / 2) + f * 16;
-      go[f] = lds_smem + (uint32_t)((sub0 * 32 + row) * RBG + ((((cb >> 3) + (pp >> 1)) ^ szA) << 4) + sub8);
-    }
-#pragma unroll
-    for (int i = 0; i < NSUBW; ++i) {
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        const int jr = S2 ? 2 * ((sub0 + i) * 32 + row) + ks : (sub0 + i) * 32 + row + ks;
-        const int szX = S2 ? wg_swz<T, BCI>(jr >> 1) : wg_swz<T, BCI>(jr);
-#pragma unroll
-        for (int j = 0; j < NFB; ++j) {
-          const int cb = wc * (16 * NFB) + j * 16;
-          xo[i][ks][j] = lds_smem + (uint32_t)(2 * KP * RBG + jr * RBX + ((((cb >> 3) + (pp >> 1)) ^ szX) << 4) + sub8);
-        }
-      }
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const uint32_t pm = (uint32_t)(kbeg + (sub0 + i) * 32 + row + 16 * hh);
-        rem[i][hh] = pm - fastdiv(pm, p.d_howo) * p.d_howo.div;
-      }
-    }
-    __syncthreads();  // the code table is complete
-#pragma unroll
-    for (int i = 0; i < NSUBW; ++i) masks_from_rem(i);
+  for (int f = 0; f < NFA; ++f) {
+    const int cb = f * 16;
+    go[f] = lds_smem + (uint32_t)((sub0 * 32 + row) * RBG + ((((cb >> 3) + (pp >> 1)) ^ szA) << 4) + sub8);
   }
+#pragma unroll
+  for (int i = 0; i < NSUBW; ++i) {
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int jr = (sub0 + i) * 32 + row + ks;
+      const int szX = wg_swz<T, BCI>(jr);
+#pragma unroll
+      for (int j = 0; j < NFB; ++j) {
+        const int cb = wc * (16 * NFB) + j * 16;
+        xo[i][ks][j] = lds_smem + (uint32_t)(2 * KP * RBG + jr * RBX + ((((cb >> 3) + (pp >> 1)) ^ szX) << 4) + sub8);
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const uint32_t pm = (uint32_t)(kbeg + (sub0 + i) * 32 + row + 16 * hh);
+      rem[i][hh] = pm - fastdiv(pm, p.d_howo) * p.d_howo.div;
+    }
+  }
+  __syncthreads();  // the code table is complete
+#pragma unroll
+  for (int i = 0; i < NSUBW; ++i) masks_from_rem(i);
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   auto lds_tr = [](uint32_t addr, int imm) -> s16x4 {  // ds_read_b64_tr_b16 addr offset:imm
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr) + imm / 8);
@@ -688,8 +620,8 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   // read: a piece holds the wave at issue for ~65 cycles (tools/stamp_wgrad.py: 560-675 cycles per tile for nine pieces).
   // Measured: 1.00 against 0.93 ms per update for the window weight gradients — the pieces stall the MFMA stream more than
   // they stall in front of it.  Not the default.
-  auto compute_pipe = [&](int buf, int kb_next) {
-    if constexpr (PIPE) {
+  auto compute = [&](int buf, int kb_next) {
+    {
       // Software pipeline over the wave's NSUBW sub-steps: NSUBW x (3 taps x NFB channel fragments) stages of NFA MFMAs (one x
       // fragment against the NFA gy fragments).  The x fragment of stage s + 2 is read while stage s computes (three register
       // sets), the gy fragments of the next sub-step (second register set) while the current one's stages 2.. compute: no MFMA
@@ -747,34 +679,6 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     }
   };
 
-  auto compute = [&](int buf, int kb, int kb_next) {
-    const unsigned char* xw = sX + buf * (WR * RBX);
-    if constexpr (PIPE) {
-      (void)xw; (void)kb;
-      compute_pipe(buf, kb_next);
-    } else {
-#pragma unroll 1
-      for (int sub = 0; sub < KSUB; ++sub) {
-        const unsigned char* a = sA + buf * (KP * RBG) + sub * (32 * RBG);
-        uint32_t zl[3];
-        border(kb, sub, zl);
-        s16x8 af[NFA];
-#pragma unroll
-        for (int f = 0; f < NFA; ++f) af[f] = load_g(a, wr * (BCO / 2) + f * 16);
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-#pragma unroll
-          for (int j = 0; j < NFB; ++j) {  // one x fragment live at a time (register budget)
-            const s16x8 bj = load_x(xw, sub, ks, wc * (16 * NFB) + j * 16, zl[ks]);
-#pragma unroll
-            for (int f = 0; f < NFA; ++f)
-              acc[ks][f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[f]), __builtin_bit_cast(bf16x8, bj), acc[ks][f][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-  };
-
 #ifdef VDQN_STAMP
   unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_comp = 0;
   const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rt_begin = __builtin_amdgcn_s_memrealtime();
@@ -792,13 +696,13 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
     __builtin_amdgcn_s_barrier();  // tile k landed for every wave; every wave is done with tile k-1
     VDQN_WST(st_bar)
 #ifdef VDQN_WGRAD_TRICKLE  // (build flag: measured 8 % slower per kernel, profiles/r03h_ab_wgrad_trickle.txt — off)
-    constexpr bool kTrickle = PIPE;
+    constexpr bool kTrickle = true;
 #else
     constexpr bool kTrickle = false;
 #endif
     if (!kTrickle && k + 1 < nk) issue_tile(kbeg + (k + 1) * KP, buf ^ 1);
     VDQN_WST(st_issue)
-    compute(buf, kbeg + k * KP, (kTrickle && k + 1 < nk) ? kbeg + (k + 1) * KP : -1);
+    compute(buf, (kTrickle && k + 1 < nk) ? kbeg + (k + 1) * KP : -1);
     VDQN_WST(st_comp)
   }
 #ifdef VDQN_STAMP
@@ -814,36 +718,19 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_win_kernel(const WgradParams
   for (int ks = 0; ks < 3; ++ks) {
     const int tap = kr * 3 + ks;
     __syncthreads();  // staging buffers (or the previous tap's tile) are free
-    if constexpr (WSPLIT) {
 #pragma unroll
-      for (int f = 0; f < NFA; ++f)
+    for (int f = 0; f < NFA; ++f)
 #pragma unroll
-        for (int j = 0; j < NFB; ++j)
+      for (int j = 0; j < NFB; ++j)
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) red[(wave >> 1) * 4096 + (f * 16 + grp * 4 + reg) * 64 + wc * 32 + j * 16 + i16] = acc[ks][f][j][reg];
-      __syncthreads();
+        for (int reg = 0; reg < 4; ++reg) red[(wave >> 1) * 4096 + (f * 16 + grp * 4 + reg) * 64 + wc * 32 + j * 16 + i16] = acc[ks][f][j][reg];
+    __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int o = tid + 256 * e;
-        const float v = red[o] + red[4096 + o];
-        const int co = co0 + (o >> 6), ci = ci0 + (o & 63);
-        if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, v);
-      }
-    } else {
-#pragma unroll
-      for (int f = 0; f < NFA; ++f)
-#pragma unroll
-        for (int j = 0; j < NFB; ++j)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg)
-            red[(wr * (BCO / 2) + f * 16 + grp * 4 + reg) * BCI + wc * (16 * NFB) + j * 16 + i16] = acc[ks][f][j][reg];
-      __syncthreads();
-#pragma unroll 8
-      for (int e = 0; e < BCO * BCI / NT; ++e) {
-        const int o = tid + NT * e;
-        const int co = co0 + o / BCI, ci = ci0 + o % BCI;
-        if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, red[o]);
-      }
+    for (int e = 0; e < 16; ++e) {
+      const int o = tid + 256 * e;
+      const float v = red[o] + red[4096 + o];
+      const int co = co0 + (o >> 6), ci = ci0 + (o & 63);
+      if (co < p.co) wg_emit(dwp + (size_t)co * row_len + (size_t)tap * p.ci + ci, det, v);
     }
   }
 #ifdef VDQN_STAMP
@@ -1299,18 +1186,15 @@ int launch_stem_wgrad(const WgradParams& p, hipStream_t stream) {
   return VDQN_OK;
 }
 
-template <int BCO, int BCI, int NW = 4, bool S2 = false>
 int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t stream) {
-  constexpr int KP = 32 * (S2 ? 2 : (((BCO == 64 && BCI == 64) || NW == 8) ? 4 : 2));
-  constexpr int WR = S2 ? 2 * KP + 8 : KP + 8;
-  constexpr int ZB = S2 ? 32 * BCI * 2 + 256 : kWgZeroBytes;
-  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * WR) * BCI * 2 + ZB + kWgCodeBytes;  // gy tiles, x windows, zeros, border codes
-  const size_t smem_epi = (BCO == 64 && BCI == 64) ? (size_t)2 * 64 * 64 * 4 : (size_t)BCO * BCI * 4;
+  constexpr int BCO = 64, BCI = 64, KP = 128, WR = KP + 8;
+  const size_t smem_stage = (size_t)2 * KP * BCO * 2 + (size_t)(2 * WR) * BCI * 2 + kWgZeroBytes + kWgCodeBytes;  // gy tiles, x windows, zeros, border codes
+  const size_t smem_epi = (size_t)2 * 64 * 64 * 4;
   const size_t smem = smem_stage > smem_epi ? smem_stage : smem_epi;
-  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel<BCO, BCI, NW, S2>), (size_t)smem);
-  vdqn_prof_begin(S2 ? "wgrad_s2win<bf16,128>" : (NW == 8 ? "wgrad_win<bf16,128>" : (BCO == 128 ? "wgrad_win<bf16,128x64>" : "wgrad_win<bf16,64>")), 2.0 * p.M * p.co * p.taps * p.ci,
+  vdqn_ensure_dyn_smem(reinterpret_cast<const void*>(&wgrad_win_kernel), (size_t)smem);
+  vdqn_prof_begin("wgrad_win<bf16,64>", 2.0 * p.M * p.co * p.taps * p.ci,
                   2.0 * ((double)p.M * p.ldg + (double)p.n_img * p.hi * p.wi * p.ci) + 4.0 * p.co * p.taps * p.ci, stream);
-  hipLaunchKernelGGL((wgrad_win_kernel<BCO, BCI, NW, S2>), dim3(tiles * splitk), dim3(64 * NW), smem, stream, p);
+  hipLaunchKernelGGL(wgrad_win_kernel, dim3(tiles * splitk), dim3(256), smem, stream, p);
   vdqn_prof_end(stream);
   VDQN_LAUNCH_CHECK();
   return VDQN_OK;
@@ -1318,13 +1202,11 @@ int launch_wgrad_win(const WgradParams& p, int tiles, int splitk, hipStream_t st
 
 // Which kernel a call runs on and how its pixel range is split (shared by the launch and by the workspace-size query).
 struct WgradPlan {
-  int variant;      // 0 stem kernel, 1 window 64x64, 2 window 128x64, 3 generic, 4 window 128x128 (eight waves), 5 stride-2 window 128x128 (eight waves)
+  int variant;      // 0 stem kernel, 1 window 64x64, 3 generic
   int bt, ci_tiles, tiles, splitk, kchunk;
   int copies;       // partial copies of dw the deterministic mode stores (active splits, or blocks of the stem kernel)
   long long copy_elems;  // floats per copy
 };
-
-int g_wgrad_s2win_override = -1;  // tests: vdqn_debug_set_wgrad_s2win
 
 int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
   VDQN_CHECK(a != nullptr, "vdqn_conv2d_wgrad: null args");
@@ -1356,15 +1238,12 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
     if (splitk < 1) splitk = 1;
   }
   pl->variant = 3;
-  // (round 3: default 3 — with the K loop's vector instructions cut the 64 x 64 window tiles win on layer4 too: 0.91 + 0.13 against
-  // 0.70 + 0.40 ms per update for window + generic launches, profiles/r03f_ab_wgrad_valu_diet.txt)
-  static const int use_win = [] { const char* e = getenv("VDQN_WGRAD_WINDOW"); return e ? atoi(e) : 3; }();
+  // VDQN_WGRAD_WINDOW=0: the 3x3 / stride-1 layers on the generic kernel too (A/B).  (Since round 3 the 64 x 64 window tiles take
+  // every such layer: with the K loop's vector instructions cut they win on layer4 too — 0.91 + 0.13 against 0.70 + 0.40 ms per
+  // update for window + generic launches, profiles/r03f_ab_wgrad_valu_diet.txt)
+  static const int use_win = [] { const char* e = getenv("VDQN_WGRAD_WINDOW"); return e ? atoi(e) : 1; }();
   static const int use_stem = [] { const char* e = getenv("VDQN_WGRAD_STEM"); return e ? atoi(e) : 1; }();
-  // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps.  64 x 64 window tiles win
-  // on the 64-channel layers (672 vs 420 TFLOP/s) and on the 128- and 256-channel layers (layer2 / layer3: 705 vs 645) as
-  // long as tiles x split fills one round of 512 blocks; layer4 (192 tiles -> 384 blocks) stays on the generic 128 x 128
-  // kernel (650 vs 605).  VDQN_WGRAD_WINDOW=2: 128(co) x 64(ci) window tiles for layer4 too, =3: 64 x 64 everywhere
-  const bool small_win = bt == 64 || (long long)co_pad * a->ci <= 256 * 256;
+  // window kernel: one block per (co tile, kernel ROW, ci tile) computes the three horizontal taps
   if (use_stem && a->dtype == VDQN_BF16 && a->r == 4 && a->s == 1 && a->ci == 64 && a->pix_stride == 16 && a->hi == 115 && a->wi == 115 && a->ho == 112 &&
       a->wo == 112 && a->co == 64 && a->ldg == 64 && a->stride == 1 && a->pad == 0 && a->splitk <= 0) {
     pl->variant = 0;
@@ -1377,43 +1256,12 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
     pl->kchunk = M;
     return VDQN_OK;
   }
-  // VDQN_WGRAD_WIN128=1: 128 x 128 window tiles on eight waves, one workgroup per CU, for the 3x3 / stride-1 layers with 128+ channels
-  // (layer2 - layer4): twice the MFMAs per staged byte of the 64 x 64 tiles, no sum across waves.  Measured SLOWER (0.94 ms per update
-  // for the nine launches against 0.47 + 0.28 on 64 x 64 window / generic 128 x 128 tiles, profiles/r03d_ab_wgrad_win128.txt): at one
-  // block per CU every block ends with 196 KB of f32 atomics (50 MB per launch against 25-28 MB) — off by default
-  static const int use_win128 = [] { const char* e = getenv("VDQN_WGRAD_WIN128"); return e ? atoi(e) : 0; }();
   const bool win_geom = a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 1 && a->pad == 1 && a->pix_stride == a->ci && a->wo >= 2 &&
                         a->hi == a->ho && a->wi == a->wo && a->ho * a->wo <= kWgCodeBytes;  // (border-code table of one image in LDS)
-  // VDQN_WGRAD_S2WIN=1 (default 0): the 3x3 / stride-2 layers with 128+ channels on both sides (layer3.0, layer4.0 conv1) on the stride-2
-  // window tiles (wgrad_win_kernel<128, 128, 8, true>) instead of the generic kernel.  Built on the generic kernel's stamps (half of a
-  // K tile in the DMA issue) and MEASURED SLOWER: 0.146 vs 0.120 ms per update for the two launches (0.154 with 128 blocks;
-  // profiles/r06e_ab_wgrad_s2win_vs_generic.txt): at one 109 KB workgroup per CU nothing covers the tile's barriers, and the
-  // launches stay dominated by what they share with the generic kernel — 33-50 MB of f32 atomics for a 1.2-4.7 MB gradient.
-  static const int use_s2win_env = [] { const char* e = getenv("VDQN_WGRAD_S2WIN"); return e ? atoi(e) : 0; }();
-  const int use_s2win = g_wgrad_s2win_override >= 0 ? g_wgrad_s2win_override : use_s2win_env;
-  const bool s2_geom = a->dtype == VDQN_BF16 && a->r == 3 && a->s == 3 && a->stride == 2 && a->pad == 1 && a->pix_stride == a->ci && a->wo >= 2 &&
-                       a->hi == 2 * a->ho && a->wi == 2 * a->wo && a->ho * a->wo <= kWgCodeBytes && co_pad % 128 == 0 && a->ci % 128 == 0 && M64 < (1 << 22);
-  if (use_s2win && s2_geom) {
-    pl->variant = 5;
-    pl->ci_tiles = a->ci / 128;
-    pl->tiles = (co_pad / 128) * 3 * pl->ci_tiles;
-    static const int target_s2 = [] { const char* e = getenv("VDQN_WGRAD_S2WIN_BLOCKS"); return e ? atoi(e) : 256; }();  // one workgroup per CU
-    splitk = a->splitk > 0 ? a->splitk : target_s2 / pl->tiles;
-    if (splitk > max_split) splitk = max_split;
-    if (splitk < 1) splitk = 1;
-  } else if (use_win && use_win128 && use_win < 3 && win_geom && co_pad % 128 == 0 && a->ci % 128 == 0) {
-    pl->variant = 4;
-    pl->ci_tiles = a->ci / 128;
-    pl->tiles = (co_pad / 128) * 3 * pl->ci_tiles;
-    const int target8 = [] { const char* e = getenv("VDQN_WGRAD_BLOCKS8"); return e ? atoi(e) : 256; }();  // one workgroup per CU
-    splitk = a->splitk > 0 ? a->splitk : target8 / pl->tiles;
-    if (splitk > max_split) splitk = max_split;
-    if (splitk < 1) splitk = 1;
-  } else if (use_win && (small_win || use_win >= 2) && win_geom) {
-    const int bco = (small_win || use_win >= 3) ? 64 : bt, bci = 64;
-    pl->variant = bco == 128 ? 2 : 1;
-    pl->ci_tiles = a->ci / bci;
-    pl->tiles = (co_pad / bco) * 3 * pl->ci_tiles;
+  if (use_win && win_geom) {
+    pl->variant = 1;
+    pl->ci_tiles = a->ci / 64;
+    pl->tiles = (co_pad / 64) * 3 * pl->ci_tiles;
     // VDQN_WGRAD_WIN_BLOCKS: workgroups per window weight-gradient launch.  512 = one full round at two per CU, the fastest launch on
     // its own (0.903 ms per update for the 13 launches; 384: 0.938, 768: 1.090) — but with the weight gradients alternating between two
     // low-priority streams beside the data-gradient chain, slightly fewer and longer blocks give the shorter UPDATE: 448: 5.636-5.643,
@@ -1430,8 +1278,6 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
 }
 
 }  // namespace
-
-extern "C" void vdqn_debug_set_wgrad_s2win(int v) { g_wgrad_s2win_override = v; }  // test hook (not part of include/vdqn.h): -1 = VDQN_WGRAD_S2WIN
 
 extern "C" int64_t vdqn_conv2d_wgrad_workspace_bytes(const vdqn_wgrad_args* a) {
   WgradPlan pl;
@@ -1479,10 +1325,7 @@ extern "C" int vdqn_conv2d_wgrad(const vdqn_wgrad_args* a, void* stream) {
   }
   int rc;
   if (pl.variant == 0) rc = launch_stem_wgrad(p, st);
-  else if (pl.variant == 5) rc = launch_wgrad_win<128, 128, 8, true>(p, pl.tiles, pl.splitk, st);
-  else if (pl.variant == 4) rc = launch_wgrad_win<128, 128, 8>(p, pl.tiles, pl.splitk, st);
-  else if (pl.variant == 2) rc = launch_wgrad_win<128, 64>(p, pl.tiles, pl.splitk, st);
-  else if (pl.variant == 1) rc = launch_wgrad_win<64, 64>(p, pl.tiles, pl.splitk, st);
+  else if (pl.variant == 1) rc = launch_wgrad_win(p, pl.tiles, pl.splitk, st);
   else if (a->dtype == VDQN_BF16) rc = pl.bt == 128 ? launch_wgrad<bf16raw, 128>(p, pl.tiles, pl.splitk, st) : launch_wgrad<bf16raw, 64>(p, pl.tiles, pl.splitk, st);
   else rc = pl.bt == 128 ? launch_wgrad<float, 128>(p, pl.tiles, pl.splitk, st) : launch_wgrad<float, 64>(p, pl.tiles, pl.splitk, st);
   if (rc != VDQN_OK) return rc;

@@ -32,15 +32,7 @@ _DIST_EARLY_ADAM = os.environ.get("VDQN_DIST_EARLY_ADAM", "0") in ("1", "2", "3"
 # diagnostic values (one rank only — they are wrong with more): 2 = the same without waiting for the bucket's collective (is the wait
 # the cost?), 3 = waiting for it, but without the Adam launch (is the extra kernel the cost?)
 _DIST_EARLY_ADAM_MODE = os.environ.get("VDQN_DIST_EARLY_ADAM", "0")
-# VDQN_EARLY_FOLD=1 (off by default): stage 0 / stage 1 weights are folded for the NEXT update right behind their early Adam, so that
-# update starts with a 0.7 M-parameter fold instead of a 12.4 M one.  Measured on alternating runs it is 0.6 % SLOWER (5.747 against
-# 5.712 ms, profiles/r04g_ab_early_fold_two_stream_packs.txt): at the start of an update the fold already runs beside the two input
-# packs on the other stream, so nothing is exposed there, while the moved fold lengthens the gradient stream that carries every
-# weight gradient.  Kept as a tested switch (bit-identical updates).
-_EARLY_FOLD = os.environ.get("VDQN_EARLY_FOLD", "0") == "1"
-# VDQN_AUX_STREAM=1: work of the NEXT update that runs under the current one (frames packed ahead, early fold) goes to the engine's
-# auxiliary low-priority stream (vdqn_net_aux_stream) instead of the gradient stream, where it delays no weight gradient
-_AUX_STREAM = os.environ.get("VDQN_AUX_STREAM", "0") == "1"
+
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -294,7 +286,7 @@ class TDStepper:
     def __init__(self, net: NetEngine, batch: int, lr: float, gamma: float, clip_rect: bool, linear: bool = False,
                  remove_before_reward: bool = False, train_on_ground_truth: bool = False, value_learning: bool = False,
                  target_update_interval: int = 8000, betas=(0.9, 0.999), eps: float = 1e-8, world_size: int = 1,
-                 allreduce=None, loss_kind: str = "l2", grouped_forward: Optional[bool] = None, allreduce_loss=None, allreduce_wait=None):
+                 allreduce=None, loss_kind: str = "l2", allreduce_loss=None, allreduce_wait=None):
         net._need_gpu()
         self.net, self.B = net, batch
         self.lib = net.lib
@@ -323,18 +315,10 @@ class TDStepper:
         with torch.cuda.device(dev):
             self.packed_online = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
             self.packed_target = torch.zeros(net.packed_bytes, dtype=torch.uint8, device=dev)
-            # grouped forward (VDQN_GROUPED_FWD=1 / grouped_forward=True; TD branch of extra_capacity): the target network's pass over
-            # s' runs inside the online pass's launches (include/vdqn.h, vdqn_step_args.acts_target).  Off by default: it saves
-            # 0.26 ms of kernel time per update (fewer partial rounds, 21 launches fewer) but the update gets 0.2 ms LONGER — as
-            # two passes the target forward runs on the engine's side stream and fills the online chain's launch gaps and tail
-            # rounds, which one merged chain cannot (profiles/r03b_ab_grouped_mfma32_wgradwin.txt: 5.98 vs 5.77 ms)
-            if grouped_forward is None:
-                grouped_forward = os.environ.get("VDQN_GROUPED_FWD", "0") == "1"
-            self.grouped = bool(grouped_forward) and not self.gtb and net.extra_capacity
-            n_online = batch if self.gtb else (3 * batch if self.grouped else 2 * batch)
+            n_online = batch if self.gtb else 2 * batch
             self.layout_samples = n_online  # what vdqn_net_act_offset must be asked for to find a tensor inside acts_online
             self.acts_online = torch.empty(net.acts_bytes(n_online), dtype=torch.uint8, device=dev)
-            self.acts_target = None if (self.gtb or self.grouped) else torch.empty(net.acts_bytes(batch), dtype=torch.uint8, device=dev)
+            self.acts_target = None if self.gtb else torch.empty(net.acts_bytes(batch), dtype=torch.uint8, device=dev)
             net.register_sync_buffer(self.acts_online)
             self.bwd = torch.empty(net.bwd_bytes(batch), dtype=torch.uint8, device=dev)
             self.grads = torch.zeros(nt, dtype=torch.float32, device=dev)
@@ -346,9 +330,7 @@ class TDStepper:
         self.adam_step = 0
         self.sample_number = 0
         self._grad_stream = None  # torch view of the engine's side stream (vdqn_net_grad_stream)
-        self._aux_stream, self._aux_used = None, False  # ... and of its auxiliary low-priority stream
         self._adam_done = []
-        self._prefolded, self._prefold_key = 0, None  # stages of packed_online refreshed behind their early Adam, and for which parameters
         self._packed_bufs, self._ahead = [None, None], None
         self.stage_ranges = [net.stage_range(s) for s in range(3)]
         self.sync_target()
@@ -374,12 +356,28 @@ class TDStepper:
         a.grads, a.loss, a.q_before = _ptr(self.grads), _ptr(self.loss), _ptr(self.q_before)
         a.loss_kind = LOSS_KINDS[self.loss_kind]
         a.packed_frames = None
-        # stages whose packed weights the previous update already refreshed (see forward_backward): valid only while nothing else
-        # has touched the parameters since
-        a.prefolded_stages = self._prefolded if (self._prefolded and self._prefold_key == n.version_key()) else 0
         return a
 
     # ---- frames packed one update ahead (vdqn_step_args.packed_frames) -----------------------------------------------------
+    def _dist_early_ok(self) -> bool:
+        """Per-bucket Adam under an exchange (VDQN_DIST_EARLY_ADAM) is taken only where it is right: modes 2 / 3 are one-rank
+        diagnostics (mode 2 would update with gradients that have not been reduced) and raise with more ranks; mode 1 needs a
+        backend whose Work.wait() orders the STREAM (RCCL) — gloo's blocks the host thread, which would serialise the enqueue of the
+        remaining backward stages — and falls back to the finish-time update elsewhere."""
+        ok = getattr(self, "_dist_early_checked", None)
+        if ok is None:
+            ok = True
+            if self.world_size > 1:
+                if _DIST_EARLY_ADAM_MODE in ("2", "3"):
+                    raise RuntimeError("VDQN_DIST_EARLY_ADAM=2/3 are one-rank diagnostics: with world_size > 1 they apply unreduced gradients")
+                try:
+                    import torch.distributed as dist
+                    ok = not dist.is_initialized() or dist.get_backend() == "nccl"
+                except Exception:  # noqa: BLE001 - a caller-supplied exchange without torch.distributed
+                    ok = True
+            self._dist_early_checked = ok
+        return ok
+
     @staticmethod
     def _frames_key(before, after, src_kind):
         # identity AND content version: a loop that refills fixed staging buffers in place (copy_ advances `_version`) announces
@@ -405,10 +403,9 @@ class TDStepper:
         half = buf.numel() // 2
         dt = _lib.VDQN_BF16 if n.dtype_name == "bf16" else _lib.VDQN_F32
         main = torch.cuda.current_stream()
-        with (self._aux_stream_ctx() if _AUX_STREAM else self._grad_stream_ctx()):
+        with self._grad_stream_ctx():
             # the announced tensors may have been produced on the caller's stream a moment ago (a host-to-device copy, a gather)
             torch.cuda.current_stream().wait_stream(main)
-            self._aux_used = self._aux_used or _AUX_STREAM
             _lib.check(self.lib.vdqn_pack_input(_ptr(nb), int(nk), buf.data_ptr(), nf, dt, _stream()), "vdqn_pack_input")
             if na is not None and not self.gtb:
                 _lib.check(self.lib.vdqn_pack_input(_ptr(na), int(nk), buf.data_ptr() + half, nf, dt, _stream()), "vdqn_pack_input")
@@ -423,14 +420,10 @@ class TDStepper:
         the packed copies); `optimizer_step` then only covers what is left.  Same arithmetic, same results."""
         n = self.net
         self._adam_done = []
-        prefolded = 0
         keep = (before, after, act, rew, term, valid, gt)  # keep inputs alive until the launches are queued
         with torch.cuda.device(n.device):
             a = self._args(before, after, src_kind, act, rew, term, valid if valid is not None else self._ones, gt)
             st = _stream()
-            if self._aux_used:  # what the previous update queued on the auxiliary stream (packed frames, folded weights) is consumed now
-                torch.cuda.current_stream().wait_stream(self._aux_stream)
-                self._aux_used = False
             ahead, self._ahead = self._ahead, None
             slot = None
             if ahead is not None and ahead[0] == self._frames_key(before, after, src_kind):
@@ -438,10 +431,15 @@ class TDStepper:
                 a.packed_frames = self._packed_buffer(slot).data_ptr()
             _lib.check(self.lib.vdqn_net_td_forward(n.handle, C.byref(a), st), "vdqn_net_td_forward")
             if next_frames is not None:
-                # (next_frames may alias this call's tensors — a loop that replays the same resident minibatch: the pack made now is
-                # valid as long as the tensors are not rewritten.  A loop that REFILLS them in place advances `_version`, the key
-                # announced here then differs from the one that arrives, and the stale pack is discarded: _frames_key)
-                self._pack_ahead(next_frames, 1 if slot == 0 else 0)
+                # next_frames that ALIAS this call's tensors (same storage) are packed ahead only under the caller's explicit promise
+                # that the content stays as it is — a fourth element True: a loop that replays one resident minibatch.  Without the
+                # promise an aliased announcement is ignored (the next call packs its own frames, always correct): `_version` in
+                # _frames_key catches in-place refills through torch ops, but not writes through `.data`, DLPack / numpy views or a
+                # native kernel's pointer, and a stale pack would train on the previous minibatch without any error.
+                nb_, na_ = next_frames[0], next_frames[1]
+                aliased = nb_.data_ptr() == before.data_ptr() or (na_ is not None and after is not None and na_.data_ptr() == after.data_ptr())
+                if not aliased or (len(next_frames) > 3 and next_frames[3] is True):
+                    self._pack_ahead(next_frames[:3], 1 if slot == 0 else 0)
             if not n.extra_capacity:  # train-mode BatchNorm: model(before) [+ model(after)], F feature calls each
                 n.num_batches_tracked += (1 if self.gtb else 2) * n.num_frames
                 n.mark_dirty()  # the running statistics changed: eval-mode packed weights are stale
@@ -455,7 +453,7 @@ class TDStepper:
                         self.allreduce(self.grads[b:e], stage)
                         if stage == 2 and self.allreduce_loss is not None:
                             self.allreduce_loss(self.loss)
-                    if _DIST_EARLY_ADAM and stage < 2 and self.allreduce_wait is not None and n.extra_capacity:
+                    if _DIST_EARLY_ADAM and stage < 2 and self.allreduce_wait is not None and n.extra_capacity and self._dist_early_ok():
                         b4, e4 = (b + 3) // 4 * 4, e // 4 * 4
                         if e4 > b4:
                             if self._post_stream is None:
@@ -476,33 +474,8 @@ class TDStepper:
                     if e > b:
                         with self._grad_stream_ctx():
                             self._adam_range(b, e, self.adam_step + 1)
-                            # ... and the stage's packed weights for the NEXT update right behind it (nothing in this update reads
-                            # them any more: the stage's data gradients are done), so that update starts with a 0.7 M-parameter fold
-                            # instead of a 12.4 M one in front of its first convolution
-                            if _EARLY_FOLD and (b, e) == tuple(self.stage_ranges[stage]):
-                                fold_ctx = contextlib.nullcontext()
-                                if _AUX_STREAM:
-                                    done = torch.cuda.Event()
-                                    done.record()  # this stage's Adam, on the gradient stream
-                                    fold_ctx = self._aux_stream_ctx()
-                                with fold_ctx:
-                                    if _AUX_STREAM:
-                                        torch.cuda.current_stream().wait_event(done)
-                                        self._aux_used = True
-                                    _lib.check(self.lib.vdqn_net_pack_weights_stage(n.handle, _ptr(n.params), _ptr(n.bnstats), _ptr(self.packed_online),
-                                                                                    1, stage, _stream()), "vdqn_net_pack_weights_stage")
-                                prefolded |= 1 << stage
                         self._adam_done.append((b, e))
-        self._prefolded = prefolded
         del keep
-
-    def _aux_stream_ctx(self):
-        ptr = self.lib.vdqn_net_aux_stream(self.net.handle)
-        if not ptr:
-            return contextlib.nullcontext()
-        if self._aux_stream is None or self._aux_stream.cuda_stream != ptr:
-            self._aux_stream = torch.cuda.ExternalStream(ptr, device=self.net.device)
-        return torch.cuda.stream(self._aux_stream)
 
     def _grad_stream_ctx(self):
         ptr = self.lib.vdqn_net_grad_stream(self.net.handle)
@@ -534,7 +507,6 @@ class TDStepper:
                     self._adam_range(pos, b, self.adam_step)
                 pos = max(pos, e)
         n.mark_dirty()
-        self._prefold_key = n.version_key() if self._prefolded else None
 
     def step(self, before, after, src_kind, act, rew, term, valid=None, gt=None, finish_allreduce=None, next_frames=None) -> torch.Tensor:
         """One iteration of the reference loop body (train_q_network.py:213-227).  Returns the device loss scalar
@@ -542,8 +514,9 @@ class TDStepper:
 
         next_frames = (before, after, src_kind) of the NEXT call, if the loop already has them (the reference's DataLoader does: it
         prefetches): they are normalised and packed for the stem while this update's head and backward pass run, instead of at
-        the start of the next update.  The tensors must not change until that call; a call whose frames are not the ones
-        announced packs its own, as always.  Same arithmetic, same results — and, measured, a SLOWER update (5.81 against 5.74 ms,
+        the start of the next update.  The tensors must not change until that call (refills must go through version-bumping torch
+        ops such as copy_; tensors that alias THIS call's are accepted only as (before, after, src_kind, True) — the caller's promise
+        that they are replayed unchanged); a call whose frames are not the ones announced packs its own, as always.  Same arithmetic, same results — and, measured, a SLOWER update (5.81 against 5.74 ms,
         profiles/r03w_ab_pack_ahead.txt: the HBM-bound pack beside layer4 and the head costs more than the start of the update
         gains), so neither bench.py nor the trainer uses it by default; it stays for callers whose frames arrive packed
         (vdqn_step_args.packed_frames)."""

@@ -27,9 +27,8 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
            relu: bool = False, mode: int = 0, pix_stride: Optional[int] = None, ci: Optional[int] = None,
            want_f32: bool = False, ldo: Optional[int] = None, want_colsum: bool = False,
            wt2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None, co2: int = 0, relu2: bool = False,
-           in2: Optional[torch.Tensor] = None, splitk_ws: Optional[torch.Tensor] = None):
+           in2: Optional[torch.Tensor] = None):
     """x: [n, hi, wi, c] NHWC; wt: [co_pad, r, s, ci].  Returns out [n, ho, wo, ldo] (and the f32 copy).
-    splitk_ws: scratch of splitk_workspace_bytes() bytes (uint8) for the split-K remainder of the nine-tap window kernel.
     Fused sibling 1x1 / stride 2 (include/vdqn.h): forward — wt2 [co2, 1, 1, ci] (+ bias2, relu2) gives a second output
     (returned after `out`); data gradient — in2 [n, hi, wi, ci2] and wt2 [co, 1, 1, ci2] add the sibling's gradient."""
     lib = _lib.load()
@@ -65,19 +64,12 @@ def conv2d(x: torch.Tensor, wt: torch.Tensor, *, ho: int, wo: int, co: int, r: i
             n_tiles = (n * ho * wo + rows - 1) // rows
         part = torch.empty((n_tiles, ldo), dtype=torch.float32, device=x.device)
     a.colsum_part = _ptr(part)
-    if splitk_ws is not None:
-        a.splitk_ws, a.splitk_ws_bytes = _ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size()
     _lib.check(lib.vdqn_conv2d(C.byref(a), _stream()), "vdqn_conv2d")
     if out2 is not None:
         return out, out2
     if want_colsum:
         return out, part
     return (out, out_f32) if want_f32 else out
-
-
-def splitk_workspace_bytes() -> int:
-    """Bytes of the `splitk_ws` scratch that serve any conv2d call (include/vdqn.h)."""
-    return int(_lib.load().vdqn_conv2d_splitk_workspace_bytes())
 
 
 def conv2d_wgrad(gy: torch.Tensor, x: torch.Tensor, *, co: int, r: int, s: int, stride: int, pad: int,

@@ -303,9 +303,11 @@ class RankShardedFrameStore:
         self.threads = int(threads) if threads else max(1, min(16, (os.cpu_count() or 2) // 2))
         self._lib = _lib.load()
         self._chunk = int(chunk_frames)
-        stage = torch.empty((self._chunk, 224, 224, 3), dtype=torch.uint8)
-        self._stage = stage.pin_memory() if self.cuda else stage
-        self.frames = torch.empty((0, 224, 224, 3), dtype=torch.uint8, device=self.device)
+        self._stage = []
+        for _ in range(2):
+            stage = torch.empty((self._chunk, 224, 224, 3), dtype=torch.uint8)
+            self._stage.append(stage.pin_memory() if self.cuda else stage)
+        self.frames = None
         self.resident_frames = 0
         self.total_frames = sum(m.shape[0] for m in self._maps)
 
@@ -316,17 +318,40 @@ class RankShardedFrameStore:
         """Bytes of frames resident on this rank for the current epoch."""
         return self.resident_frames * FRAME_BYTES
 
+    def _epoch_samples(self, batch_size: int, seed: int, epoch: int) -> np.ndarray:
+        per_rank = (self.n // self.world // batch_size) * batch_size
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed + epoch)
+        return torch.randperm(self.n, generator=g)[self.rank::self.world][:per_rank].numpy()
+
+    def epoch_frames(self, batch_size: int, seed: int, epoch: int = 0) -> int:
+        """Number of distinct frames this rank's samples of ``epoch`` reference (what _load_epoch will make resident)."""
+        idx = self._epoch_samples(batch_size, seed, epoch)
+        return int(np.unique(np.concatenate([self._before[idx].reshape(-1), self._after[idx].reshape(-1)])).shape[0])
+
     def _load_epoch(self, idx: np.ndarray):
         fb, fa = self._before[idx], self._after[idx]
         need = np.unique(np.concatenate([fb.reshape(-1), fa.reshape(-1)]))
-        if self.frames.shape[0] < need.shape[0]:
-            self.frames = torch.empty((need.shape[0], 224, 224, 3), dtype=torch.uint8, device=self.device)
+        if self.frames is None or self.frames.shape[0] < need.shape[0]:
+            self.frames = None  # release the old buffer first: the peak is one subset, not two
+            cap = min(self.total_frames, need.shape[0] + need.shape[0] // 16 + 1)
+            self.frames = torch.empty((cap, 224, 224, 3), dtype=torch.uint8, device=self.device)
         addr = self._base[need // self._shard_frames] + (need % self._shard_frames).astype(np.uint64) * np.uint64(FRAME_BYTES)
-        for lo in range(0, need.shape[0], self._chunk):
+        busy = [None, None]  # event behind the last copy that read each staging buffer
+        for k, lo in enumerate(range(0, need.shape[0], self._chunk)):
             a = np.ascontiguousarray(addr[lo:lo + self._chunk])
-            if self._lib.vdqn_host_gather(self._stage.data_ptr(), a.ctypes.data, a.shape[0], FRAME_BYTES, self.threads) != 0:
+            stage = self._stage[k & 1]
+            if busy[k & 1] is not None:
+                busy[k & 1].synchronize()
+            if self._lib.vdqn_host_gather(stage.data_ptr(), a.ctypes.data, a.shape[0], FRAME_BYTES, self.threads) != 0:
                 raise RuntimeError("vdqn_host_gather failed")
-            self.frames[lo:lo + a.shape[0]].copy_(self._stage[:a.shape[0]], non_blocking=False)  # (blocking: the staging buffer is reused)
+            self.frames[lo:lo + a.shape[0]].copy_(stage[:a.shape[0]], non_blocking=self.cuda)
+            if self.cuda:
+                busy[k & 1] = torch.cuda.Event()
+                busy[k & 1].record()
+        for ev in busy:
+            if ev is not None:
+                ev.synchronize()
         self.resident_frames = int(need.shape[0])
         self._b_local = torch.from_numpy(np.searchsorted(need, fb)).to(self.device)  # [per_rank, nf] positions inside the resident subset
         self._a_local = torch.from_numpy(np.searchsorted(need, fa)).to(self.device)
@@ -339,9 +364,7 @@ class RankShardedFrameStore:
             raise ValueError(f"dataset of {self.n} samples is smaller than one global batch ({batch_size} x {self.world})")
         epoch = 0
         while True:
-            g = torch.Generator(device="cpu")
-            g.manual_seed(seed + epoch)
-            idx = torch.randperm(self.n, generator=g)[self.rank::self.world][:per_rank].numpy()
+            idx = self._epoch_samples(batch_size, seed, epoch)
             self._load_epoch(idx)
             for lo in range(0, per_rank, batch_size):
                 sl = slice(lo, lo + batch_size)
@@ -450,11 +473,24 @@ class HostFrameStream:
                         self._slot_free[slot] = ev
                     else:
                         dev, idx_d, ev = buf.clone(), idx_t, None
-                    self._q.put((dev, idx_d, ev))
+                    if not self._put((dev, idx_d, ev)):
+                        return
                 epoch += 1
         except BaseException as e:  # noqa: BLE001 - handed to the consumer, which re-raises it
             self._err = e
-            self._q.put(None)
+            self._put(None)
+
+    def _put(self, item) -> bool:
+        """Queue ``item`` for the consumer; gives up (False) once close() has been called, so a full queue never holds the
+        producer thread behind a consumer that has gone."""
+        import queue
+        while not self._stop:
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def batches(self):
         """Endless stream of device batches, the tuple of DeviceFrameStore.gather: (before, after, 0, act, rew, term, valid, gt)."""
@@ -476,12 +512,45 @@ class HostFrameStream:
             yield (b, a, 0, self.act.index_select(0, idx), self.rew.index_select(0, idx), self.term.index_select(0, idx),
                    self.valid.index_select(0, idx), self.gt.index_select(0, idx))
 
-    def close(self):
+    def close(self, timeout: float = 30.0):
+        """Stop the producer thread and JOIN it (it may be inside vdqn_host_gather, reading the memory maps, or queueing copies
+        on the prefetch stream: neither may outlive this object), wait for the copies it queued, release the pinned slots."""
+        import queue
+        import time
         self._stop = True
+        t = getattr(self, "_thread", None)
+        deadline = time.monotonic() + timeout
+        while t is not None and t.is_alive():
+            try:
+                while True:
+                    self._q.get_nowait()
+            except queue.Empty:
+                pass
+            t.join(0.05)
+            if time.monotonic() > deadline:
+                raise RuntimeError("the host frame stream's producer thread did not stop")
         try:
             while True:
                 self._q.get_nowait()
-        except Exception:  # noqa: BLE001 - queue.Empty
+        except queue.Empty:
+            pass
+        if self._stream is not None:
+            self._stream.synchronize()
+        self._slots, self._slot_free, self._maps = [], [], []
+        self._thread = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_thread", None) is not None:
+                self.close(timeout=5.0)
+        except Exception:  # noqa: BLE001 - interpreter teardown
             pass
 
 

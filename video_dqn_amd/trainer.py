@@ -150,22 +150,39 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
             resident = str(getattr(config, "DEVICE_RESIDENT_DATA", "auto")).lower()
             if resident not in ("auto", "on", "off"):
                 raise ValueError("DEVICE_RESIDENT_DATA must be 'auto', 'on' or 'off'")
-            if resident != "auto":
+            sharded = world_size > 1 and bool(getattr(config, "RANK_SHARDED_DATA", True))
+            gather_threads = int(getattr(config, "HOST_GATHER_THREADS", 0))
+            headroom = 32 << 30  # activations, workspaces, allocator slack
+            if sharded and resident != "off":
+                # N ranks: each holds only the frames its samples of the current epoch reference (re-uploaded per epoch), not a full
+                # copy of the dataset; same minibatch sequence as the full per-rank copy.  Residency is decided from THIS rank's
+                # subset (epoch 0's distinct frames + 10 % for later epochs), one decision for the whole job: a rank on another
+                # input path would draw from a different sharding of the epoch than the resident ones
+                from .shards import RankShardedFrameStore
+                store = RankShardedFrameStore(config.DATASET, config.device, rank, world_size, threads=gather_threads, **kw)
+                need = store.epoch_frames(B, config.SEED) * 224 * 224 * 3
+                free, _ = torch.cuda.mem_get_info(torch.device(config.device))
+                fits = agree_all(need + need // 10 + headroom < free, device=config.device)
+                if not fits and resident == "on":
+                    raise RuntimeError(f"DEVICE_RESIDENT_DATA: 'on', but this rank's share of the frames ({need / 2**30:.1f} GiB + "
+                                       f"{headroom >> 30} GiB of headroom) does not fit in {free / 2**30:.1f} GiB of free HBM on every rank")
+                if fits:
+                    log(f"dataset resident in HBM, sharded by rank: the frames of this rank's samples are uploaded per epoch "
+                        f"({need / 2**30:.2f} GiB of the dataset's {store.total_frames * 224 * 224 * 3 / 2**30:.2f} GiB)")
+                else:
+                    store = None
+                    log(f"this rank's share of the frames ({need / 2**30:.1f} GiB) does not fit in HBM on every rank: streaming")
+                resident = fits
+            elif resident != "auto":
                 resident = resident == "on"
             else:  # frames + 32 GiB of headroom must fit in the GPU's free memory
                 n_frames = sum(np.load(p_, mmap_mode="r").shape[0] for p_ in dataset._paths)
                 free, _ = torch.cuda.mem_get_info(torch.device(config.device))
-                resident = n_frames * 224 * 224 * 3 + (32 << 30) < free
-                if world_size > 1:  # one decision for the whole job: a rank on the loader path would draw from a different
-                    resident = agree_all(resident, device=config.device)  # sharding of the epoch than the resident ones
-            if resident and world_size > 1 and bool(getattr(config, "RANK_SHARDED_DATA", True)):
-                # N ranks: each holds only the frames its samples of the current epoch reference (re-uploaded per epoch), not a full
-                # copy of the dataset; same minibatch sequence as the full per-rank copy
-                from .shards import RankShardedFrameStore
-                store = RankShardedFrameStore(config.DATASET, config.device, rank, world_size,
-                                              threads=int(getattr(config, "HOST_GATHER_THREADS", 0)), **kw)
-                log(f"dataset resident in HBM, sharded by rank: the frames of this rank's samples are uploaded per epoch "
-                    f"(dataset: {store.total_frames * 224 * 224 * 3 / 2**30:.2f} GiB)")
+                resident = n_frames * 224 * 224 * 3 + headroom < free
+                if world_size > 1:
+                    resident = agree_all(resident, device=config.device)
+            if store is not None:
+                pass
             elif resident:
                 from .shards import DeviceFrameStore
                 store = DeviceFrameStore(config.DATASET, config.device, **kw)
@@ -175,7 +192,7 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
                 # host-to-device copies on a prefetch stream — same minibatch sequence as the resident store
                 from .shards import HostFrameStream
                 stream = HostFrameStream(config.DATASET, config.device, B, config.SEED, rank, world_size,
-                                         threads=int(getattr(config, "HOST_GATHER_THREADS", 0)), **kw)
+                                         threads=gather_threads, **kw)
                 log(f"dataset streamed from memory-mapped shards: {stream.threads} gather threads, {len(stream._slots)} pinned staging buffers")
         else:
             dataset = QLearningRealDataset(config.DATASET, as_uint8=True, **kw)
@@ -254,52 +271,54 @@ def run_train(config, resume_from=-1, max_steps=None, rank=0, world_size=1, log=
         v = float(host_loss[slot])
         running_loss = v if running_loss is None else running_loss * 0.99 + v * 0.01  # :228-231
 
-    while sample_number < num_steps:
-        sample_number += 1
-        model.set_train()  # :221 (flags only; the engine's BatchNorm is always in eval mode in extra_capacity)
-        before, after, src_kind, act, rew, term, valid, gt = next(iterator)
-        # the stepper performs the :215-216 target refresh itself (sample_number % TARGET_UPDATE_INTERVAL == 0)
-        loss = stepper.step(before, after, src_kind, act, rew, term,
-                            valid if config.REMOVE_BEFORE_REWARD else None,
-                            gt if config.TRAIN_ON_GROUND_TRUTH else None,
-                            finish_allreduce=(comm.finish if comm else None))
-        # every rank's `loss` is its share of the global mean (the TD kernel divides by the global batch): their SUM is the
-        # batch-mean loss the reference feeds into its running average every update (:228-231).  The stepper has queued that
-        # 4-byte all-reduce on the gradient stream behind the last gradient bucket (dist.launch_loss); it is waited for and
-        # copied to the host on the read-back stream only — the compute stream, i.e. the next update's first kernel, never
-        # waits for it — so the average that is printed, logged and returned is still the reference's: an EMA of the true
-        # global batch-mean loss, one update late like the single-process read-back
-        slot = sample_number & 1
-        ev = torch.cuda.Event()
-        reduced = comm.take_loss() if comm is not None else None
-        if reduced is not None:
-            buf, work = reduced
-            if loss_stream is None:
-                loss_stream = torch.cuda.Stream(device=model.engine.device)
-            with torch.cuda.stream(loss_stream):
-                work.wait()
-                host_loss[slot:slot + 1].copy_(buf, non_blocking=True)
-                ev.record(loss_stream)
-        else:
-            host_loss[slot:slot + 1].copy_(loss, non_blocking=True)
-            ev.record()
+    try:  # (the streaming input path owns a thread, pinned buffers and a prefetch stream: released on every exit)
+        while sample_number < num_steps:
+            sample_number += 1
+            model.set_train()  # :221 (flags only; the engine's BatchNorm is always in eval mode in extra_capacity)
+            before, after, src_kind, act, rew, term, valid, gt = next(iterator)
+            # the stepper performs the :215-216 target refresh itself (sample_number % TARGET_UPDATE_INTERVAL == 0)
+            loss = stepper.step(before, after, src_kind, act, rew, term,
+                                valid if config.REMOVE_BEFORE_REWARD else None,
+                                gt if config.TRAIN_ON_GROUND_TRUTH else None,
+                                finish_allreduce=(comm.finish if comm else None))
+            # every rank's `loss` is its share of the global mean (the TD kernel divides by the global batch): their SUM is the
+            # batch-mean loss the reference feeds into its running average every update (:228-231).  The stepper has queued that
+            # 4-byte all-reduce on the gradient stream behind the last gradient bucket (dist.launch_loss); it is waited for and
+            # copied to the host on the read-back stream only — the compute stream, i.e. the next update's first kernel, never
+            # waits for it — so the average that is printed, logged and returned is still the reference's: an EMA of the true
+            # global batch-mean loss, one update late like the single-process read-back
+            slot = sample_number & 1
+            ev = torch.cuda.Event()
+            reduced = comm.take_loss() if comm is not None else None
+            if reduced is not None:
+                buf, work = reduced
+                if loss_stream is None:
+                    loss_stream = torch.cuda.Stream(device=model.engine.device)
+                with torch.cuda.stream(loss_stream):
+                    work.wait()
+                    host_loss[slot:slot + 1].copy_(buf, non_blocking=True)
+                    ev.record(loss_stream)
+            else:
+                host_loss[slot:slot + 1].copy_(loss, non_blocking=True)
+                ev.record()
+            if pending is not None:
+                consume(pending)
+            pending = (slot, ev)
+            log_now = sample_number % 100 == 0 and rank == 0 and hasattr(config, "writer")
+            if log_now:  # the reference logs the average INCLUDING this update's loss (:228-238): take it in before writing
+                consume(pending)
+                pending = None
+            if rank == 0 and running_loss is not None:
+                print(f"\rbatch:{sample_number}/{config.NUM_STEPS} avg_loss: {running_loss}", end="")
+            if log_now and running_loss is not None:
+                config.writer.add_scalar("avg_q_loss/train", running_loss, sample_number)  # :236-238
+            if sample_number % config.CHECKPOINT_INTERVAL == 0 and rank == 0:  # :241-247
+                torch.cuda.synchronize()
+                save_checkpoint(f"{config.folder}/models/sample{sample_number}.torch", sample_number, model, stepper)
         if pending is not None:
             consume(pending)
-        pending = (slot, ev)
-        log_now = sample_number % 100 == 0 and rank == 0 and hasattr(config, "writer")
-        if log_now:  # the reference logs the average INCLUDING this update's loss (:228-238): take it in before writing
-            consume(pending)
-            pending = None
-        if rank == 0 and running_loss is not None:
-            print(f"\rbatch:{sample_number}/{config.NUM_STEPS} avg_loss: {running_loss}", end="")
-        if log_now and running_loss is not None:
-            config.writer.add_scalar("avg_q_loss/train", running_loss, sample_number)  # :236-238
-        if sample_number % config.CHECKPOINT_INTERVAL == 0 and rank == 0:  # :241-247
-            torch.cuda.synchronize()
-            save_checkpoint(f"{config.folder}/models/sample{sample_number}.torch", sample_number, model, stepper)
-    if pending is not None:
-        consume(pending)
-    torch.cuda.synchronize()
-    if stream is not None:
-        stream.close()
+        torch.cuda.synchronize()
+    finally:
+        if stream is not None:
+            stream.close()
     return model, stepper, running_loss
