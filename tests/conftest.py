@@ -11,7 +11,8 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "refonly: needs /root/reference (build container only)")
-    config.addinivalue_line("markers", "variants: A/B switch variants of the default path; run only with VDQN_TEST_VARIANTS=1 (tools/job.sh suite)")
+    config.addinivalue_line("markers", "variants: A/B switch variants of the default path; run only with VDQN_TEST_VARIANTS=1 (tools/job.sh variants)")
+    config.addinivalue_line("markers", "slow_oracle: minutes of CPU-oracle time at a full-size geometry; run only with VDQN_TEST_SLOW=1 (tools/job.sh slow)")
 
 
 # Collection order of the GPU suite: a time limit must cut the multi-process tests, never the tests that
@@ -49,13 +50,14 @@ def _rank(item):
 
 
 def pytest_collection_modifyitems(config, items):
-    if os.environ.get("VDQN_TEST_VARIANTS", "0") != "1":
-        keep, drop = [], []
-        for it in items:
-            (drop if it.get_closest_marker("variants") else keep).append(it)
-        if drop:
-            config.hook.pytest_deselected(items=drop)
-            items[:] = keep
+    for marker, env in (("variants", "VDQN_TEST_VARIANTS"), ("slow_oracle", "VDQN_TEST_SLOW")):
+        if os.environ.get(env, "0") != "1":
+            keep, drop = [], []
+            for it in items:
+                (drop if it.get_closest_marker(marker) else keep).append(it)
+            if drop:
+                config.hook.pytest_deselected(items=drop)
+                items[:] = keep
     order = {id(it): n for n, it in enumerate(items)}
     items.sort(key=lambda it: (_rank(it), order[id(it)]))
 

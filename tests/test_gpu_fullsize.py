@@ -213,7 +213,10 @@ def _bf16_emulation_check(B, F, tup, net, stp, failures, notes):
         failures.append(("bf16 loss vs emulating oracle", stp.loss.item(), loss_e))
 
 
-@pytest.mark.parametrize("B,F,seed", [(256, 1, 501), (16, 12, 502)], ids=["C2_batch256", "C5_12views_batch16"])
+# (C5: four oracle passes over 576 frames, two of them in float64 = five minutes of host time for one test.  Under the driver's plain
+# `-m gpu` the 12-view geometry is covered by test_full_size_step_properties[C5] (f32 engine vs bf16 engine, overlap, determinism) and
+# by the F = 4 oracle tests; this case runs with VDQN_TEST_SLOW=1 — tools/job.sh slow — and its log is committed under profiles/)
+@pytest.mark.parametrize("B,F,seed", [(256, 1, 501), pytest.param(16, 12, 502, marks=pytest.mark.slow_oracle)], ids=["C2_batch256", "C5_12views_batch16"])
 def test_full_size_step_vs_oracle(B, F, seed):
     """One TD update at the benchmarked geometry (train_q_network.py:126-181,226), engine against oracle on the same minibatch:
 

@@ -3,6 +3,7 @@
 #     tools/gpu_job.sh <timeout_s> 'bash tools/job.sh <TAG> <recipe> [<recipe> ...]'
 # Every recipe writes under gpurun_out/<TAG>/; what is to be judged is then copied into profiles/ by hand.
 #   suite          the GPU test suite as the driver runs it (plain pytest -m gpu, 1150 s limit, --durations) + smoke(), logs + return codes
+#   slow           the full-size CPU-oracle cases (VDQN_TEST_SLOW=1, -m 'gpu and slow_oracle')
 #   variants       the switch-variant tests (VDQN_TEST_VARIANTS=1, -m 'gpu and variants')
 #   tests:<expr>   pytest -m gpu -k "<expr>" (underscores for spaces: tests:vs_oracle_or_emulating)
 #   bench          three default bench.py runs in a row (the first with the CPU baseline)
@@ -28,6 +29,8 @@ for recipe in "$@"; do
              t0=$(date +%s); timeout 1150 python -m pytest tests -m gpu -q --maxfail=8 --durations=60 --durations-min=1.5 > "$O/pytest_gpu.log" 2>&1; echo "pytest rc=$? wall=$(( $(date +%s) - t0 ))s" >> "$O/pytest_gpu.log"
              timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1; echo "smoke rc=$?" >> "$O/smoke.log"
              tail -4 "$O/pytest_gpu.log" | cut -c1-300; tail -2 "$O/smoke.log" | cut -c1-200 ;;
+    slow)    # the full-size CPU-oracle cases the plain suite deselects (@pytest.mark.slow_oracle)
+             t0=$(date +%s); VDQN_TEST_SLOW=1 timeout 1500 python -m pytest tests -m "gpu and slow_oracle" -q > "$O/pytest_slow_oracle.log" 2>&1; echo "pytest rc=$? wall=$(( $(date +%s) - t0 ))s" >> "$O/pytest_slow_oracle.log"; tail -3 "$O/pytest_slow_oracle.log" | cut -c1-300 ;;
     variants) # the A/B switch variants the plain suite deselects (tests/conftest.py: @pytest.mark.variants)
              t0=$(date +%s); VDQN_TEST_VARIANTS=1 timeout 2400 python -m pytest tests -m "gpu and variants" -q --maxfail=8 > "$O/pytest_variants.log" 2>&1; echo "pytest rc=$? wall=$(( $(date +%s) - t0 ))s" >> "$O/pytest_variants.log"; tail -3 "$O/pytest_variants.log" | cut -c1-300 ;;
     tests)   timeout 2400 python -m pytest tests -m gpu -q -k "${arg//_or_/ or }" > "$O/pytest_${arg:0:40}.log" 2>&1; echo "pytest rc=$?" >> "$O/pytest_${arg:0:40}.log"; tail -3 "$O/pytest_${arg:0:40}.log" | cut -c1-300 ;;
