@@ -1355,7 +1355,7 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
   if (tst != st) join_side(net, st);  // packed input ready for the online pass
   if (!gtb) {
     const ActLayout T = act_layout(net, B);
-    RC(forward_impl(net, (const unsigned char*)a->packed_target, tin + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst));
+    RC(forward_impl(net, (const unsigned char*)a->packed_target, tin + (int64_t)B * F * frame_bytes, B, (unsigned char*)a->acts_target, T, tst, false, 0));  // (no backward: no arg-max bytes)
   }
   if (net->basic())  // two model calls (before, after), each with its own batch statistics; running stats updated in place
     RC(forward_train_impl(net, (const unsigned char*)a->packed_online, a->params, a->bnstats, tin, ns_online, gtb ? 1 : 2, ao, A, st));
