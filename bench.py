@@ -414,7 +414,12 @@ def main():
             if live_traffic is not None and not live:
                 live_reason = f"the live passes hold no row for {name}"
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": live if live else pmc_traffic(name, B, F, args.dtype, args.arch),
+                        "frac": round(ach / peak, 4),
+                        # the same achieved rate against what THIS box's matrix pipes delivered a moment later on random operands with
+                        # nothing else to do (mfma_clock_under_load.bare_mfma_tflops: the power-limited clock, not the 2.5 PFLOP/s nominal)
+                        "frac_of_measured_bare": (round(ach / mfma_clock["bare_mfma_tflops"], 4) if (mfma_clock and args.dtype == "bf16"
+                                                                                                    and mfma_clock["bare_mfma_tflops"] > 0) else None),
+                        "traffic": live if live else pmc_traffic(name, B, F, args.dtype, args.arch),
                         "traffic_source": ("live: two rocprofv3 child passes of this command (--kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE; "
                                            "2 steps, side streams serialised) run after the timed region; 2 x FETCH_SIZE + WRITE_SIZE per launch"
                                            if live else

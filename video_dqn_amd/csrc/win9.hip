@@ -427,7 +427,9 @@ int vdqn_launch_win9u(const void* pv, int mode, hipStream_t stream) {
     const long long tiles128 = (long long)p.tiles_m * p.tiles_n, res128 = 2ll * vdqn_num_cus();
     const double r = (double)tiles128 / (double)res128;  // rounds of the 128-row tiles (p.tiles_m counts those)
     const double frac = r - (double)(long long)r;
-    big = r >= 0.7 && frac >= 0.45;
+    // (layer4 at 192 frames — config 5's target and backward passes, 0.58 rounds — gains 4 % on 256-row tiles, every other layer at
+    // 192 / 384 frames stays on 128 rows: profiles/r6_06_bench_conv_192_384_frames_tile_rule.txt)
+    big = r >= (p.ci >= 512 ? 0.55 : 0.7) && frac >= 0.45;
   }
   void* stamps = nullptr;
 #ifdef VDQN_STAMP
