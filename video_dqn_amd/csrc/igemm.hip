@@ -1118,11 +1118,7 @@ constexpr int kC64WinRows = 248;                 // 128 + 2 * 56 + 2 = 242 rows,
 constexpr int kC64WinBytes = kC64WinRows * 128;
 constexpr int kC64LoadTap = 4;                   // K-loop tap in front of which the epilogue's residual / mask loads are issued
 constexpr int kC64RegTaps = 7;                   // taps whose weight fragments live in registers; the rest are read from LDS
-#ifndef VDQN_C64_PREFETCH
-#define VDQN_C64_PREFETCH 0
-#endif
-constexpr int kC64PfBytes = VDQN_C64_PREFETCH ? 1024 : 0;  // landing zone of the L2 prefetch (one dword per lane, never read)
-constexpr int kC64Smem = 2 * kC64WinBytes + 256 + 512 + 256 + (9 - kC64RegTaps) * 8192 + kC64PfBytes;  // windows, zero pair, column-sum scratch, bias, LDS taps
+constexpr int kC64Smem = 2 * kC64WinBytes + 256 + 512 + 256 + (9 - kC64RegTaps) * 8192;  // windows, zero pair, column-sum scratch, bias, LDS taps
 
 // HAS_RES / HAS_MSK: whether a residual / a ReLU-mask operand exists is a TEMPLATE parameter — their 16 + 16 registers (loaded in the
 // middle of the K loop for the epilogue) otherwise stay reserved in every instance, and with all 256 VGPRs taken the compiler
@@ -1276,28 +1272,6 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
     unsigned long long* st_row = (p.pool_out && st_k < 16) ? reinterpret_cast<unsigned long long*>(p.pool_out) + ((size_t)blockIdx.x * 16 + st_k) * 8 : nullptr;
     if (st_row && tid == 0) { st_row[0] = st_w0; st_row[1] = __builtin_amdgcn_s_memtime(); }
 #endif
-    // L2 prefetch (-DVDQN_C64_PREFETCH=1): the kernel runs at 0.62 of the achievable HBM rate with one window (31 KB) in flight per
-    // workgroup — latency-bound, and neither LDS nor registers have room for a third window.  One dword per 128-byte pixel row of the
-    // window of the tile AFTER the next (and of its residual rows) is requested by LDS-DMA into a 1 KB landing zone nobody reads: the
-    // lines travel HBM -> L2 a tile early, the real window DMA then finds them in L2.  No VGPR, one instruction per wave and operand.
-    auto c64_prefetch = [&]() {
-      const int t2 = t + 2 * g_blocks;
-      if (t2 >= g_tiles) return;
-      const int tl2 = g_first + (int)xcd_remap((uint32_t)t2, (uint32_t)g_tiles);
-      const uint32_t l_ = lds_base + (uint32_t)(kC64Smem - kC64PfBytes) + (uint32_t)wave_u * 256u;
-      const uint32_t vp = (uint32_t)(tl2 * 128 - W - 1 + tid) * 128u;  // row tid of that window (rows past 247: a few lines more)
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %0, %2, 0 offen lds" ::"v"(vp), "s"(l_), "s"(rs_a) : "memory");
-      if constexpr (HAS_RES) {
-        if (wave_u < 2) {
-          const unsigned long long r_ptr = (unsigned long long)p.resid;
-          const i32x4 rs_r = {__builtin_amdgcn_readfirstlane((int)(unsigned)r_ptr), __builtin_amdgcn_readfirstlane((int)((r_ptr >> 32) & 0xffff)),
-                              __builtin_amdgcn_readfirstlane(io_bytes), 0x00020000};
-          const uint32_t vr = (uint32_t)(tl2 * 128 + tid) * (uint32_t)(p.ldo * 2);
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %0, %2, 0 offen lds" ::"v"(vr), "s"(l_), "s"(rs_r) : "memory");
-        }
-      }
-    };
-    (void)c64_prefetch;
     const bool c64_has_nx = t + g_blocks < g_tiles;
     const int c64_tl_nx = c64_has_nx ? g_first + (int)xcd_remap((uint32_t)(t + g_blocks), (uint32_t)g_tiles) : 0;
     if constexpr (!kSpread) {
@@ -1394,10 +1368,6 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(const IgemmParams p, con
   {                                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
     VDQN_C64_SPREAD_ISSUE(HS)                                                                                               \
-    if constexpr (VDQN_C64_PREFETCH && (HS) == 2 * kC64LoadTap + 1) {                                                       \
-      c64_prefetch();                                                                                                       \
-      __builtin_amdgcn_sched_barrier(0);                                                                                    \
-    }                                                                                                                       \
     if constexpr ((HS) == 2 * kC64LoadTap) {                                                                                \
       if constexpr (HAS_RES) {                                                                                              \
         _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) rv[f_] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)off[f_], 0, 0); \
