@@ -37,6 +37,10 @@ struct WgradParams {
 
 // partial-sum sink of a block: an atomic into dw, or a plain store into the block's split copy (uniform branch)
 __device__ __forceinline__ void wg_emit(float* dst, bool det, float v) {
+#ifdef VDQN_WGRAD_NO_EMIT  // timing-only diagnostic build (results INVALID): the kernels without their partial-sum sink = the bound of
+  asm volatile("" ::"v"(v), "v"(dst));  // any cheaper reduction scheme (tools/bench_wgrad.py, profiles/r6_08_*)
+  return;
+#endif
   if (det) *dst = v;
   else atomicAdd(dst, v);
 }
