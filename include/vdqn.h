@@ -179,6 +179,8 @@ typedef struct vdqn_td_args {
   int32_t clip_rect, linear, use_valid, dtype;
   int32_t loss_kind;      /* 0 = half squared error (reference), 1 = Huber */
   int32_t deterministic;  /* 1: the loss is summed by ONE block in a fixed order (no cross-block atomics) */
+  float* q_copy;          /* optional [batch][n_cat * n_act] f32: a compact copy of q_before's first n_cat * n_act columns (what the
+                             training loop reads back as Q(s)), written by the same launch */
 } vdqn_td_args;
 int vdqn_td_loss(const vdqn_td_args* a, void* stream);
 

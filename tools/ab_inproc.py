@@ -5,7 +5,8 @@ switches that are read per call (module attributes of video_dqn_amd.engine, the 
     python tools/ab_inproc.py [--rounds 8] [--steps 40] base ahead pack separate ...
 modes:  base      default engine, no announcement of the next minibatch
         pack      next minibatch announced and packed under this update's backward pass (TDStepper.step(next_frames=...))
-        <name>:<attr>=<value>[,<attr>=<value>]   base with module attributes of video_dqn_amd.engine set, e.g. late:_EARLY_ADAM=False
+        <name>:<attr>=<value>[,<attr>=<value>]   base with module attributes of video_dqn_amd.engine set, e.g. late:_EARLY_ADAM=False;
+                  lib.<setter>=<int> calls a debug setter of libvdqn instead, e.g. bm128:lib.vdqn_debug_set_win9_bm256=0 (reset to -1 afterwards)
 (Round 6 used it with two more modes — a fused Adam + weight-fold kernel and the next update's target pass run ahead — both measured
 slower: experiments/r6_fused_adam_fold_and_target_ahead.patch, profiles/r6_05_ab_inproc_*.txt.)"""
 import argparse
@@ -49,14 +50,23 @@ def main():
         nxt = (pool[k["i"] % 4][0], pool[k["i"] % 4][1], 0, True) if announce else None
         stp.step(b_, a_, 0, act_, rew_, term_, next_frames=nxt)
 
-    defaults = {}
+    defaults, lib_set = {}, set()
+    import ctypes as C
+    from video_dqn_amd import _lib
+    raw = C.CDLL(_lib.LIB_PATH)
 
     def setup(mode):
         for k_, v_ in defaults.items():
             setattr(eng, k_, v_)
+        for fn in lib_set:
+            getattr(raw, fn)(C.c_int(-1))
         name, _, attrs = mode.partition(":")
         for kv in filter(None, attrs.split(",")):
             k_, v_ = kv.split("=", 1)
+            if k_.startswith("lib."):
+                lib_set.add(k_[4:])
+                getattr(raw, k_[4:])(C.c_int(int(v_)))
+                continue
             defaults.setdefault(k_, getattr(eng, k_))
             setattr(eng, k_, {"True": True, "False": False}.get(v_, v_))
         return name == "pack"

@@ -42,7 +42,7 @@ class TdArgs(C.Structure):
                 ("rew", c_vp), ("term", c_vp), ("valid", c_vp), ("loss", c_vp), ("dq", c_vp), ("dq_f32", c_vp),
                 ("batch", c_i32), ("n_cat", c_i32), ("n_act", c_i32), ("ldq", c_i32),
                 ("gamma", c_f32), ("inv_count", c_f32),
-                ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("dtype", c_i32), ("loss_kind", c_i32), ("deterministic", c_i32)]
+                ("clip_rect", c_i32), ("linear", c_i32), ("use_valid", c_i32), ("dtype", c_i32), ("loss_kind", c_i32), ("deterministic", c_i32), ("q_copy", c_vp)]
 
 
 class NetConfig(C.Structure):

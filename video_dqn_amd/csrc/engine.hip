@@ -208,11 +208,16 @@ void join_side2(vdqn_net* net, hipStream_t main) {
 // Round 4: default ON now that the side streams run below the caller's stream in priority — seven alternating rounds on one box:
 // better in five, equal in two, median 5.828 against 5.900 ms per update (profiles/r04n_ab_wgrad_two_low_priority_streams.txt;
 // at equal priorities round 3 had measured no gain).  VDQN_WGRAD_STREAMS=1 keeps them on one stream.
+int g_wgrad_streams_override = -1;  // tools/ab_inproc.py: vdqn_debug_set_wgrad_streams (1 / 2; -1 = VDQN_WGRAD_STREAMS)
 bool wgrad_two_streams(const vdqn_net* net) {
-  static const bool on = [] { const char* e = getenv("VDQN_WGRAD_STREAMS"); return !e || atoi(e) == 2; }();
+  static const bool env_on = [] { const char* e = getenv("VDQN_WGRAD_STREAMS"); return !e || atoi(e) == 2; }();
+  const bool on = g_wgrad_streams_override > 0 ? g_wgrad_streams_override == 2 : env_on;
   static const bool two_stage = [] { const char* e = getenv("VDQN_WGRAD_TWO_STAGE"); return e && e[0] == '1'; }();
   return on && !two_stage && !net->cfg.deterministic;
 }
+}  // namespace
+extern "C" void vdqn_debug_set_wgrad_streams(int v) { g_wgrad_streams_override = v; }
+namespace {
 hipStream_t wgrad_stream(vdqn_net* net, hipStream_t main) {
   if (!wgrad_two_streams(net)) return fork_side(net, main);
   net->wgrad_rr ^= 1;
@@ -1363,6 +1368,8 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     RC(forward_impl(net, (const unsigned char*)a->packed_online, tin, ns_online, ao, A, st, false, B));
   if (tst != st) join_side(net, st);
 
+  // (clearing the 47 MB of accumulators on a side stream beside the packs instead of here, between the forward pass and the loss,
+  // measured no gain: profiles/r6_12_ab_inproc_fused_head_and_clear_placement.txt)
   hipError_t e = hipMemsetAsync(bw + W.zero_begin, 0, (size_t)W.zero_bytes, st);
   VDQN_CHECK(e == hipSuccess, "vdqn_net_td_forward: memset failed: %s", hipGetErrorString(e));
   e = hipMemsetAsync(a->loss, 0, 4, st);
@@ -1385,12 +1392,13 @@ extern "C" int vdqn_net_td_forward(vdqn_net* net, const vdqn_step_args* a, void*
     t.clip_rect = a->clip_rect; t.linear = a->linear; t.use_valid = a->use_valid; t.dtype = dt;
     t.loss_kind = a->loss_kind;
     t.deterministic = net->cfg.deterministic;
+    t.q_copy = a->q_before;  // (the compact copy of Q(s) rides in the loss launch: no 2-D copy between the loss and the first data gradient)
     RC(vdqn_td_loss(&t, st));
   } else {
     RC(vdqn_gt_loss(qf_online, a->act, a->gt, a->loss, bw + W.dq, nullptr, B, net->cfg.num_classes, net->cfg.action_dim, 64, a->inv_count,
                     a->value_learning, dt, st));
   }
-  if (a->q_before) {
+  if (a->q_before && gtb) {
     const int nq = net->cfg.action_dim * net->cfg.num_classes;
     e = hipMemcpy2DAsync(a->q_before, (size_t)nq * 4, qf_online, 64 * 4, (size_t)nq * 4, (size_t)B, hipMemcpyDeviceToDevice, st);
     VDQN_CHECK(e == hipSuccess, "vdqn_net_td_forward: q copy failed: %s", hipGetErrorString(e));

@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void td_loss_kernel(const vdqn_td_args a) {
     if (col < a.n_cat * a.n_act) {
       const int c = col / a.n_act, ac = col - c * a.n_act;
       const int act = (int)a.act[b];
+      if (a.q_copy) a.q_copy[(size_t)b * (a.n_cat * a.n_act) + col] = a.q_before[(size_t)b * a.ldq + col];
       if (ac == act) {
         const float qb = a.q_before[(size_t)b * a.ldq + col];
         const float* qo = a.q_after_online + (size_t)b * a.ldq + c * a.n_act;

@@ -1212,6 +1212,8 @@ struct WgradPlan {
   long long copy_elems;  // floats per copy
 };
 
+int g_wgrad_win_blocks_override = -1;  // tools/ab_inproc.py: vdqn_debug_set_wgrad_win_blocks
+
 int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
   VDQN_CHECK(a != nullptr, "vdqn_conv2d_wgrad: null args");
   VDQN_CHECK(a->dtype == VDQN_F32 || a->dtype == VDQN_BF16, "vdqn_conv2d_wgrad: bad dtype %d", a->dtype);
@@ -1270,7 +1272,8 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
     // its own (0.903 ms per update for the 13 launches; 384: 0.938, 768: 1.090) — but with the weight gradients alternating between two
     // low-priority streams beside the data-gradient chain, slightly fewer and longer blocks give the shorter UPDATE: 448: 5.636-5.643,
     // 384: 5.648-5.655, 512: 5.653-5.671, 768: 5.746, 256: 5.703 ms (steady box, profiles/r04ab_ab_wgrad_win_blocks.txt)
-    static const int target_w = [] { const char* e = getenv("VDQN_WGRAD_WIN_BLOCKS"); return e ? atoi(e) : 448; }();
+    static const int target_env = [] { const char* e = getenv("VDQN_WGRAD_WIN_BLOCKS"); return e ? atoi(e) : 448; }();
+    const int target_w = g_wgrad_win_blocks_override > 0 ? g_wgrad_win_blocks_override : target_env;
     splitk = a->splitk > 0 ? a->splitk : target_w / pl->tiles;
     if (splitk > max_split) splitk = max_split;
     if (splitk < 1) splitk = 1;
@@ -1282,6 +1285,8 @@ int plan_wgrad(const vdqn_wgrad_args* a, WgradPlan* pl) {
 }
 
 }  // namespace
+
+extern "C" void vdqn_debug_set_wgrad_win_blocks(int v) { g_wgrad_win_blocks_override = v; }  // measurement hook (not part of include/vdqn.h): -1 = VDQN_WGRAD_WIN_BLOCKS
 
 extern "C" int64_t vdqn_conv2d_wgrad_workspace_bytes(const vdqn_wgrad_args* a) {
   WgradPlan pl;
