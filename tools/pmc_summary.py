@@ -50,6 +50,8 @@ def tag_of(kernel_name: str):
     m = re.search(r"wgrad_win_kernel<(\d+)(?:, \d+)?>", kernel_name)
     if m:
         return f"wgrad_win<bf16,{m[1]}>"
+    if re.search(r"wgrad_win_kernel\b(?!<)", kernel_name):  # round 6: the one shipped tiling, no template arguments
+        return "wgrad_win<bf16,64>"
     m = re.search(r"wgrad_kernel<(unsigned short|float), (\d+)>", kernel_name)
     if m:
         return f"wgrad<{'bf16' if m[1] == 'unsigned short' else 'f32'},{m[2]}>"
