@@ -217,6 +217,8 @@ bool wgrad_two_streams(const vdqn_net* net) {
 }
 }  // namespace
 extern "C" void vdqn_debug_set_wgrad_streams(int v) { g_wgrad_streams_override = v; }
+static int g_stem_wgrad_main_override = -1;  // tools/ab_inproc.py (0 / 1; -1 = VDQN_STEM_WGRAD_MAIN)
+extern "C" void vdqn_debug_set_stem_wgrad_main(int v) { g_stem_wgrad_main_override = v; }
 namespace {
 hipStream_t wgrad_stream(vdqn_net* net, hipStream_t main) {
   if (!wgrad_two_streams(net)) return fork_side(net, main);
@@ -1625,7 +1627,8 @@ extern "C" int vdqn_net_backward_stage(vdqn_net* net, const vdqn_step_args* a, i
       // Which stream: the side stream still holds block 0's last two weight gradients when the data-gradient chain ends, so in
       // the default mode this kernel runs on the CALLER's stream beside them (the update's tail on two streams instead of one;
       // its unfold below waits for it).  Deterministic mode keeps it on the side stream: the partial copies share one workspace.
-      static const bool on_main = [] { const char* e = getenv("VDQN_STEM_WGRAD_MAIN"); return !(e && e[0] == '0'); }();
+      static const bool on_main_env = [] { const char* e = getenv("VDQN_STEM_WGRAD_MAIN"); return !(e && e[0] == '0'); }();
+      const bool on_main = g_stem_wgrad_main_override >= 0 ? g_stem_wgrad_main_override != 0 : on_main_env;
       const bool main_st = on_main && split_conv1 && !net->cfg.deterministic;
       return vdqn_stem_wgrad_pool(bw + W.g_pool, ao + A.idx, a->packed_frames ? a->packed_frames : ao + A.t_in, reinterpret_cast<float*>(bw + L1.dw_off), n,
                                   net->cfg.deterministic ? bw + W.det_ws : nullptr, W.det_ws_bytes, main_st ? st : fork_side(net, st));
